@@ -1,0 +1,193 @@
+/*
+ * segan_hip.h — C ABI of libsegan_hip.so, the MI355X (gfx950) kernels behind the
+ * SEGAN+/WSEGAN GAN training step.
+ *
+ * The reference (santi-pdp/segan_pytorch) has no FFI: every FLOP of its hot path is
+ * an implicit ATen op dispatched by a torch.nn module.  Each entry point below
+ * replaces one such implicit op (the reference call site it stands in for is cited
+ * per function); the Python package `segan_pytorch_amd` binds them with ctypes (see
+ * INTEGRATION.md for the stub a reference maintainer would add).
+ *
+ * Conventions
+ *  - all tensors are contiguous fp32, NCL ([batch, channel, time]) like torch;
+ *  - every pointer is a DEVICE pointer owned by the caller (PyTorch's allocator);
+ *    the library never allocates, frees or keeps a pointer past the call;
+ *  - `stream` is a hipStream_t passed as void*; all work is enqueued on it and the
+ *    call returns without synchronising;
+ *  - return value: 0 on success, negative on error; segan_last_error() returns a
+ *    thread-local message.  Nothing throws, nothing calls exit().
+ *
+ * Weight tensors are [m, n, K] in both directions: Conv1d.weight = [Cout, Cin, K]
+ * (m = low-rate side = Cout) and ConvTranspose1d.weight = [Cin, Cout, K] (m = Cin).
+ */
+#ifndef SEGAN_HIP_H
+#define SEGAN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SEGAN_ABI_VERSION 1
+
+#define SEGAN_PAD_REFLECT 0
+#define SEGAN_PAD_ZERO 1
+
+#define SEGAN_ACT_NONE 0
+#define SEGAN_ACT_TANH 1
+
+/* A logical [B, C0+C1, L] activation made of up to two channel segments, with an
+ * optional per-channel transform applied while it is staged into LDS:
+ *     v = x * scale[c] + shift[c];   v = v > 0 ? v : v * slope[c]
+ * (each vector may be NULL = identity; c indexes the concatenated channel axis).
+ * This is how PReLU (modules.py:101), BatchNorm-normalise (modules.py:100), the
+ * skip scale alpha and both torch.cat's (generator.py:76,205) are folded into the
+ * consumer's load instead of being materialised. */
+typedef struct segan_src {
+  const float* p0;
+  const float* p1; /* NULL when C1 == 0 */
+  int32_t C0;
+  int32_t C1;
+  const float* scale;
+  const float* shift;
+  const float* slope;
+} segan_src;
+
+int segan_abi_version(void);
+const char* segan_last_error(void);
+
+/* Bytes of packed-weight workspace segan_pack_weights needs for each form. */
+size_t segan_packed_f_bytes(int M, int N, int S);
+size_t segan_packed_t_bytes(int M, int N, int S);
+
+/* Re-lay w[m][n][K] into the two polyphase packings the contraction kernels read
+ * (either destination may be NULL).  `pad_t` is the transposed-form padding: the
+ * ConvTranspose1d padding for a deconv weight (modules.py:115), 0 for a conv
+ * weight (whose T form is its data gradient in padded coordinates). */
+int segan_pack_weights(const float* w, float* wf, float* wt, int M, int N, int K, int S,
+                       int pad_t, void* stream);
+
+/* GConv1DBlock forward without norm/activation (modules.py:91-99):
+ *   out[b,m,t] = bias[m] + sum_{n,k} w[m,n,k] * pad(roll(x))[b,n,S*t+k]
+ * x: [B, N, L] (segan_src), out: [B, M, L/S].  mode = reflect with
+ * (K/2-1, K/2) padding (stride>1) as the reference, or zero padding `padL`.
+ * `roll` is the discriminator phase shift (discriminator.py:160-172; the conv sees
+ * torch.roll(x, roll, 2)).  The output is the PRE-activation; its consumer applies
+ * PReLU/BN through its own segan_src. */
+int segan_conv1d_fwd(const segan_src* x, const float* wf, const float* bias, float* out, int B,
+                     int N, int M, int L, int K, int S, int padL, int mode, int roll,
+                     void* stream);
+
+/* Data gradient of the above (autograd of modules.py:98-99): dx[b,n,i] += over the
+ * reflect-padded, rolled coordinates.  da: [B, M, L/S]; dx: [B, N, L] is fully
+ * overwritten.  `halo` is scratch of B*N*(K-1) floats. */
+int segan_conv1d_dgrad(const float* da, const float* wt, float* dx, float* halo, int B, int N,
+                       int M, int L, int K, int S, int padL, int roll, void* stream);
+
+/* Weight gradient shared by both layer types (W form):
+ *   dw[m,n,k] += sum_{b,t} lo[b,m,t] * pad(roll(hi))[b,n,S*t+k]
+ * conv:   lo = da (grad of pre-activation), hi = layer input x, reflect padding;
+ * deconv: lo = layer input x (with its transform), hi = dy, zero padding.
+ * Accumulates (atomically) into dw, which is how torch accumulates .grad. */
+int segan_wgrad(const segan_src* lo, const segan_src* hi, float* dw, int B, int M, int N, int Ls,
+                int K, int S, int padL, int mode, int roll, void* stream);
+
+/* GDeconv1DBlock forward (modules.py:135-141): ConvTranspose1d(stride S, padding
+ * `pad`) trimmed to S*Ls samples, + bias, optional tanh (last generator layer).
+ *   y[b,n,j] = bias[n] + sum_{m} sum_{t,k: S*t+k-pad=j} x[b,m,t] * w[m,n,k]
+ * x: [B, M, Ls] as a segan_src (the skip concat and alpha scaling of
+ * generator.py:64-76 are its second segment), y: [B, N, S*Ls]. */
+int segan_deconv1d_fwd(const segan_src* x, const float* wt, const float* bias, float* y, int B,
+                       int M, int N, int Ls, int K, int S, int pad, int act, void* stream);
+
+/* Data gradient of the deconv: dx[b,m,t] = sum_{n,k} w[m,n,k] * dy[b,n,S*t+k-pad].
+ * The M rows are split at M0 into two destinations (dx0: [B,M0,Ls], dx1:
+ * [B,M-M0,Ls]); a NULL destination skips that half's tiles entirely (the z half of
+ * the first decoder layer needs no gradient). */
+int segan_deconv1d_dgrad(const float* dy, const float* wf, float* dx0, float* dx1, int B, int M,
+                         int M0, int N, int Ls, int K, int S, int pad, void* stream);
+
+/* ---- per-channel pointwise / reduction kernels ------------------------------------ */
+
+/* BatchNorm1d training statistics (modules.py:10-11; torch.nn.BatchNorm1d): per
+ * channel mean and biased variance of x[B,C,L]; writes scale = gamma*rstd and
+ * shift = beta - mean*scale for the consumer's segan_src, saves mean/rstd for the
+ * backward, and updates running_mean / running_var (momentum, unbiased variance)
+ * when they are non-NULL.  `ws` is scratch of 3*C*nsplit floats (nsplit from
+ * segan_bn_nsplit, which is also the split count of act_bwd / tanh_bwd). */
+int segan_bn_nsplit(int B, int C, int L);
+int segan_bn_stats(const float* x, const float* gamma, const float* beta, float eps,
+                   float momentum, float* running_mean, float* running_var, float* mean,
+                   float* rstd, float* scale, float* shift, float* ws, int B, int C, int L,
+                   void* stream);
+
+/* y = prelu(x*scale[c] + shift[c], slope[c]) materialised (used for the FC input
+ * h.view(B,-1) of discriminator.py:181 and for int_act / ret_hid outputs). */
+int segan_affine_prelu(const float* x, const float* scale, const float* shift, const float* slope,
+                       float* y, int B, int C, int L, void* stream);
+
+/* Backward through an (optional BN) + PReLU/identity + optional alpha-skip tap of a
+ * pre-activation a[B,C,L]:
+ *   v  = a*scale + shift (BN folded; identity when NULL)
+ *   g  = dh * (v > 0 ? 1 : slope)          (+ alpha * dskip when dskip != NULL)
+ *   dslope += sum dh * min(v, 0) ; dalpha += sum dskip * a ; dbias += sum da
+ *   BN: dbeta += sum g ; dgamma += sum g*xhat ; da = scale*(g - dbeta/N - xhat*dgamma/N)
+ * Any gradient output may be NULL.  ws: scratch of (4*nsplit + 2)*C floats. */
+int segan_act_bwd(const float* a, const float* dh, const float* dskip, const float* slope,
+                  const float* alpha, const float* bn_mean, const float* bn_rstd,
+                  const float* bn_gamma, const float* bn_beta, float* da, float* dslope,
+                  float* dalpha, float* dgamma, float* dbeta, float* dbias, float* ws, int B, int C,
+                  int L, void* stream);
+
+/* tanh backward of the generator output with the L1 term of model.py:316-319 fused:
+ *   g = dy_adv (may be NULL) + l1_scale * sign(y - clean) (when clean != NULL)
+ *   da = g * (1 - y*y) ; dbias += sum da.   ws: scratch of nsplit*C floats. */
+int segan_tanh_bwd(const float* y, const float* dy, const float* clean, float l1_scale, float* da,
+                   float* dbias, float* ws, int B, int C, int L, void* stream);
+
+/* ---- dense layers of the discriminator head (discriminator.py:111-117) ------------ */
+
+/* C[M,N] (+)= op(A)[M,K] * op(B)[K,N] with explicit element strides; exact fp32 on
+ * MFMA.  beta0 != 0 overwrites C (C is zeroed first), otherwise accumulates. */
+int segan_gemm(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn,
+               float* C, int64_t ldc, int M, int N, int K, int beta0, void* stream);
+
+/* y[r,c] = prelu(x[r,c] + bias[c], slope[c]) (slope NULL = identity), rows x cols. */
+int segan_bias_prelu_rows(const float* x, const float* bias, const float* slope, float* y,
+                          int rows, int cols, void* stream);
+/* backward: dx = dy*(v>0?1:slope), dslope[c] += sum dy*min(v,0), dbias[c] += sum dx,
+ * with v = x + bias. */
+int segan_bias_prelu_rows_bwd(const float* x, const float* bias, const float* slope,
+                              const float* dy, float* dx, float* dslope, float* dbias, int rows,
+                              int cols, void* stream);
+
+/* ---- losses (train.py:94 nn.MSELoss; model.py:79 F.l1_loss) ------------------------ */
+/* loss[0] = mean((x - target)^2) (loss may be NULL);
+ * grad (may be NULL) = 2*(x-target)/n * gscale * (gout ? gout[0] : 1), gout being the
+ * upstream scalar gradient as a DEVICE pointer (no host sync). */
+int segan_mse_const(const float* x, float target, float* loss, float* grad, const float* gout,
+                    float gscale, int n, void* stream);
+/* loss[0] = mean(|x - y|)  (n may be large; ws: scratch of 1024 floats). */
+int segan_l1_mean(const float* x, const float* y, float* loss, float* ws, int64_t n,
+                  void* stream);
+/* grad = sign(x - y) / n * gscale * (gout ? gout[0] : 1)   (torch.sign: sign(0) = 0). */
+int segan_l1_bwd(const float* x, const float* y, const float* gout, float gscale, float* grad,
+                 int64_t n, void* stream);
+
+/* ---- optimizers (model.py:219-228) ---------------------------------------------------- */
+/* torch.optim.RMSprop (no momentum, not centered): sq = alpha*sq + (1-alpha)*g*g;
+ * p -= lr * g / (sqrt(sq) + eps), over a flat arena of n floats. */
+int segan_rmsprop_step(float* p, const float* g, float* sq, float lr, float alpha, float eps,
+                       int64_t n, void* stream);
+/* torch.optim.Adam without weight decay/amsgrad; `step` is the 1-based step count. */
+int segan_adam_step(float* p, const float* g, float* m, float* v, float lr, float beta1,
+                    float beta2, float eps, int step, int64_t n, void* stream);
+int segan_fill(float* p, float value, int64_t n, void* stream);
+int segan_scale(float* p, float s, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEGAN_HIP_H */

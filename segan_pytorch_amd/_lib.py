@@ -1,0 +1,95 @@
+"""ctypes binding of libsegan_hip.so (the C ABI declared in include/segan_hip.h).
+
+The product path has no fallback: if the library is missing or a call fails, a
+RuntimeError carrying ``segan_last_error()`` is raised.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libsegan_hip.so')
+
+PAD_REFLECT = 0
+PAD_ZERO = 1
+ACT_NONE = 0
+ACT_TANH = 1
+ABI_VERSION = 1
+
+
+class SeganSrc(Structure):
+    """Mirror of ``segan_src`` (include/segan_hip.h)."""
+    _fields_ = [('p0', c_void_p), ('p1', c_void_p), ('C0', c_int32), ('C1', c_int32),
+                ('scale', c_void_p), ('shift', c_void_p), ('slope', c_void_p)]
+
+
+_P = c_void_p
+_SRC = POINTER(SeganSrc)
+
+# name -> (restype, argtypes); mirrors include/segan_hip.h one to one
+SIGNATURES = {
+    'segan_abi_version': (c_int, []),
+    'segan_last_error': (c_char_p, []),
+    'segan_packed_f_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'segan_packed_t_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'segan_pack_weights': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    'segan_conv1d_fwd': (c_int, [_SRC, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                 c_int, c_int, _P]),
+    'segan_conv1d_dgrad': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                   c_int, _P]),
+    'segan_wgrad': (c_int, [_SRC, _SRC, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                            c_int, _P]),
+    'segan_deconv1d_fwd': (c_int, [_SRC, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                   c_int, _P]),
+    'segan_deconv1d_dgrad': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                     c_int, _P]),
+    'segan_bn_nsplit': (c_int, [c_int, c_int, c_int]),
+    'segan_bn_stats': (c_int, [_P, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, _P, c_int, c_int,
+                               c_int, _P]),
+    'segan_affine_prelu': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    'segan_act_bwd': (c_int, [_P] * 16 + [c_int, c_int, c_int, _P]),
+    'segan_tanh_bwd': (c_int, [_P, _P, _P, c_float, _P, _P, _P, c_int, c_int, c_int, _P]),
+    'segan_gemm': (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int64, c_int, c_int,
+                           c_int, c_int, _P]),
+    'segan_bias_prelu_rows': (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
+    'segan_bias_prelu_rows_bwd': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
+    'segan_mse_const': (c_int, [_P, c_float, _P, _P, _P, c_float, c_int, _P]),
+    'segan_l1_bwd': (c_int, [_P, _P, _P, c_float, _P, c_int64, _P]),
+    'segan_l1_mean': (c_int, [_P, _P, _P, _P, c_int64, _P]),
+    'segan_rmsprop_step': (c_int, [_P, _P, _P, c_float, c_float, c_float, c_int64, _P]),
+    'segan_adam_step': (c_int, [_P, _P, _P, _P, c_float, c_float, c_float, c_float, c_int, c_int64,
+                                _P]),
+    'segan_fill': (c_int, [_P, c_float, c_int64, _P]),
+    'segan_scale': (c_int, [_P, c_float, c_int64, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises if the .so is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            'segan_pytorch_amd: {} not found. Build it with `make` (or '
+            '`python -c "import __graft_entry__ as g; g.build()"`) at the repo root. '
+            'There is no non-HIP fallback.'.format(LIB_PATH))
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    ver = lib.segan_abi_version()
+    if ver != ABI_VERSION:
+        raise RuntimeError('libsegan_hip ABI {} != expected {}'.format(ver, ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = load().segan_last_error()
+        raise RuntimeError('libsegan_hip {} failed ({}): {}'.format(
+            what, rc, msg.decode() if msg else '?'))

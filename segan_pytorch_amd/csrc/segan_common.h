@@ -1,0 +1,81 @@
+// Shared device/host helpers of libsegan_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/segan_hip.h"
+
+#define SEGAN_OK 0
+#define SEGAN_EINVAL (-1)
+#define SEGAN_ELAUNCH (-2)
+#define SEGAN_EUNSUPPORTED (-3)
+
+// error string shared by all translation units (defined in segan_api.hip)
+void segan_set_error(const char* fmt, ...);
+int segan_check_launch(const char* what);
+
+#define SEGAN_REQUIRE(cond, ...)                 \
+  do {                                           \
+    if (!(cond)) {                               \
+      segan_set_error(__VA_ARGS__);              \
+      return SEGAN_EINVAL;                       \
+    }                                            \
+  } while (0)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
+
+// Padded coordinate p of the high-rate signal -> stored index, or -1 for an implicit
+// zero.  Reflect: F.pad(..., mode='reflect') of modules.py:98 (mirror without
+// repeating the edge sample); roll: the conv sees torch.roll(h, roll) =
+// discriminator.py:160-172.  Mirrors segan_pytorch_amd/layout.py:hi_index.
+__host__ __device__ static inline int segan_hi_index(int p, int L, int padL, int mode, int roll) {
+  int i = p - padL;
+  if (mode == SEGAN_PAD_REFLECT) {
+    if (i < 0) i = -i;
+    if (i >= L) i = 2 * (L - 1) - i;
+  }
+  if (i < 0 || i >= L) return -1;
+  if (roll != 0) {
+    i -= roll;
+    if (i < 0) i += L;
+    if (i >= L) i -= L;
+  }
+  return i;
+}
+
+// transform-on-load of a segan_src channel
+struct ChanXf {
+  float sc, sh, sl;
+  bool has_sl;
+};
+
+__device__ __forceinline__ ChanXf segan_chan_xf(const segan_src& s, int c) {
+  ChanXf x;
+  x.sc = s.scale ? s.scale[c] : 1.0f;
+  x.sh = s.shift ? s.shift[c] : 0.0f;
+  x.has_sl = s.slope != nullptr;
+  x.sl = x.has_sl ? s.slope[c] : 1.0f;
+  return x;
+}
+
+__device__ __forceinline__ float segan_apply_xf(const ChanXf& x, float v) {
+  v = fmaf(v, x.sc, x.sh);
+  return v > 0.0f ? v : v * x.sl;
+}
+
+// row base pointer of logical channel n of sample b
+__device__ __forceinline__ const float* segan_src_row(const segan_src& s, int b, int n, int L) {
+  if (n < s.C0) return s.p0 + ((size_t)b * s.C0 + n) * (size_t)L;
+  return s.p1 + ((size_t)b * s.C1 + (n - s.C0)) * (size_t)L;
+}
+
+__device__ __forceinline__ float warp_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}

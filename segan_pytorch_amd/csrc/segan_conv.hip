@@ -1,0 +1,851 @@
+// segan_conv.hip — the two contraction kernels of the SEGAN GAN step for gfx950.
+//
+// Every strided conv / transposed conv of the generator and discriminator
+// (reference segan/models/modules.py:75-141), forward and backward, is one of three
+// forms over the polyphase split  k = S*u + r  of the K<=32 taps (see
+// segan_pytorch_amd/layout.py, which restates this arithmetic for the CPU tests):
+//
+//   corr<IN_HI=1,OUT_HI=0>  "F": out[m,t]      = sum_{(n,r),u} Wf[(n,r),u,m] * X_r[n,t+u]
+//        conv fwd (modules.py:99) and deconv dgrad
+//   corr<IN_HI=0,OUT_HI=1>  "T": y[n,S*q+r]   = sum_{m,u'} Wt[m,u',(r,n)] * x[m,q+c(r)-(U-1)+u']
+//        deconv fwd (modules.py:136) and conv dgrad
+//   wgrad                   "W": dW[m,n,S*u+r] += sum_{b,t} lo[b,m,t] * HI_r[b,n,t+u]
+//
+// All three are exact-fp32 implicit GEMMs on v_mfma_f32_32x32x2_f32 (bitwise an fmaf
+// chain): 256-thread workgroups, 2x2 waves, each wave a (MB/2)x(NB/2) tile of 32x32
+// MFMA blocks, operands staged through LDS.  Nothing is im2col'ed: the activation
+// tile in LDS is the raw (phase-split) signal with a U-1 halo per sample, and the
+// 8/16/32 taps of a phase read it at shifted addresses.  Reflect padding, the
+// discriminator's circular phase shift, both torch.cat's, the alpha skip scale,
+// BatchNorm-normalise and PReLU are all applied while the tile is staged
+// (segan_src), so none of those tensors is ever materialised in HBM.
+#include "segan_common.h"
+
+#define KCH 64  // contraction elements per LDS chunk (= 32 MFMA k-steps of 2)
+
+// ------------------------------------------------------------------------------------
+// column bookkeeping: the GEMM column space is the flattened (sample, time) axis.  A
+// tile of NB consecutive columns may cover several short samples; in LDS every sample
+// segment carries its own halo of H entries, so column `cl` of local sample s sits at
+// LDS position cl + s*H and tap u of it at cl + s*H + u.
+// ------------------------------------------------------------------------------------
+struct ColTile {
+  int col0, b0, t_first, len0;
+};
+
+__device__ __forceinline__ ColTile make_coltile(int col0, int Tcols, int NBcols) {
+  ColTile t;
+  t.col0 = col0;
+  t.b0 = col0 / Tcols;
+  t.t_first = col0 - t.b0 * Tcols;
+  t.len0 = min(Tcols - t.t_first, NBcols);
+  return t;
+}
+
+// LDS position j -> (local sample s, window coordinate tau)
+__device__ __forceinline__ void lds_pos_decode(const ColTile& ct, int j, int Tcols, int H, int& s,
+                                               int& tau) {
+  if (j < ct.len0 + H) {
+    s = 0;
+    tau = ct.t_first + j;
+  } else {
+    const int jj = j - (ct.len0 + H);
+    const int per = Tcols + H;
+    const int q = jj / per;
+    s = 1 + q;
+    tau = jj - q * per;
+  }
+}
+
+// ====================================================================================
+// corr kernel
+// ====================================================================================
+struct CorrArgs {
+  segan_src in;
+  const float* wp;  // packed weights [Ktot][RP]
+  float* out0;
+  float* out1;
+  const float* bias;
+  float* halo;
+  int B, Cv, Ktot, RP, Rvalid;
+  int Tcols, Ctot, ncoltiles;
+  int Lin;                // stored row length of the input tensor
+  int padL, mode, roll;   // HI input view
+  int win_start, H, RLs;  // window geometry
+  int rowshift[4];
+  int NP, Nout;           // T form row decode: row = r*NP + n
+  int OC0, OC1, Lout, act;
+  int o_padL, o_roll, o_padR;  // HI store (conv dgrad: reflect halo)
+};
+
+template <int MB, int NB, int U, bool IN_HI, bool OUT_HI>
+__global__ __launch_bounds__(256, 2) void corr_kernel(const CorrArgs a) {
+  constexpr int S = 32 / U;
+  constexpr int CV = KCH / U;  // virtual channels per chunk
+  constexpr int NI = MB / 64;
+  constexpr int NJ = NB / 64;
+  constexpr int MAXPOS = 2;  // RLs <= 512
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int RLs = a.RLs;
+  float* Wl0 = smem;                  // [2][KCH*MB]
+  float* Il0 = smem + 2 * KCH * MB;   // [2][CV*RLs]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, h = lane >> 5;
+
+  const int rowtile = blockIdx.x / a.ncoltiles;
+  const int coltile = blockIdx.x - rowtile * a.ncoltiles;
+  const int m0 = rowtile * MB;
+  if (!OUT_HI) {
+    // dual destination: skip tiles whose rows all go to a NULL destination
+    if (a.out0 == nullptr && m0 + MB <= a.OC0) return;
+    if (a.out1 == nullptr && m0 >= a.OC0) return;
+  }
+  const ColTile ct = make_coltile(coltile * NB, a.Tcols, NB);
+
+  // ---- per-thread staging positions of the activation tile (fixed for all chunks) ----
+  int pos_b[MAXPOS];
+  int pos_idx[MAXPOS][S];
+#pragma unroll
+  for (int pp = 0; pp < MAXPOS; ++pp) {
+    const int j = tid + 256 * pp;
+    pos_b[pp] = -1;
+#pragma unroll
+    for (int r = 0; r < S; ++r) pos_idx[pp][r] = -1;
+    if (j < RLs) {
+      int s, tau;
+      lds_pos_decode(ct, j, a.Tcols, a.H, s, tau);
+      const int b = ct.b0 + s;
+      if (b < a.B) {
+        pos_b[pp] = b;
+        const int wq = tau + a.win_start;
+        if (IN_HI) {
+#pragma unroll
+          for (int r = 0; r < S; ++r)
+            pos_idx[pp][r] = segan_hi_index(S * wq + r, a.Lin, a.padL, a.mode, a.roll);
+        } else {
+          pos_idx[pp][0] = (wq >= 0 && wq < a.Lin) ? wq : -1;
+        }
+      }
+    }
+  }
+
+  // ---- per-lane operand offsets ----
+  int aoff[NI], boff[NJ], rsh[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int rloc = wm * (MB / 2) + 32 * i;
+    aoff[i] = h * MB + rloc + l31;
+    rsh[i] = 0;
+    if (OUT_HI) {
+      const int r = (m0 + rloc) / a.NP;
+      rsh[i] = a.rowshift[r < S ? r : S - 1];
+    }
+  }
+  int col_b[NJ], col_t[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int cl = wn * (NB / 2) + 32 * j + l31;
+    const int col = ct.col0 + cl;
+    if (col < a.Ctot) {
+      const int b = col / a.Tcols;
+      col_b[j] = b;
+      col_t[j] = col - b * a.Tcols;
+      boff[j] = cl + (b - ct.b0) * a.H + h;
+    } else {
+      col_b[j] = -1;
+      col_t[j] = 0;
+      boff[j] = h;
+    }
+  }
+
+  f32x16 acc[NI][NJ];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+  // ---- staging registers ----
+  constexpr int F4R = MB / 4;        // float4 per weight row
+  constexpr int RPP = 256 / F4R;     // rows per pass
+  constexpr int NPASS = KCH / RPP;
+  float4 wreg[NPASS];
+  float ireg[CV][MAXPOS];
+  const int wrow = tid / F4R, wc4 = tid % F4R;
+
+  auto load_chunk = [&](int ch) {
+    const int kbase = ch * KCH;
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+      const int gk = kbase + wrow + RPP * p;
+      const int gm = m0 + 4 * wc4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gk < a.Ktot && gm < a.RP)
+        v = *reinterpret_cast<const float4*>(a.wp + (size_t)gk * a.RP + gm);
+      wreg[p] = v;
+    }
+#pragma unroll
+    for (int c = 0; c < CV; ++c) {
+      const int cv = ch * CV + c;
+      const int n = IN_HI ? cv / S : cv;
+      const int r = IN_HI ? c % S : 0;  // CV is a multiple of S
+      const bool cvalid = cv < a.Cv;
+      ChanXf xf;
+      xf.sc = 1.f; xf.sh = 0.f; xf.sl = 1.f; xf.has_sl = false;
+      if (cvalid) xf = segan_chan_xf(a.in, n);
+#pragma unroll
+      for (int pp = 0; pp < MAXPOS; ++pp) {
+        float v = 0.0f;
+        const int idx = pos_idx[pp][r];
+        if (cvalid && pos_b[pp] >= 0 && idx >= 0) {
+          const float* row = segan_src_row(a.in, pos_b[pp], n, a.Lin);
+          v = segan_apply_xf(xf, row[idx]);
+        }
+        ireg[c][pp] = v;
+      }
+    }
+  };
+  auto store_chunk = [&](int buf) {
+    float* Wl = Wl0 + buf * (KCH * MB);
+    float* Il = Il0 + buf * (CV * RLs);
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p)
+      *reinterpret_cast<float4*>(Wl + (wrow + RPP * p) * MB + 4 * wc4) = wreg[p];
+#pragma unroll
+    for (int c = 0; c < CV; ++c)
+#pragma unroll
+      for (int pp = 0; pp < MAXPOS; ++pp) {
+        const int j = tid + 256 * pp;
+        if (j < RLs) Il[c * RLs + j] = ireg[c][pp];
+      }
+  };
+
+  const int nch = (a.Ktot + KCH - 1) / KCH;
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+  for (int ch = 0; ch < nch; ++ch) {
+    const int buf = ch & 1;
+    if (ch + 1 < nch) load_chunk(ch + 1);
+    const float* Wl = Wl0 + buf * (KCH * MB);
+    const float* Il = Il0 + buf * (CV * RLs);
+#pragma unroll
+    for (int s = 0; s < KCH / 2; ++s) {
+      const int kk = 2 * s;
+      const int c = kk / U, u = kk % U;
+      const float* wr = Wl + kk * MB;
+      const float* ir = Il + c * RLs + u;
+      float av[NI];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) av[i] = wr[aoff[i]];
+      if (OUT_HI) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            const float bv = ir[boff[j] + rsh[i]];
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv, acc[i][j], 0, 0, 0);
+          }
+      } else {
+        float bv[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) bv[j] = ir[boff[j]];
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    if (ch + 1 < nch) store_chunk(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue ----
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = m0 + wm * (MB / 2) + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+      if (row >= a.Rvalid) continue;
+      if (!OUT_HI) {
+        // LO store: out[b, row, t]
+        float* dst;
+        int oc, och;
+        if (row < a.OC0) { dst = a.out0; oc = a.OC0; och = row; }
+        else { dst = a.out1; oc = a.OC1; och = row - a.OC0; }
+        if (dst == nullptr) continue;
+        const float bs = a.bias ? a.bias[row] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          if (col_b[j] < 0) continue;
+          float v = acc[i][j][e] + bs;
+          if (a.act == SEGAN_ACT_TANH) v = tanhf(v);
+          dst[((size_t)col_b[j] * oc + och) * (size_t)a.Lout + col_t[j]] = v;
+        }
+      } else {
+        const int r = row / a.NP;
+        const int n = row - r * a.NP;
+        if (n >= a.Nout) continue;
+        const float bs = a.bias ? a.bias[n] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          if (col_b[j] < 0) continue;
+          float v = acc[i][j][e] + bs;
+          if (a.act == SEGAN_ACT_TANH) v = tanhf(v);
+          const int P = S * col_t[j] + r;
+          int ii = P - a.o_padL;
+          const size_t rowoff = (size_t)col_b[j] * a.Nout + n;
+          if (ii >= 0 && ii < a.Lout) {
+            if (a.o_roll != 0) {
+              ii -= a.o_roll;
+              if (ii < 0) ii += a.Lout;
+              if (ii >= a.Lout) ii -= a.Lout;
+            }
+            a.out0[rowoff * (size_t)a.Lout + ii] = v;
+          } else if (a.halo != nullptr) {
+            const int hl = a.o_padL + a.o_padR;
+            if (ii < 0) a.halo[rowoff * hl + P] = v;
+            else if (ii - a.Lout < a.o_padR) a.halo[rowoff * hl + a.o_padL + (ii - a.Lout)] = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+// fold the reflect halo of a conv dgrad back into dx: one thread per (b, n) row.
+__global__ void fold_halo_kernel(float* dx, const float* halo, int rows, int L, int padL,
+                                 int padR, int roll) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= rows) return;
+  const int hl = padL + padR;
+  float* d = dx + (size_t)row * L;
+  const float* hrow = halo + (size_t)row * hl;
+  for (int P = 0; P < padL; ++P) {
+    const int idx = segan_hi_index(P, L, padL, SEGAN_PAD_REFLECT, roll);
+    if (idx >= 0) d[idx] += hrow[P];
+  }
+  for (int P2 = 0; P2 < padR; ++P2) {
+    const int idx = segan_hi_index(L + padL + P2, L, padL, SEGAN_PAD_REFLECT, roll);
+    if (idx >= 0) d[idx] += hrow[padL + P2];
+  }
+}
+
+template <int MB, int U, bool IN_HI, bool OUT_HI>
+static int launch_corr_t(const CorrArgs& a, hipStream_t st) {
+  constexpr int NB = 128;
+  constexpr int CV = KCH / U;
+  const int nrowtiles = ceil_div(a.Rvalid, MB);
+  const size_t lds = (size_t)(2 * KCH * MB + 2 * CV * a.RLs) * sizeof(float);
+  if (lds > 160 * 1024) {
+    segan_set_error("corr: LDS tile %zu B too large (RLs=%d)", lds, a.RLs);
+    return SEGAN_EUNSUPPORTED;
+  }
+  auto kern = corr_kernel<MB, NB, U, IN_HI, OUT_HI>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  dim3 grid((unsigned)(nrowtiles * a.ncoltiles));
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
+  return segan_check_launch("corr_kernel");
+}
+
+template <bool IN_HI, bool OUT_HI>
+static int launch_corr(CorrArgs& a, int U, hipStream_t st) {
+  constexpr int NB = 128;
+  a.ncoltiles = ceil_div(a.Ctot, NB);
+  // worst-case samples touched by one tile -> LDS row length
+  int NS;
+  if (a.Tcols >= NB) NS = (a.Tcols % NB == 0) ? 1 : 2;
+  else NS = (NB % a.Tcols == 0) ? NB / a.Tcols : (NB + a.Tcols - 2) / a.Tcols + 1;
+  a.RLs = NB + NS * a.H;
+  if (a.RLs > 512) {
+    segan_set_error("corr: sample length %d too short for stride %d (RLs=%d)", a.Tcols, 32 / U,
+                    a.RLs);
+    return SEGAN_EUNSUPPORTED;
+  }
+  const bool small = a.Rvalid <= 64;
+  switch (U) {
+    case 8:
+      return small ? launch_corr_t<64, 8, IN_HI, OUT_HI>(a, st)
+                   : launch_corr_t<128, 8, IN_HI, OUT_HI>(a, st);
+    case 16:
+      return small ? launch_corr_t<64, 16, IN_HI, OUT_HI>(a, st)
+                   : launch_corr_t<128, 16, IN_HI, OUT_HI>(a, st);
+    case 32:
+      return small ? launch_corr_t<64, 32, IN_HI, OUT_HI>(a, st)
+                   : launch_corr_t<128, 32, IN_HI, OUT_HI>(a, st);
+  }
+  segan_set_error("corr: unsupported stride (U=%d)", U);
+  return SEGAN_EUNSUPPORTED;
+}
+
+// ====================================================================================
+// wgrad kernel
+// ====================================================================================
+struct WgradArgs {
+  segan_src lo;
+  segan_src hi;
+  float* dw;
+  int B, M, N, K, Ls, Lhi;
+  int Cv;                 // N*S virtual channels
+  int padL, mode, roll;
+  int Ctot;               // B*Ls
+  int cols_per_split;
+  int H, RLw;
+};
+
+template <int U>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
+  constexpr int S = 32 / U;
+  constexpr int MB = 128;
+  constexpr int TK = KCH;            // contraction columns per chunk
+  constexpr int CVW = 128 / U;       // virtual channels per block (128 output columns)
+  constexpr int AST = TK + 1;        // padded A row stride
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int RLw = a.RLw;
+  float* Al = smem;                  // [MB][AST]
+  float* Bl = Al + MB * AST;         // [CVW][RLw]
+  int* posT = reinterpret_cast<int*>(Bl + CVW * RLw);  // [TK]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, h = lane >> 5;
+
+  const int cv0 = blockIdx.x * CVW;
+  const int m0 = blockIdx.y * MB;
+  const int split_beg = blockIdx.z * a.cols_per_split;
+  const int split_end = min(split_beg + a.cols_per_split, a.Ctot);
+  if (split_beg >= split_end) return;
+  const int nch = (split_end - split_beg + TK - 1) / TK;
+
+  // per-lane operand offsets
+  int aoff[2], bch[2], bu[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) aoff[i] = (wm * 64 + 32 * i + l31) * AST + h;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int cc = wn * 64 + 32 * j + l31;
+    bch[j] = (cc / U) * RLw;
+    bu[j] = cc % U;
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+  // A staging: thread owns 4 consecutive columns (one float4; Ls % 4 == 0 keeps them in
+  // one sample) of rows tid/16 + 16*i
+  const int kc4 = tid & 15, ar0 = tid >> 4;
+  float4 areg[MB / 16];
+  float breg[CVW];
+  int posreg = 0;
+
+  auto load_chunk = [&](int ch) {
+    const int col0 = split_beg + ch * TK;
+    // ---- A: lo[m][col] ----
+    {
+      const int col = col0 + 4 * kc4;
+      const bool cok = col < split_end;
+      int b = 0, t = 0;
+      if (cok) { b = col / a.Ls; t = col - b * a.Ls; }
+#pragma unroll
+      for (int i = 0; i < MB / 16; ++i) {
+        const int m = m0 + ar0 + 16 * i;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (cok && m < a.M) {
+          const ChanXf xf = segan_chan_xf(a.lo, m);
+          v = *reinterpret_cast<const float4*>(segan_src_row(a.lo, b, m, a.Ls) + t);
+          v.x = segan_apply_xf(xf, v.x);
+          v.y = segan_apply_xf(xf, v.y);
+          v.z = segan_apply_xf(xf, v.z);
+          v.w = segan_apply_xf(xf, v.w);
+        }
+        areg[i] = v;
+      }
+    }
+    // ---- B: hi phases (RLw <= 256: one position per thread) ----
+    const ColTile ct = make_coltile(col0, a.Ls, TK);
+    int pb = -1, pidx[S];
+#pragma unroll
+    for (int r = 0; r < S; ++r) pidx[r] = -1;
+    if (tid < RLw) {
+      int s, tau;
+      lds_pos_decode(ct, tid, a.Ls, a.H, s, tau);
+      const int b = ct.b0 + s;
+      if (b < a.B) {
+        pb = b;
+#pragma unroll
+        for (int r = 0; r < S; ++r)
+          pidx[r] = segan_hi_index(S * tau + r, a.Lhi, a.padL, a.mode, a.roll);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CVW; ++c) {
+      const int cv = cv0 + c;
+      const int n = cv / S, r = c % S;  // cv0 is a multiple of S
+      const bool cvalid = cv < a.Cv;
+      float v = 0.0f;
+      const int idx = pidx[r];
+      if (cvalid && pb >= 0 && idx >= 0) {
+        const ChanXf xf = segan_chan_xf(a.hi, n);
+        v = segan_apply_xf(xf, segan_src_row(a.hi, pb, n, a.Lhi)[idx]);
+      }
+      breg[c] = v;
+    }
+    // position table for the contraction columns of this chunk
+    if (tid < TK) {
+      const int col = col0 + tid;
+      posreg = 0;
+      if (col < a.Ctot) posreg = tid + (col / a.Ls - ct.b0) * a.H;
+    }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int i = 0; i < MB / 16; ++i) {
+      float* d = Al + (ar0 + 16 * i) * AST + 4 * kc4;
+      d[0] = areg[i].x; d[1] = areg[i].y; d[2] = areg[i].z; d[3] = areg[i].w;
+    }
+    if (tid < RLw) {
+#pragma unroll
+      for (int c = 0; c < CVW; ++c) Bl[c * RLw + tid] = breg[c];
+    }
+    if (tid < TK) posT[tid] = posreg;
+  };
+
+  load_chunk(0);
+  store_chunk();
+  __syncthreads();
+  for (int ch = 0; ch < nch; ++ch) {
+    if (ch + 1 < nch) load_chunk(ch + 1);
+#pragma unroll
+    for (int s = 0; s < TK / 2; ++s) {
+      const int kk = 2 * s;
+      const int pz = posT[kk + h];
+      float av[2], bv[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) av[i] = Al[aoff[i] + kk];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bv[j] = Bl[bch[j] + pz + bu[j]];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+    if (ch + 1 < nch) {
+      store_chunk();
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: dw[m][n][S*u + r] += acc ----
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int cc = wn * 64 + 32 * j + l31;
+    const int cv = cv0 + cc / U;
+    const int u = cc % U;
+    const int n = cv / S, r = cv % S;
+    const int k = S * u + r;
+    if (cv >= a.Cv || k >= a.K) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * 64 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (m < a.M) atomicAdd(a.dw + ((size_t)m * a.N + n) * a.K + k, acc[i][j][e]);
+      }
+  }
+}
+
+template <int U>
+static int launch_wgrad_t(WgradArgs& a, hipStream_t st) {
+  constexpr int CVW = 128 / U;
+  constexpr int TK = KCH;
+  int NS;
+  if (a.Ls >= TK) NS = (a.Ls % TK == 0) ? 1 : 2;
+  else NS = (TK % a.Ls == 0) ? TK / a.Ls : (TK + a.Ls - 2) / a.Ls + 1;
+  a.H = U - 1;
+  a.RLw = TK + NS * a.H;
+  if (a.RLw > 256 || a.Ls % 4 != 0) {
+    segan_set_error("wgrad: low-rate length %d unsupported for stride %d (needs a multiple of 4, "
+                    "and >= %d)", a.Ls, 32 / U, U / 2);
+    return SEGAN_EUNSUPPORTED;
+  }
+  const int ncol = ceil_div(a.Cv, CVW);
+  const int nrow = ceil_div(a.M, 128);
+  // split the (b,t) contraction so the grid has ~2 waves of workgroups
+  const int tiles = ncol * nrow;
+  const int chunks = ceil_div(a.Ctot, TK);
+  int nsplit = ceil_div(1024, tiles);
+  if (nsplit > chunks) nsplit = chunks;
+  if (nsplit < 1) nsplit = 1;
+  const int chunks_per = ceil_div(chunks, nsplit);
+  nsplit = ceil_div(chunks, chunks_per);
+  a.cols_per_split = chunks_per * TK;
+  const size_t lds = (size_t)(128 * (TK + 1) + CVW * a.RLw) * sizeof(float) + TK * sizeof(int);
+  auto kern = wgrad_kernel<U>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(ncol, nrow, nsplit), dim3(256), lds, st, a);
+  return segan_check_launch("wgrad_kernel");
+}
+
+// ====================================================================================
+// weight packing
+// ====================================================================================
+__global__ void pack_f_kernel(const float* __restrict__ w, float* __restrict__ wf, int M, int N,
+                              int K, int S, int U, int MP) {
+  const size_t total = (size_t)N * S * U * MP;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int m = (int)(i % MP);
+    size_t t = i / MP;
+    const int u = (int)(t % U);
+    t /= U;
+    const int r = (int)(t % S);
+    const int n = (int)(t / S);
+    const int k = S * u + r;
+    float v = 0.0f;
+    if (m < M && k < K) v = w[((size_t)m * N + n) * K + k];
+    wf[i] = v;
+  }
+}
+
+__global__ void pack_t_kernel(const float* __restrict__ w, float* __restrict__ wt, int M, int N,
+                              int K, int S, int U, int NP, int pad) {
+  const int RP = S * NP;
+  const size_t total = (size_t)M * U * RP;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int col = (int)(i % RP);
+    size_t t = i / RP;
+    const int up = (int)(t % U);
+    const int m = (int)(t / U);
+    const int r = col / NP, n = col % NP;
+    const int rho = (r + pad) % S;
+    const int k = S * (U - 1 - up) + rho;
+    float v = 0.0f;
+    if (n < N && k < K) v = w[((size_t)m * N + n) * K + k];
+    wt[i] = v;
+  }
+}
+
+// ====================================================================================
+// C ABI
+// ====================================================================================
+static bool stride_ok(int S) { return S == 1 || S == 2 || S == 4; }
+
+extern "C" size_t segan_packed_f_bytes(int M, int N, int S) {
+  if (!stride_ok(S) || M <= 0 || N <= 0) return 0;
+  return (size_t)N * 32 * round_up(M, 32) * sizeof(float);
+}
+extern "C" size_t segan_packed_t_bytes(int M, int N, int S) {
+  if (!stride_ok(S) || M <= 0 || N <= 0) return 0;
+  return (size_t)M * (32 / S) * S * round_up(N, 32) * sizeof(float);
+}
+
+extern "C" int segan_pack_weights(const float* w, float* wf, float* wt, int M, int N, int K, int S,
+                                  int pad_t, void* stream) {
+  SEGAN_REQUIRE(w != nullptr, "pack_weights: w is NULL");
+  SEGAN_REQUIRE(stride_ok(S), "pack_weights: stride %d not in {1,2,4}", S);
+  SEGAN_REQUIRE(K >= 1 && K <= 32, "pack_weights: kernel width %d not in [1,32]", K);
+  SEGAN_REQUIRE(M > 0 && N > 0, "pack_weights: bad channel counts %d,%d", M, N);
+  SEGAN_REQUIRE(pad_t >= 0, "pack_weights: negative padding");
+  hipStream_t st = (hipStream_t)stream;
+  const int U = 32 / S;
+  if (wf) {
+    const int MP = round_up(M, 32);
+    const size_t total = (size_t)N * 32 * MP;
+    const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    hipLaunchKernelGGL(pack_f_kernel, dim3(blocks), dim3(256), 0, st, w, wf, M, N, K, S, U, MP);
+  }
+  if (wt) {
+    const int NP = round_up(N, 32);
+    const size_t total = (size_t)M * U * S * NP;
+    const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    hipLaunchKernelGGL(pack_t_kernel, dim3(blocks), dim3(256), 0, st, w, wt, M, N, K, S, U, NP,
+                       pad_t);
+  }
+  return segan_check_launch("pack_weights");
+}
+
+static int check_src(const segan_src* s, int C, const char* what) {
+  SEGAN_REQUIRE(s != nullptr && s->p0 != nullptr, "%s: source is NULL", what);
+  SEGAN_REQUIRE(s->C0 > 0 && s->C1 >= 0 && s->C0 + s->C1 == C,
+                "%s: channel segments %d+%d != %d", what, s->C0, s->C1, C);
+  SEGAN_REQUIRE(s->C1 == 0 || s->p1 != nullptr, "%s: second segment pointer is NULL", what);
+  return SEGAN_OK;
+}
+
+extern "C" int segan_conv1d_fwd(const segan_src* x, const float* wf, const float* bias, float* out,
+                                int B, int N, int M, int L, int K, int S, int padL, int mode,
+                                int roll, void* stream) {
+  SEGAN_REQUIRE(stride_ok(S), "conv1d_fwd: stride %d not in {1,2,4}", S);
+  SEGAN_REQUIRE(K >= 1 && K <= 32, "conv1d_fwd: kernel width %d not in [1,32]", K);
+  SEGAN_REQUIRE(B > 0 && N > 0 && M > 0 && L > 0, "conv1d_fwd: bad sizes");
+  SEGAN_REQUIRE(L % S == 0, "conv1d_fwd: length %d not divisible by stride %d", L, S);
+  SEGAN_REQUIRE(wf && out, "conv1d_fwd: NULL pointer");
+  SEGAN_REQUIRE(mode == SEGAN_PAD_REFLECT || mode == SEGAN_PAD_ZERO, "conv1d_fwd: bad pad mode");
+  SEGAN_REQUIRE(mode != SEGAN_PAD_REFLECT || (padL < L && K - 1 - padL < L),
+                "conv1d_fwd: reflect padding %d needs length > pad (L=%d)", padL, L);
+  SEGAN_REQUIRE(roll > -L && roll < L, "conv1d_fwd: |roll| must be < L");
+  if (int e = check_src(x, N, "conv1d_fwd")) return e;
+  const int U = 32 / S;
+  CorrArgs a = {};
+  a.in = *x;
+  a.wp = wf;
+  a.out0 = out; a.out1 = nullptr; a.bias = bias; a.halo = nullptr;
+  a.B = B; a.Cv = N * S; a.Ktot = N * 32; a.RP = round_up(M, 32); a.Rvalid = M;
+  a.Tcols = L / S; a.Ctot = B * a.Tcols;
+  a.Lin = L; a.padL = padL; a.mode = mode; a.roll = roll;
+  a.win_start = 0; a.H = U - 1;
+  a.NP = 1; a.Nout = 0;
+  a.OC0 = M; a.OC1 = 0; a.Lout = a.Tcols; a.act = SEGAN_ACT_NONE;
+  return launch_corr<true, false>(a, U, (hipStream_t)stream);
+}
+
+extern "C" int segan_deconv1d_dgrad(const float* dy, const float* wf, float* dx0, float* dx1, int B,
+                                    int M, int M0, int N, int Ls, int K, int S, int pad,
+                                    void* stream) {
+  SEGAN_REQUIRE(stride_ok(S), "deconv1d_dgrad: stride %d not in {1,2,4}", S);
+  SEGAN_REQUIRE(K >= 1 && K <= 32, "deconv1d_dgrad: kernel width %d not in [1,32]", K);
+  SEGAN_REQUIRE(B > 0 && N > 0 && M > 0 && Ls > 0, "deconv1d_dgrad: bad sizes");
+  SEGAN_REQUIRE(M0 >= 0 && M0 <= M, "deconv1d_dgrad: split %d outside [0,%d]", M0, M);
+  SEGAN_REQUIRE(dy && wf, "deconv1d_dgrad: NULL pointer");
+  SEGAN_REQUIRE(dx0 || dx1, "deconv1d_dgrad: both destinations NULL");
+  const int U = 32 / S;
+  CorrArgs a = {};
+  a.in.p0 = dy; a.in.p1 = nullptr; a.in.C0 = N; a.in.C1 = 0;
+  a.in.scale = a.in.shift = a.in.slope = nullptr;
+  a.wp = wf;
+  a.bias = nullptr; a.halo = nullptr;
+  a.B = B; a.Cv = N * S; a.Ktot = N * 32; a.RP = round_up(M, 32); a.Rvalid = M;
+  a.Tcols = Ls; a.Ctot = B * Ls;
+  a.Lin = S * Ls; a.padL = pad; a.mode = SEGAN_PAD_ZERO; a.roll = 0;
+  a.win_start = 0; a.H = U - 1;
+  a.NP = 1; a.Nout = 0;
+  if (M0 == 0) { a.out0 = dx1; a.OC0 = M; a.out1 = nullptr; a.OC1 = 0; }
+  else { a.out0 = dx0; a.OC0 = M0; a.out1 = dx1; a.OC1 = M - M0; }
+  a.Lout = Ls; a.act = SEGAN_ACT_NONE;
+  return launch_corr<true, false>(a, U, (hipStream_t)stream);
+}
+
+extern "C" int segan_deconv1d_fwd(const segan_src* x, const float* wt, const float* bias, float* y,
+                                  int B, int M, int N, int Ls, int K, int S, int pad, int act,
+                                  void* stream) {
+  SEGAN_REQUIRE(stride_ok(S), "deconv1d_fwd: stride %d not in {1,2,4}", S);
+  SEGAN_REQUIRE(K >= 1 && K <= 32, "deconv1d_fwd: kernel width %d not in [1,32]", K);
+  SEGAN_REQUIRE(B > 0 && N > 0 && M > 0 && Ls > 0, "deconv1d_fwd: bad sizes");
+  SEGAN_REQUIRE(wt && y, "deconv1d_fwd: NULL pointer");
+  SEGAN_REQUIRE(pad >= 0 && K - 2 * pad - S == (K & 1),
+                "deconv1d_fwd: K=%d S=%d pad=%d does not give an output of S*Ls samples", K, S, pad);
+  SEGAN_REQUIRE(act == SEGAN_ACT_NONE || act == SEGAN_ACT_TANH, "deconv1d_fwd: bad activation");
+  if (int e = check_src(x, M, "deconv1d_fwd")) return e;
+  const int U = 32 / S;
+  CorrArgs a = {};
+  a.in = *x;
+  a.wp = wt;
+  a.out0 = y; a.out1 = nullptr; a.bias = bias; a.halo = nullptr;
+  a.NP = round_up(N, 32); a.Nout = N;
+  a.B = B; a.Cv = M; a.Ktot = M * U; a.RP = S * a.NP; a.Rvalid = S * a.NP;
+  a.Tcols = Ls; a.Ctot = B * Ls;
+  a.Lin = Ls; a.padL = 0; a.mode = SEGAN_PAD_ZERO; a.roll = 0;
+  int cmin = 1 << 30, cmax = 0;
+  for (int r = 0; r < S; ++r) {
+    const int c = (r + pad) / S;
+    cmin = c < cmin ? c : cmin;
+    cmax = c > cmax ? c : cmax;
+  }
+  for (int r = 0; r < 4; ++r) a.rowshift[r] = r < S ? (r + pad) / S - cmin : 0;
+  a.win_start = cmin - (U - 1);
+  a.H = U - 1 + (cmax - cmin);
+  a.OC0 = N; a.OC1 = 0; a.Lout = S * Ls; a.act = act;
+  a.o_padL = 0; a.o_roll = 0; a.o_padR = 0;
+  return launch_corr<false, true>(a, U, (hipStream_t)stream);
+}
+
+extern "C" int segan_conv1d_dgrad(const float* da, const float* wt, float* dx, float* halo, int B,
+                                  int N, int M, int L, int K, int S, int padL, int roll,
+                                  void* stream) {
+  SEGAN_REQUIRE(stride_ok(S), "conv1d_dgrad: stride %d not in {1,2,4}", S);
+  SEGAN_REQUIRE(K >= 1 && K <= 32, "conv1d_dgrad: kernel width %d not in [1,32]", K);
+  SEGAN_REQUIRE(B > 0 && N > 0 && M > 0 && L > 0 && L % S == 0, "conv1d_dgrad: bad sizes");
+  SEGAN_REQUIRE(da && wt && dx && halo, "conv1d_dgrad: NULL pointer");
+  SEGAN_REQUIRE(roll > -L && roll < L, "conv1d_dgrad: |roll| must be < L");
+  const int padR = K - 1 - padL;
+  SEGAN_REQUIRE(padL >= 0 && padR >= 0 && padL < L && padR < L, "conv1d_dgrad: bad padding");
+  const int U = 32 / S;
+  const int Ls = L / S;
+  hipStream_t st = (hipStream_t)stream;
+  CorrArgs a = {};
+  a.in.p0 = da; a.in.p1 = nullptr; a.in.C0 = M; a.in.C1 = 0;
+  a.in.scale = a.in.shift = a.in.slope = nullptr;
+  a.wp = wt;
+  a.out0 = dx; a.out1 = nullptr; a.bias = nullptr; a.halo = halo;
+  a.NP = round_up(N, 32); a.Nout = N;
+  a.B = B; a.Cv = M; a.Ktot = M * U; a.RP = S * a.NP; a.Rvalid = S * a.NP;
+  // padded coordinates P = S*q + r in [0, L + padL + padR)
+  a.Tcols = (L + padL + padR - 1) / S + 1;
+  a.Ctot = B * a.Tcols;
+  a.Lin = Ls; a.padL = 0; a.mode = SEGAN_PAD_ZERO; a.roll = 0;
+  for (int r = 0; r < 4; ++r) a.rowshift[r] = 0;
+  a.win_start = -(U - 1);
+  a.H = U - 1;
+  a.OC0 = N; a.OC1 = 0; a.Lout = L; a.act = SEGAN_ACT_NONE;
+  a.o_padL = padL; a.o_roll = roll; a.o_padR = padR;
+  int e = launch_corr<false, true>(a, U, st);
+  if (e) return e;
+  if (padL + padR > 0) {
+    const int rows = B * N;
+    hipLaunchKernelGGL(fold_halo_kernel, dim3(ceil_div(rows, 256)), dim3(256), 0, st, dx, halo,
+                       rows, L, padL, padR, roll);
+    return segan_check_launch("fold_halo_kernel");
+  }
+  return SEGAN_OK;
+}
+
+extern "C" int segan_wgrad(const segan_src* lo, const segan_src* hi, float* dw, int B, int M, int N,
+                           int Ls, int K, int S, int padL, int mode, int roll, void* stream) {
+  SEGAN_REQUIRE(stride_ok(S), "wgrad: stride %d not in {1,2,4}", S);
+  SEGAN_REQUIRE(K >= 1 && K <= 32, "wgrad: kernel width %d not in [1,32]", K);
+  SEGAN_REQUIRE(B > 0 && N > 0 && M > 0 && Ls > 0, "wgrad: bad sizes");
+  SEGAN_REQUIRE(dw != nullptr, "wgrad: dw is NULL");
+  SEGAN_REQUIRE(mode == SEGAN_PAD_REFLECT || mode == SEGAN_PAD_ZERO, "wgrad: bad pad mode");
+  if (int e = check_src(lo, M, "wgrad(lo)")) return e;
+  if (int e = check_src(hi, N, "wgrad(hi)")) return e;
+  const int L = S * Ls;
+  SEGAN_REQUIRE(roll > -L && roll < L, "wgrad: |roll| must be < L");
+  WgradArgs a = {};
+  a.lo = *lo; a.hi = *hi; a.dw = dw;
+  a.B = B; a.M = M; a.N = N; a.K = K; a.Ls = Ls; a.Lhi = L;
+  a.Cv = N * S; a.padL = padL; a.mode = mode; a.roll = roll;
+  a.Ctot = B * Ls;
+  hipStream_t st = (hipStream_t)stream;
+  switch (S) {
+    case 4: return launch_wgrad_t<8>(a, st);
+    case 2: return launch_wgrad_t<16>(a, st);
+    default: return launch_wgrad_t<32>(a, st);
+  }
+}

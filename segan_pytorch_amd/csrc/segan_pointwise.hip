@@ -1,0 +1,595 @@
+// segan_pointwise.hip — HBM-bound per-channel kernels of the SEGAN GAN step (gfx950):
+// BatchNorm statistics, the backward of (BN +) PReLU / alpha-skip / tanh with their
+// per-channel parameter gradients, the dense-head bias/PReLU, losses and the fused
+// optimizers.  All reductions are two-stage (per-workgroup partials, then one
+// finalising thread per channel) so results do not depend on scheduling order.
+#include "segan_common.h"
+
+#define PW_THREADS 256
+
+// number of batch splits per channel for the [B,C,L] reductions
+static int pw_nsplit(int B, int C, int L) {
+  int ns = ceil_div(2048, C);
+  if (ns > B) ns = B;
+  // keep at least ~2048 elements per workgroup
+  long per = (long)B * L / ns;
+  while (ns > 1 && per < 2048) {
+    ns = (ns + 1) / 2;
+    per = (long)B * L / ns;
+  }
+  return ns < 1 ? 1 : ns;
+}
+
+extern "C" int segan_bn_nsplit(int B, int C, int L) {
+  if (B <= 0 || C <= 0 || L <= 0) return 0;
+  return pw_nsplit(B, C, L);
+}
+
+// block-wide sum of up to 4 values; result valid in thread 0
+template <int NV>
+__device__ __forceinline__ void block_sum(float (&v)[NV], float* sm) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) v[k] = warp_sum(v[k]);
+  if (lane == 0)
+#pragma unroll
+    for (int k = 0; k < NV; ++k) sm[wave * NV + k] = v[k];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      float s = 0.f;
+      for (int w = 0; w < PW_THREADS / 64; ++w) s += sm[w * NV + k];
+      v[k] = s;
+    }
+  }
+  __syncthreads();
+}
+
+struct ChanRange {
+  int c, b_beg, b_end;
+};
+__device__ __forceinline__ ChanRange chan_range(int B, int nsplit) {
+  ChanRange r;
+  r.c = blockIdx.x;
+  const int per = (B + nsplit - 1) / nsplit;
+  r.b_beg = blockIdx.y * per;
+  r.b_end = min(B, r.b_beg + per);
+  return r;
+}
+
+// ---------------------------------------------------------------------------------
+// BatchNorm statistics
+// ---------------------------------------------------------------------------------
+__global__ void bn_partial_kernel(const float* __restrict__ x, float* __restrict__ ws, int B, int C,
+                                  int L, int nsplit) {
+  __shared__ float sm[16];
+  __shared__ float s_mean;
+  const ChanRange cr = chan_range(B, nsplit);
+  const int nb = cr.b_end - cr.b_beg;
+  const long cnt = (long)(nb > 0 ? nb : 0) * L;
+  float v[1] = {0.f};
+  for (long e = threadIdx.x; e < cnt; e += PW_THREADS) {
+    const int b = cr.b_beg + (int)(e / L);
+    const int t = (int)(e % L);
+    v[0] += x[((size_t)b * C + cr.c) * L + t];
+  }
+  block_sum<1>(v, sm);
+  if (threadIdx.x == 0) s_mean = cnt > 0 ? v[0] / (float)cnt : 0.f;
+  __syncthreads();
+  const float mean = s_mean;
+  float q[1] = {0.f};
+  for (long e = threadIdx.x; e < cnt; e += PW_THREADS) {
+    const int b = cr.b_beg + (int)(e / L);
+    const int t = (int)(e % L);
+    const float d = x[((size_t)b * C + cr.c) * L + t] - mean;
+    q[0] = fmaf(d, d, q[0]);
+  }
+  block_sum<1>(q, sm);
+  if (threadIdx.x == 0) {
+    float* w = ws + ((size_t)blockIdx.y * C + cr.c) * 3;
+    w[0] = (float)cnt;
+    w[1] = mean;
+    w[2] = q[0];
+  }
+}
+
+__global__ void bn_final_kernel(const float* __restrict__ ws, const float* gamma, const float* beta,
+                                float eps, float momentum, float* running_mean, float* running_var,
+                                float* mean_o, float* rstd_o, float* scale_o, float* shift_o, int C,
+                                int nsplit) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  // Chan et al. parallel combination, in double
+  double n = 0.0, mean = 0.0, m2 = 0.0;
+  for (int s = 0; s < nsplit; ++s) {
+    const float* w = ws + ((size_t)s * C + c) * 3;
+    const double nb = w[0], mb = w[1], qb = w[2];
+    if (nb <= 0.0) continue;
+    const double tot = n + nb;
+    const double d = mb - mean;
+    mean += d * nb / tot;
+    m2 += qb + d * d * n * nb / tot;
+    n = tot;
+  }
+  const double var = n > 0 ? m2 / n : 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float g = gamma ? gamma[c] : 1.0f;
+  const float bt = beta ? beta[c] : 0.0f;
+  const float sc = g * rstd;
+  if (mean_o) mean_o[c] = (float)mean;
+  if (rstd_o) rstd_o[c] = rstd;
+  if (scale_o) scale_o[c] = sc;
+  if (shift_o) shift_o[c] = bt - (float)mean * sc;
+  if (running_mean) running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
+  if (running_var) {
+    const double unb = n > 1 ? m2 / (n - 1.0) : var;
+    running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unb;
+  }
+}
+
+extern "C" int segan_bn_stats(const float* x, const float* gamma, const float* beta, float eps,
+                              float momentum, float* running_mean, float* running_var, float* mean,
+                              float* rstd, float* scale, float* shift, float* ws, int B, int C,
+                              int L, void* stream) {
+  SEGAN_REQUIRE(x && ws, "bn_stats: NULL pointer");
+  SEGAN_REQUIRE(B > 0 && C > 0 && L > 0, "bn_stats: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  const int ns = pw_nsplit(B, C, L);
+  hipLaunchKernelGGL(bn_partial_kernel, dim3(C, ns), dim3(PW_THREADS), 0, st, x, ws, B, C, L, ns);
+  hipLaunchKernelGGL(bn_final_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, ws, gamma, beta, eps,
+                     momentum, running_mean, running_var, mean, rstd, scale, shift, C, ns);
+  return segan_check_launch("bn_stats");
+}
+
+// ---------------------------------------------------------------------------------
+// y = prelu(x*scale + shift, slope)
+// ---------------------------------------------------------------------------------
+__global__ void affine_prelu_kernel(const float* __restrict__ x, const float* scale,
+                                    const float* shift, const float* slope, float* __restrict__ y,
+                                    size_t total, int C, int L) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)((i / L) % C);
+    float v = x[i];
+    v = fmaf(v, scale ? scale[c] : 1.0f, shift ? shift[c] : 0.0f);
+    if (slope) v = v > 0.f ? v : v * slope[c];
+    y[i] = v;
+  }
+}
+
+extern "C" int segan_affine_prelu(const float* x, const float* scale, const float* shift,
+                                  const float* slope, float* y, int B, int C, int L, void* stream) {
+  SEGAN_REQUIRE(x && y, "affine_prelu: NULL pointer");
+  SEGAN_REQUIRE(B > 0 && C > 0 && L > 0, "affine_prelu: bad sizes");
+  const size_t total = (size_t)B * C * L;
+  const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipLaunchKernelGGL(affine_prelu_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, scale,
+                     shift, slope, y, total, C, L);
+  return segan_check_launch("affine_prelu");
+}
+
+// ---------------------------------------------------------------------------------
+// backward of (BN +) PReLU + alpha-skip tap
+// ---------------------------------------------------------------------------------
+struct ActBwdArgs {
+  const float* a;
+  const float* dh;
+  const float* dskip;
+  const float* slope;
+  const float* alpha;
+  const float* mean;
+  const float* rstd;
+  const float* gamma;
+  const float* beta;
+  float* da;
+  float* ws;      // [nsplit][C][4] partials, then [C][2] totals of (dbeta, dgamma)
+  int B, C, L, nsplit;
+};
+
+// PHASE 0: no BN (single pass).  PHASE 1: BN reductions.  PHASE 2: BN apply.
+template <int PHASE>
+__global__ void act_bwd_kernel(const ActBwdArgs p) {
+  __shared__ float sm[16];
+  const ChanRange cr = chan_range(p.B, p.nsplit);
+  const int c = cr.c;
+  const int nb = cr.b_end - cr.b_beg;
+  const long cnt = (long)(nb > 0 ? nb : 0) * p.L;
+  const float sl = p.slope ? p.slope[c] : 1.0f;
+  const float al = p.alpha ? p.alpha[c] : 0.0f;
+  float mu = 0.f, rs = 1.f, ga = 1.f, be = 0.f, dbeta_m = 0.f, dgamma_m = 0.f;
+  if (PHASE != 0) {
+    mu = p.mean[c];
+    rs = p.rstd[c];
+    ga = p.gamma ? p.gamma[c] : 1.0f;
+    be = p.beta ? p.beta[c] : 0.0f;
+  }
+  if (PHASE == 2) {
+    const float* tot = p.ws + (size_t)p.nsplit * p.C * 4 + (size_t)c * 2;
+    const float invn = 1.0f / ((float)p.B * (float)p.L);
+    dbeta_m = tot[0] * invn;
+    dgamma_m = tot[1] * invn;
+  }
+  float r[3] = {0.f, 0.f, 0.f};
+  for (long e = threadIdx.x; e < cnt; e += PW_THREADS) {
+    const int b = cr.b_beg + (int)(e / p.L);
+    const int t = (int)(e % p.L);
+    const size_t i = ((size_t)b * p.C + c) * p.L + t;
+    const float av = p.a[i];
+    const float dh = p.dh ? p.dh[i] : 0.0f;
+    if (PHASE == 0) {
+      float g = dh * (av > 0.f ? 1.0f : sl);
+      r[0] += dh * (av > 0.f ? 0.0f : av);
+      if (p.dskip) {
+        const float ds = p.dskip[i];
+        g = fmaf(al, ds, g);
+        r[1] = fmaf(ds, av, r[1]);
+      }
+      r[2] += g;
+      p.da[i] = g;
+    } else {
+      const float xh = (av - mu) * rs;
+      const float v = fmaf(ga, xh, be);
+      const float g = dh * (v > 0.f ? 1.0f : sl);
+      if (PHASE == 1) {
+        r[0] += dh * (v > 0.f ? 0.0f : v);
+        r[1] += g;
+        r[2] = fmaf(g, xh, r[2]);
+      } else {
+        const float d = ga * rs * (g - dbeta_m - xh * dgamma_m);
+        r[0] += d;
+        p.da[i] = d;
+      }
+    }
+  }
+  block_sum<3>(r, sm);
+  if (threadIdx.x == 0) {
+    float* w = p.ws + ((size_t)blockIdx.y * p.C + c) * 4;
+    w[0] = r[0];
+    w[1] = r[1];
+    w[2] = r[2];
+  }
+}
+
+// one thread per channel: sum partials, accumulate into the parameter gradients
+template <int PHASE>
+__global__ void act_bwd_final_kernel(const ActBwdArgs p, float* dslope, float* dalpha,
+                                     float* dgamma, float* dbeta, float* dbias) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= p.C) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  for (int s = 0; s < p.nsplit; ++s) {
+    const float* w = p.ws + ((size_t)s * p.C + c) * 4;
+    s0 += w[0];
+    s1 += w[1];
+    s2 += w[2];
+  }
+  if (PHASE == 0) {
+    if (dslope) dslope[c] += s0;
+    if (dalpha) dalpha[c] += s1;
+    if (dbias) dbias[c] += s2;
+  } else if (PHASE == 1) {
+    if (dslope) dslope[c] += s0;
+    if (dbeta) dbeta[c] += s1;
+    if (dgamma) dgamma[c] += s2;
+    float* tot = p.ws + (size_t)p.nsplit * p.C * 4 + (size_t)c * 2;
+    tot[0] = s1;
+    tot[1] = s2;
+  } else {
+    if (dbias) dbias[c] += s0;
+  }
+}
+
+extern "C" int segan_act_bwd(const float* a, const float* dh, const float* dskip,
+                             const float* slope, const float* alpha, const float* bn_mean,
+                             const float* bn_rstd, const float* bn_gamma, const float* bn_beta,
+                             float* da, float* dslope, float* dalpha, float* dgamma, float* dbeta,
+                             float* dbias, float* ws, int B, int C, int L, void* stream) {
+  SEGAN_REQUIRE(a && da && ws, "act_bwd: NULL pointer");
+  SEGAN_REQUIRE(dh || dskip, "act_bwd: no incoming gradient");
+  SEGAN_REQUIRE(B > 0 && C > 0 && L > 0, "act_bwd: bad sizes");
+  SEGAN_REQUIRE((bn_mean == nullptr) == (bn_rstd == nullptr), "act_bwd: mean/rstd must pair");
+  SEGAN_REQUIRE(!(dskip && !alpha), "act_bwd: dskip needs alpha");
+  SEGAN_REQUIRE(!(bn_mean && dskip), "act_bwd: BN layers have no skip tap");
+  hipStream_t st = (hipStream_t)stream;
+  ActBwdArgs p;
+  p.a = a; p.dh = dh; p.dskip = dskip; p.slope = slope; p.alpha = alpha;
+  p.mean = bn_mean; p.rstd = bn_rstd; p.gamma = bn_gamma; p.beta = bn_beta;
+  p.da = da; p.ws = ws; p.B = B; p.C = C; p.L = L;
+  p.nsplit = pw_nsplit(B, C, L);
+  const dim3 grid(C, p.nsplit), fgrid(ceil_div(C, 64));
+  if (!bn_mean) {
+    hipLaunchKernelGGL(act_bwd_kernel<0>, grid, dim3(PW_THREADS), 0, st, p);
+    hipLaunchKernelGGL(act_bwd_final_kernel<0>, fgrid, dim3(64), 0, st, p, dslope, dalpha, dgamma,
+                       dbeta, dbias);
+  } else {
+    hipLaunchKernelGGL(act_bwd_kernel<1>, grid, dim3(PW_THREADS), 0, st, p);
+    hipLaunchKernelGGL(act_bwd_final_kernel<1>, fgrid, dim3(64), 0, st, p, dslope, dalpha, dgamma,
+                       dbeta, dbias);
+    hipLaunchKernelGGL(act_bwd_kernel<2>, grid, dim3(PW_THREADS), 0, st, p);
+    hipLaunchKernelGGL(act_bwd_final_kernel<2>, fgrid, dim3(64), 0, st, p, dslope, dalpha, dgamma,
+                       dbeta, dbias);
+  }
+  return segan_check_launch("act_bwd");
+}
+
+// ---------------------------------------------------------------------------------
+// tanh backward (+ fused L1 term)
+// ---------------------------------------------------------------------------------
+__global__ void tanh_bwd_kernel(const float* __restrict__ y, const float* dy, const float* clean,
+                                float l1_scale, float* __restrict__ da, float* ws, int B, int C,
+                                int L, int nsplit) {
+  __shared__ float sm[16];
+  const ChanRange cr = chan_range(B, nsplit);
+  const int nb = cr.b_end - cr.b_beg;
+  const long cnt = (long)(nb > 0 ? nb : 0) * L;
+  float r[1] = {0.f};
+  for (long e = threadIdx.x; e < cnt; e += PW_THREADS) {
+    const int b = cr.b_beg + (int)(e / L);
+    const int t = (int)(e % L);
+    const size_t i = ((size_t)b * C + cr.c) * L + t;
+    const float yv = y[i];
+    float g = dy ? dy[i] : 0.0f;
+    if (clean) {
+      const float d = yv - clean[i];
+      g += l1_scale * (d > 0.f ? 1.0f : (d < 0.f ? -1.0f : 0.0f));
+    }
+    const float d = g * (1.0f - yv * yv);
+    da[i] = d;
+    r[0] += d;
+  }
+  block_sum<1>(r, sm);
+  if (threadIdx.x == 0) ws[(size_t)blockIdx.y * C + cr.c] = r[0];
+}
+
+__global__ void sum_splits_add_kernel(const float* ws, float* out, int C, int nsplit) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int k = 0; k < nsplit; ++k) s += ws[(size_t)k * C + c];
+  out[c] += s;
+}
+
+extern "C" int segan_tanh_bwd(const float* y, const float* dy, const float* clean, float l1_scale,
+                              float* da, float* dbias, float* ws, int B, int C, int L,
+                              void* stream) {
+  SEGAN_REQUIRE(y && da && ws, "tanh_bwd: NULL pointer");
+  SEGAN_REQUIRE(dy || clean, "tanh_bwd: no incoming gradient");
+  SEGAN_REQUIRE(B > 0 && C > 0 && L > 0, "tanh_bwd: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  const int ns = pw_nsplit(B, C, L);
+  hipLaunchKernelGGL(tanh_bwd_kernel, dim3(C, ns), dim3(PW_THREADS), 0, st, y, dy, clean, l1_scale,
+                     da, ws, B, C, L, ns);
+  if (dbias)
+    hipLaunchKernelGGL(sum_splits_add_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, ws, dbias, C,
+                       ns);
+  return segan_check_launch("tanh_bwd");
+}
+
+// ---------------------------------------------------------------------------------
+// dense head: bias + PReLU over [rows, cols]
+// ---------------------------------------------------------------------------------
+__global__ void bias_prelu_rows_kernel(const float* __restrict__ x, const float* bias,
+                                       const float* slope, float* __restrict__ y, int rows,
+                                       int cols) {
+  const size_t total = (size_t)rows * cols;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cols);
+    float v = x[i] + (bias ? bias[c] : 0.0f);
+    if (slope) v = v > 0.f ? v : v * slope[c];
+    y[i] = v;
+  }
+}
+
+extern "C" int segan_bias_prelu_rows(const float* x, const float* bias, const float* slope,
+                                     float* y, int rows, int cols, void* stream) {
+  SEGAN_REQUIRE(x && y && rows > 0 && cols > 0, "bias_prelu_rows: bad arguments");
+  const size_t total = (size_t)rows * cols;
+  const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+  hipLaunchKernelGGL(bias_prelu_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x,
+                     bias, slope, y, rows, cols);
+  return segan_check_launch("bias_prelu_rows");
+}
+
+// one thread per column walks the rows (rows = batch, a few hundred): deterministic
+__global__ void bias_prelu_rows_bwd_kernel(const float* __restrict__ x, const float* bias,
+                                           const float* slope, const float* __restrict__ dy,
+                                           float* __restrict__ dx, float* dslope, float* dbias,
+                                           int rows, int cols) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  const float bs = bias ? bias[c] : 0.0f;
+  const float sl = slope ? slope[c] : 1.0f;
+  float s_sl = 0.f, s_b = 0.f;
+  for (int r = 0; r < rows; ++r) {
+    const size_t i = (size_t)r * cols + c;
+    const float v = x[i] + bs;
+    const float g = dy[i];
+    const float d = g * (v > 0.f ? 1.0f : sl);
+    s_sl += g * (v > 0.f ? 0.0f : v);
+    s_b += d;
+    dx[i] = d;
+  }
+  if (dslope && slope) dslope[c] += s_sl;
+  if (dbias) dbias[c] += s_b;
+}
+
+extern "C" int segan_bias_prelu_rows_bwd(const float* x, const float* bias, const float* slope,
+                                         const float* dy, float* dx, float* dslope, float* dbias,
+                                         int rows, int cols, void* stream) {
+  SEGAN_REQUIRE(x && dy && dx && rows > 0 && cols > 0, "bias_prelu_rows_bwd: bad arguments");
+  hipLaunchKernelGGL(bias_prelu_rows_bwd_kernel, dim3(ceil_div(cols, 64)), dim3(64), 0,
+                     (hipStream_t)stream, x, bias, slope, dy, dx, dslope, dbias, rows, cols);
+  return segan_check_launch("bias_prelu_rows_bwd");
+}
+
+// ---------------------------------------------------------------------------------
+// losses
+// ---------------------------------------------------------------------------------
+__global__ void mse_const_kernel(const float* __restrict__ x, float target, float* loss,
+                                 float* grad, const float* gout, float gscale, int n) {
+  __shared__ float sm[16];
+  float r[1] = {0.f};
+  const float inv = 1.0f / (float)n;
+  if (gout) gscale *= gout[0];
+  for (int i = threadIdx.x; i < n; i += PW_THREADS) {
+    const float d = x[i] - target;
+    r[0] = fmaf(d, d, r[0]);
+    if (grad) grad[i] = 2.0f * d * inv * gscale;
+  }
+  block_sum<1>(r, sm);
+  if (threadIdx.x == 0 && loss) loss[0] = r[0] * inv;
+}
+
+extern "C" int segan_mse_const(const float* x, float target, float* loss, float* grad,
+                               const float* gout, float gscale, int n, void* stream) {
+  SEGAN_REQUIRE(x && n > 0 && (loss || grad), "mse_const: bad arguments");
+  hipLaunchKernelGGL(mse_const_kernel, dim3(1), dim3(PW_THREADS), 0, (hipStream_t)stream, x, target,
+                     loss, grad, gout, gscale, n);
+  return segan_check_launch("mse_const");
+}
+
+__global__ void l1_partial_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                  float* ws, size_t n) {
+  __shared__ float sm[16];
+  float r[1] = {0.f};
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x)
+    r[0] += fabsf(x[i] - y[i]);
+  block_sum<1>(r, sm);
+  if (threadIdx.x == 0) ws[blockIdx.x] = r[0];
+}
+__global__ void l1_final_kernel(const float* ws, float* loss, int nblocks, float inv) {
+  __shared__ float sm[16];
+  float r[1] = {0.f};
+  for (int i = threadIdx.x; i < nblocks; i += PW_THREADS) r[0] += ws[i];
+  block_sum<1>(r, sm);
+  if (threadIdx.x == 0) loss[0] = r[0] * inv;
+}
+
+extern "C" int segan_l1_mean(const float* x, const float* y, float* loss, float* ws, int64_t n,
+                             void* stream) {
+  SEGAN_REQUIRE(x && y && loss && ws && n > 0, "l1_mean: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  int blocks = (int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256);
+  hipLaunchKernelGGL(l1_partial_kernel, dim3(blocks), dim3(PW_THREADS), 0, st, x, y, ws, (size_t)n);
+  hipLaunchKernelGGL(l1_final_kernel, dim3(1), dim3(PW_THREADS), 0, st, ws, loss, blocks,
+                     1.0f / (float)n);
+  return segan_check_launch("l1_mean");
+}
+
+__global__ void l1_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                              const float* gout, float gscale, float* __restrict__ grad, size_t n) {
+  const float g = gscale * (gout ? gout[0] : 1.0f) / (float)n;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const float d = x[i] - y[i];
+    grad[i] = d > 0.f ? g : (d < 0.f ? -g : 0.0f);
+  }
+}
+
+extern "C" int segan_l1_bwd(const float* x, const float* y, const float* gout, float gscale,
+                            float* grad, int64_t n, void* stream) {
+  SEGAN_REQUIRE(x && y && grad && n > 0, "l1_bwd: bad arguments");
+  int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+  hipLaunchKernelGGL(l1_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, gout,
+                     gscale, grad, (size_t)n);
+  return segan_check_launch("l1_bwd");
+}
+
+// ---------------------------------------------------------------------------------
+// optimizers over a flat fp32 arena
+// ---------------------------------------------------------------------------------
+__global__ void rmsprop_kernel(float* __restrict__ p, const float* __restrict__ g,
+                               float* __restrict__ sq, float lr, float alpha, float eps, size_t n) {
+  const size_t n4 = n / 4;
+  float4* p4 = reinterpret_cast<float4*>(p);
+  const float4* g4 = reinterpret_cast<const float4*>(g);
+  float4* s4 = reinterpret_cast<float4*>(sq);
+  const float oma = 1.0f - alpha;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4;
+       i += (size_t)gridDim.x * blockDim.x) {
+    float4 pv = p4[i], gv = g4[i], sv = s4[i];
+#define RMS1(f)                                       \
+  sv.f = alpha * sv.f + oma * gv.f * gv.f;            \
+  pv.f = pv.f - lr * (gv.f / (sqrtf(sv.f) + eps));
+    RMS1(x) RMS1(y) RMS1(z) RMS1(w)
+#undef RMS1
+    p4[i] = pv;
+    s4[i] = sv;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const size_t i = n4 * 4 + threadIdx.x;
+    const float gv = g[i];
+    const float sv = alpha * sq[i] + oma * gv * gv;
+    sq[i] = sv;
+    p[i] = p[i] - lr * (gv / (sqrtf(sv) + eps));
+  }
+}
+
+extern "C" int segan_rmsprop_step(float* p, const float* g, float* sq, float lr, float alpha,
+                                  float eps, int64_t n, void* stream) {
+  SEGAN_REQUIRE(p && g && sq && n > 0, "rmsprop_step: bad arguments");
+  SEGAN_REQUIRE(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)sq % 16 == 0),
+                "rmsprop_step: arenas must be 16-byte aligned");
+  int blocks = (int)((n / 4 + 255) / 256 > 2048 ? 2048 : (n / 4 + 255) / 256);
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(rmsprop_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, sq, lr,
+                     alpha, eps, (size_t)n);
+  return segan_check_launch("rmsprop_step");
+}
+
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                            float* __restrict__ m, float* __restrict__ v, float step_size,
+                            float beta1, float beta2, float eps, float inv_sqrt_bc2, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const float gv = g[i];
+    // torch: exp_avg.lerp_(grad, 1-beta1); exp_avg_sq = beta2*v + (1-beta2)*g*g
+    const float mv = m[i] + (gv - m[i]) * (1.0f - beta1);
+    const float vv = beta2 * v[i] + (1.0f - beta2) * gv * gv;
+    m[i] = mv;
+    v[i] = vv;
+    const float denom = sqrtf(vv) * inv_sqrt_bc2 + eps;
+    p[i] = p[i] - step_size * (mv / denom);
+  }
+}
+
+extern "C" int segan_adam_step(float* p, const float* g, float* m, float* v, float lr, float beta1,
+                               float beta2, float eps, int step, int64_t n, void* stream) {
+  SEGAN_REQUIRE(p && g && m && v && n > 0 && step >= 1, "adam_step: bad arguments");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const float step_size = (float)((double)lr / bc1);
+  const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
+                     step_size, beta1, beta2, eps, inv_sqrt_bc2, (size_t)n);
+  return segan_check_launch("adam_step");
+}
+
+__global__ void fill_kernel(float* p, float value, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x)
+    p[i] = value;
+}
+__global__ void scale_kernel(float* p, float s, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x)
+    p[i] *= s;
+}
+extern "C" int segan_fill(float* p, float value, int64_t n, void* stream) {
+  SEGAN_REQUIRE(p && n > 0, "fill: bad arguments");
+  int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+  hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, value,
+                     (size_t)n);
+  return segan_check_launch("fill");
+}
+extern "C" int segan_scale(float* p, float s, int64_t n, void* stream) {
+  SEGAN_REQUIRE(p && n > 0, "scale: bad arguments");
+  int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+  hipLaunchKernelGGL(scale_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, s,
+                     (size_t)n);
+  return segan_check_launch("scale");
+}

@@ -1,0 +1,100 @@
+"""Data-parallel plumbing: one process per GPU, RCCL (backend 'nccl' on ROCm) over
+xGMI.  The reference is single-process (README.md:79, "Multi-GPU is not supported
+yet"); this is the new data-parallel path SURVEY.md section 8(e) specifies:
+
+* every rank holds a full replica of G and D and its own optimizer state;
+* the batch is sharded across ranks (rank r trains on its own 1/world slice);
+* ONE all-reduce per network per step on the flat gradient arena of its optimizer
+  (D: 25.8 M floats between the D backward passes and ``Dopt.step``; G: 64.8 M floats
+  between the G backward and ``Gopt.step``), then a 1/world scale, so every rank
+  applies the gradient of the mean loss over the global batch;
+* BatchNorm statistics stay local to a rank (standard DDP semantics: each replica is
+  the reference at its per-GPU batch size).
+
+On CPU tensors (gloo) the same code runs with torch arithmetic, which is what the
+world_size-2 tests exercise.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+from . import ops
+
+
+def is_dist():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def world_size():
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+
+def rank():
+    return dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+
+
+def init_from_env(backend=None):
+    """Initialise the default process group from the torchrun environment
+    (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT).  No-op when
+    WORLD_SIZE is absent or 1.  Returns (rank, world_size, local_rank)."""
+    ws = int(os.environ.get('WORLD_SIZE', '1'))
+    rk = int(os.environ.get('RANK', '0'))
+    lr = int(os.environ.get('LOCAL_RANK', '0'))
+    if ws <= 1:
+        return 0, 1, lr
+    if not dist.is_initialized():
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        if backend == 'nccl':
+            torch.cuda.set_device(lr)
+            dist.init_process_group(backend, rank=rk, world_size=ws,
+                                    device_id=torch.device('cuda', lr))
+        else:
+            dist.init_process_group(backend, rank=rk, world_size=ws)
+    return rk, ws, lr
+
+
+def allreduce_mean_(flat):
+    """In-place mean over ranks of a flat fp32 tensor (one collective)."""
+    ws = world_size()
+    if ws <= 1:
+        return flat
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    if flat.is_cuda:
+        ops.scale_(flat, 1.0 / ws)
+    else:
+        flat.mul_(1.0 / ws)
+    return flat
+
+
+def allreduce_grads(optimizer):
+    """Average the gradients of every parameter the optimizer owns across ranks."""
+    if world_size() <= 1:
+        return
+    optimizer._resync()
+    allreduce_mean_(optimizer.flat_grad)
+
+
+def broadcast_params(module, src=0):
+    """Make every replica start from rank `src`'s weights and buffers."""
+    if world_size() <= 1:
+        return
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t.data, src)
+    ops.bump_weights_epoch()
+
+
+def shard_batch(t, dim=0):
+    """This rank's contiguous slice of a global batch."""
+    ws, rk = world_size(), rank()
+    if ws <= 1:
+        return t
+    n = t.shape[dim]
+    if n % ws != 0:
+        raise ValueError('global batch {} is not divisible by world size {}'.format(n, ws))
+    per = n // ws
+    return t.narrow(dim, rk * per, per)

@@ -1,0 +1,422 @@
+"""Autograd glue: whole-network ``torch.autograd.Function``s that drive the HIP kernels.
+
+The generator and the discriminator are each ONE autograd node.  Inside a node the
+layers exchange *pre-activations*; PReLU, BatchNorm-normalise, the alpha skip scale,
+the z / skip concatenations and the discriminator's phase shift are applied by the
+consuming kernel while it stages its tile (``ops.Src``), so the reference's
+intermediate tensors (h, sk_h, torch.cat outputs, padded/rolled copies) never exist.
+
+Parameter gradients are accumulated by the kernels directly into ``param.grad``
+(allocated zero-filled on first use) — exactly torch's accumulate-into-.grad
+semantics, minus the temporary — and the nodes return ``None`` for parameter inputs.
+
+Reference semantics followed: segan/models/generator.py:180-230,
+segan/models/discriminator.py:150-194, segan/models/modules.py:91-141.
+"""
+import torch
+
+from . import ops
+from .ops import ACT_NONE, ACT_TANH, PAD_REFLECT, PAD_ZERO, Src
+
+
+def grad_buf(p):
+    """The tensor the kernels accumulate this parameter's gradient into."""
+    if p.grad is None:
+        p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
+    elif not p.grad.is_contiguous():
+        p.grad = p.grad.contiguous()
+    return p.grad
+
+
+def _gb(p, needed=True):
+    if p is None or not needed or not p.requires_grad:
+        return None
+    return grad_buf(p)
+
+
+def _ones(n, ref):
+    return torch.ones(n, device=ref.device, dtype=torch.float32)
+
+
+def _cat(a, b):
+    return torch.cat((a.detach().reshape(-1), b.detach().reshape(-1)))
+
+
+# =====================================================================================
+# Generator
+# =====================================================================================
+class GeneratorFn(torch.autograd.Function):
+    """y = G(x, z) for an encoder/decoder generator (generator.py:180-230)."""
+
+    @staticmethod
+    def forward(ctx, gen, want_hid, x, z, *params):
+        x = x.contiguous()
+        enc, dec = list(gen.enc_blocks), list(gen.dec_blocks)
+        n_enc = len(enc)
+        a_enc, src_enc = [], []
+        src = Src(x)
+        for blk in enc:
+            a = ops.conv1d_fwd(src, blk.conv.weight, blk.conv.bias, blk.stride, pack=blk._pack)
+            src_enc.append(src)
+            a_enc.append(a)
+            src = Src(a, slope=blk.act.weight)
+        last = a_enc[-1]
+        s_last = enc[-1].act.weight
+        if not gen.no_z:
+            z = z.contiguous()
+            src = Src(z, last, slope=_cat(_ones(z.shape[1], z), s_last))
+        else:
+            src = Src(last, slope=s_last)
+        a_dec, src_dec = [], []
+        enc_idx = n_enc - 1
+        for li, blk in enumerate(dec):
+            if li > 0:
+                prev = a_dec[-1]
+                s_prev = dec[li - 1].act.weight
+                if gen.skip and enc_idx in gen.skips and gen.dec_poolings[li] > 1:
+                    alpha = gen.skips[enc_idx]['alpha'].skip_k
+                    aj = a_enc[enc_idx]
+                    src = Src(prev, aj,
+                              scale=_cat(_ones(prev.shape[1], prev), alpha),
+                              slope=_cat(s_prev, _ones(aj.shape[1], aj)))
+                else:
+                    src = Src(prev, slope=s_prev)
+            act = ACT_TANH if blk.is_tanh else ACT_NONE
+            a = ops.deconv1d_fwd(src, blk.deconv.weight, blk.deconv.bias, blk.stride, act,
+                                 pack=blk._pack)
+            src_dec.append(src)
+            a_dec.append(a)
+            enc_idx -= 1
+        y = a_dec[-1]
+        ctx.gen = gen
+        ctx.set_materialize_grads(False)
+        ctx.x_needs = x.requires_grad
+        ctx.state = (x, z, a_enc, src_enc, a_dec, src_dec)
+        hid = None
+        if want_hid:
+            hid = {}
+            for i, blk in enumerate(enc):
+                hid['enc_{}'.format(i)] = ops.affine_prelu(a_enc[i], slope=blk.act.weight)
+            if not gen.no_z:
+                hid['enc_zc'] = torch.cat((z, hid['enc_{}'.format(n_enc - 1)]), dim=1)
+            for i, blk in enumerate(dec):
+                hid['dec_{}'.format(i)] = (a_dec[i] if blk.is_tanh else
+                                           ops.affine_prelu(a_dec[i], slope=blk.act.weight))
+        ctx.mark_non_differentiable(*([] if hid is None else list(hid.values())))
+        if hid is None:
+            return y
+        return (y,) + tuple(hid.values())
+
+    @staticmethod
+    def backward(ctx, dy, *unused):
+        gen = ctx.gen
+        x, z, a_enc, src_enc, a_dec, src_dec = ctx.state
+        enc, dec = list(gen.enc_blocks), list(gen.dec_blocks)
+        n_enc, n_dec = len(enc), len(dec)
+        if dy is None:
+            return (None,) * len(ctx.needs_input_grad)
+        dy = dy.contiguous()
+        dh = dy
+        dskip = {}          # enc index -> gradient w.r.t. alpha * a_enc
+        dh_last_enc = None  # gradient w.r.t. h of the last encoder layer
+        # ---- decoder, last to first ----
+        da = None
+        for li in range(n_dec - 1, -1, -1):
+            blk = dec[li]
+            w = blk.deconv.weight
+            K, S = blk.kwidth, blk.stride
+            if blk.is_tanh:
+                da = ops.tanh_bwd(a_dec[li], dy, dbias=_gb(blk.deconv.bias))
+            else:
+                da = ops.act_bwd(a_dec[li], dh, slope=blk.act.weight,
+                                 dslope=_gb(blk.act.weight), dbias=_gb(blk.deconv.bias))
+            src = src_dec[li]
+            if w.requires_grad:
+                ops.wgrad(src, Src(da), grad_buf(w), K, S, ops.deconv_pad(K, S), PAD_ZERO)
+            if li == 0:
+                if gen.no_z:
+                    _d0, dh_last_enc = ops.deconv1d_dgrad(da, w, S, 0, pack=blk._pack)
+                else:
+                    # the z half of the input needs no gradient: its tiles are skipped
+                    _d0, dh_last_enc = ops.deconv1d_dgrad(da, w, S, src.C0, need0=False,
+                                                          pack=blk._pack)
+            else:
+                if src.C1 > 0:
+                    dh, dsk = ops.deconv1d_dgrad(da, w, S, src.C0, pack=blk._pack)
+                    dskip[n_enc - 1 - li] = dsk
+                else:
+                    _d0, dh = ops.deconv1d_dgrad(da, w, S, 0, pack=blk._pack)
+        # ---- encoder, last to first ----
+        dh = dh_last_enc
+        dx = None
+        for l in range(n_enc - 1, -1, -1):
+            blk = enc[l]
+            w = blk.conv.weight
+            K, S = blk.kwidth, blk.stride
+            alpha_p = gen.skips[l]['alpha'].skip_k if (gen.skip and l in gen.skips) else None
+            dsk = dskip.get(l)
+            da = ops.act_bwd(a_enc[l], dh, dskip=dsk, slope=blk.act.weight,
+                             alpha=alpha_p if dsk is not None else None,
+                             dslope=_gb(blk.act.weight),
+                             dalpha=_gb(alpha_p, dsk is not None),
+                             dbias=_gb(blk.conv.bias))
+            padL = ops.conv_pad(K, S)[0]
+            if w.requires_grad:
+                ops.wgrad(Src(da), src_enc[l], grad_buf(w), K, S, padL, PAD_REFLECT)
+            if l > 0:
+                dh = ops.conv1d_dgrad(da, w, src_enc[l].L, S, pack=blk._pack)
+            elif ctx.x_needs:
+                dx = ops.conv1d_dgrad(da, w, src_enc[l].L, S, pack=blk._pack)
+        ctx.state = None
+        return (None, None, dx, None) + (None,) * (len(ctx.needs_input_grad) - 4)
+
+
+# =====================================================================================
+# Discriminator
+# =====================================================================================
+class DiscriminatorFn(torch.autograd.Function):
+    """logit = D(x) (discriminator.py:150-194) with the phase shifts given as rolls."""
+
+    @staticmethod
+    def forward(ctx, disc, rolls, x, *params):
+        x = x.contiguous()
+        blocks = list(disc.enc_blocks)
+        training = disc.training
+        src = Src(x)
+        cs, srcs, bns, xfs = [], [], [], []
+        for l, blk in enumerate(blocks):
+            c = ops.conv1d_fwd(src, blk.conv.weight, blk.conv.bias, blk.stride, roll=rolls[l],
+                               pack=blk._pack)
+            srcs.append(src)
+            cs.append(c)
+            if blk.norm is not None:
+                bn = blk.norm
+                if training:
+                    mean, rstd, scale, shift = ops.bn_stats(
+                        c, bn.weight, bn.bias, bn.eps,
+                        bn.momentum if bn.momentum is not None else 0.1,
+                        bn.running_mean, bn.running_var)
+                    if bn.num_batches_tracked is not None:
+                        bn.num_batches_tracked += 1
+                    bns.append((mean, rstd, bn.weight, bn.bias))
+                else:
+                    rstd = torch.rsqrt(bn.running_var + bn.eps)
+                    scale = (bn.weight.detach() * rstd).contiguous()
+                    shift = (bn.bias.detach() - bn.running_mean * scale).contiguous()
+                    bns.append('eval')
+                xfs.append((scale, shift))
+                src = Src(c, scale=scale, shift=shift, slope=blk.act.weight)
+            else:
+                bns.append(None)
+                xfs.append((None, None))
+                src = Src(c, slope=blk.act.weight)
+        # dense head on h.view(B, -1) (discriminator.py:180-182)
+        h = ops.affine_prelu(cs[-1], xfs[-1][0], xfs[-1][1], blocks[-1].act.weight)
+        B = h.shape[0]
+        hf = h.view(B, -1)
+        fc = disc.fc
+        y1 = ops.linear_fwd(hf, fc[0].weight)
+        a1 = ops.bias_prelu_rows(y1, fc[0].bias, fc[1].weight)
+        y2 = ops.linear_fwd(a1, fc[2].weight)
+        a2 = ops.bias_prelu_rows(y2, fc[2].bias, fc[3].weight)
+        y3 = ops.linear_fwd(a2, fc[4].weight)
+        out = ops.bias_prelu_rows(y3, fc[4].bias, None)
+        ctx.disc = disc
+        ctx.rolls = tuple(rolls)
+        ctx.x_needs = x.requires_grad
+        ctx.state = (cs, srcs, bns, hf, y1, a1, y2, a2, y3)
+        disc._last_fwd = (cs, xfs)      # for the lazy int_act dict
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        disc = ctx.disc
+        cs, srcs, bns, hf, y1, a1, y2, a2, y3 = ctx.state
+        blocks = list(disc.enc_blocks)
+        fc = disc.fc
+        dout = dout.contiguous()
+        any_param = any(p.requires_grad for p in disc.parameters())
+        # ---- dense head ----
+        dy3 = ops.bias_prelu_rows_bwd(y3, fc[4].bias, None, dout, None, _gb(fc[4].bias))
+        if fc[4].weight.requires_grad:
+            ops.linear_wgrad(dy3, a2, grad_buf(fc[4].weight))
+        da2 = ops.linear_dgrad(dy3, fc[4].weight)
+        dy2 = ops.bias_prelu_rows_bwd(y2, fc[2].bias, fc[3].weight, da2, _gb(fc[3].weight),
+                                      _gb(fc[2].bias))
+        if fc[2].weight.requires_grad:
+            ops.linear_wgrad(dy2, a1, grad_buf(fc[2].weight))
+        da1 = ops.linear_dgrad(dy2, fc[2].weight)
+        dy1 = ops.bias_prelu_rows_bwd(y1, fc[0].bias, fc[1].weight, da1, _gb(fc[1].weight),
+                                      _gb(fc[0].bias))
+        if fc[0].weight.requires_grad:
+            ops.linear_wgrad(dy1, hf, grad_buf(fc[0].weight))
+        dh = ops.linear_dgrad(dy1, fc[0].weight).view(cs[-1].shape)
+        # ---- conv stack ----
+        dx = None
+        for l in range(len(blocks) - 1, -1, -1):
+            blk = blocks[l]
+            w = blk.conv.weight
+            K, S = blk.kwidth, blk.stride
+            bn = bns[l]
+            if bn == 'eval':
+                raise RuntimeError('Discriminator backward in eval() mode with BatchNorm is not '
+                                   'supported; call .train() (the reference never does this)')
+            if bn is not None:
+                dc = ops.act_bwd(cs[l], dh, slope=blk.act.weight, bn=bn,
+                                 dslope=_gb(blk.act.weight), dgamma=_gb(bn[2]), dbeta=_gb(bn[3]),
+                                 dbias=_gb(blk.conv.bias))
+            else:
+                dc = ops.act_bwd(cs[l], dh, slope=blk.act.weight, dslope=_gb(blk.act.weight),
+                                 dbias=_gb(blk.conv.bias))
+            padL = ops.conv_pad(K, S)[0]
+            if w.requires_grad:
+                ops.wgrad(Src(dc), srcs[l], grad_buf(w), K, S, padL, PAD_REFLECT, roll=ctx.rolls[l])
+            if l > 0:
+                dh = ops.conv1d_dgrad(dc, w, srcs[l].L, S, roll=ctx.rolls[l], pack=blk._pack)
+            elif ctx.x_needs:
+                dx = ops.conv1d_dgrad(dc, w, srcs[l].L, S, roll=ctx.rolls[l], pack=blk._pack)
+        ctx.state = None
+        del any_param
+        return (None, None, dx) + (None,) * (len(ctx.needs_input_grad) - 3)
+
+
+# =====================================================================================
+# stand-alone blocks (modules.py:73-141)
+# =====================================================================================
+class ConvBlockFn(torch.autograd.Function):
+    """(h, a) = GConv1DBlock(x): reflect pad + strided conv (+BatchNorm) + PReLU."""
+
+    @staticmethod
+    def forward(ctx, blk, x, *params):
+        x = x.contiguous()
+        src = Src(x)
+        c = ops.conv1d_fwd(src, blk.conv.weight, blk.conv.bias, blk.stride, pack=blk._pack)
+        bn_saved = None
+        scale = shift = None
+        if blk.norm is not None:
+            bn = blk.norm
+            if blk.training:
+                mean, rstd, scale, shift = ops.bn_stats(
+                    c, bn.weight, bn.bias, bn.eps, bn.momentum if bn.momentum is not None else 0.1,
+                    bn.running_mean, bn.running_var)
+                if bn.num_batches_tracked is not None:
+                    bn.num_batches_tracked += 1
+                bn_saved = (mean, rstd, bn.weight, bn.bias)
+            else:
+                rstd = torch.rsqrt(bn.running_var + bn.eps)
+                scale = (bn.weight.detach() * rstd).contiguous()
+                shift = (bn.bias.detach() - bn.running_mean * scale).contiguous()
+                bn_saved = 'eval'
+        h = ops.affine_prelu(c, scale, shift, blk.act.weight)
+        a = c if blk.norm is None else ops.affine_prelu(c, scale, shift, None)
+        ctx.blk = blk
+        ctx.set_materialize_grads(False)
+        ctx.x_needs = x.requires_grad
+        ctx.state = (src, c, bn_saved)
+        return h, a
+
+    @staticmethod
+    def backward(ctx, dh, da_lin):
+        blk = ctx.blk
+        src, c, bn = ctx.state
+        K, S = blk.kwidth, blk.stride
+        w = blk.conv.weight
+        if dh is None and da_lin is None:
+            return (None,) * len(ctx.needs_input_grad)
+        dh = dh.contiguous() if dh is not None else None
+        if bn is None:
+            lin = da_lin.contiguous() if da_lin is not None else None
+            dc = ops.act_bwd(c, dh, dskip=lin, slope=blk.act.weight,
+                             alpha=_ones(c.shape[1], c) if lin is not None else None,
+                             dslope=_gb(blk.act.weight), dbias=_gb(blk.conv.bias))
+        else:
+            if bn == 'eval':
+                raise RuntimeError('GConv1DBlock backward with BatchNorm in eval() is unsupported')
+            if da_lin is not None or dh is None:
+                raise RuntimeError('gradient through the linear output of a normalised '
+                                   'GConv1DBlock is unsupported')
+            dc = ops.act_bwd(c, dh, slope=blk.act.weight, bn=bn, dslope=_gb(blk.act.weight),
+                             dgamma=_gb(bn[2]), dbeta=_gb(bn[3]), dbias=_gb(blk.conv.bias))
+        padL = ops.conv_pad(K, S)[0]
+        if w.requires_grad:
+            ops.wgrad(Src(dc), src, grad_buf(w), K, S, padL, PAD_REFLECT)
+        dx = ops.conv1d_dgrad(dc, w, src.L, S, pack=blk._pack) if ctx.x_needs else None
+        ctx.state = None
+        return (None, dx) + (None,) * (len(ctx.needs_input_grad) - 2)
+
+
+class DeconvBlockFn(torch.autograd.Function):
+    """h = GDeconv1DBlock(x): transposed conv, trim, PReLU or Tanh."""
+
+    @staticmethod
+    def forward(ctx, blk, x, *params):
+        x = x.contiguous()
+        src = Src(x)
+        act = ACT_TANH if blk.is_tanh else ACT_NONE
+        a = ops.deconv1d_fwd(src, blk.deconv.weight, blk.deconv.bias, blk.stride, act,
+                             pack=blk._pack)
+        h = a if blk.is_tanh else ops.affine_prelu(a, slope=blk.act.weight)
+        ctx.blk = blk
+        ctx.x_needs = x.requires_grad
+        ctx.state = (src, a)
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        blk = ctx.blk
+        src, a = ctx.state
+        K, S = blk.kwidth, blk.stride
+        w = blk.deconv.weight
+        dh = dh.contiguous()
+        if blk.is_tanh:
+            da = ops.tanh_bwd(a, dh, dbias=_gb(blk.deconv.bias))
+        else:
+            da = ops.act_bwd(a, dh, slope=blk.act.weight, dslope=_gb(blk.act.weight),
+                             dbias=_gb(blk.deconv.bias))
+        if w.requires_grad:
+            ops.wgrad(src, Src(da), grad_buf(w), K, S, ops.deconv_pad(K, S), PAD_ZERO)
+        dx = None
+        if ctx.x_needs:
+            _d0, dx = ops.deconv1d_dgrad(da, w, S, 0, pack=blk._pack)
+        ctx.state = None
+        return (None, dx) + (None,) * (len(ctx.needs_input_grad) - 2)
+
+
+# =====================================================================================
+# losses
+# =====================================================================================
+class MSEConstFn(torch.autograd.Function):
+    """mean((x - c)^2) against a constant label (nn.MSELoss on a filled label tensor,
+    train.py:94 + model.py:298,305,316)."""
+
+    @staticmethod
+    def forward(ctx, x, target):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        ctx.target = float(target)
+        return ops.mse_const(x, target)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return ops.mse_const_bwd(x, ctx.target, gout=g.contiguous()), None
+
+
+class L1MeanFn(torch.autograd.Function):
+    """F.l1_loss(x, y) (model.py:79,318)."""
+
+    @staticmethod
+    def forward(ctx, x, y):
+        x, y = x.contiguous(), y.contiguous()
+        ctx.save_for_backward(x, y)
+        return ops.l1_mean(x, y)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y = ctx.saved_tensors
+        gx = gy = None
+        if ctx.needs_input_grad[0]:
+            gx = ops.l1_bwd(x, y, gout=g.contiguous())
+        if ctx.needs_input_grad[1]:
+            gy = ops.l1_bwd(y, x, gout=g.contiguous())
+        return gx, gy

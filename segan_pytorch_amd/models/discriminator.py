@@ -1,0 +1,113 @@
+"""SEGAN discriminator on the HIP path.
+
+API mirror of ``Discriminator`` (segan/models/discriminator.py:65-194): same
+constructor signature, sub-module names (``enc_blocks.N.{conv,norm,act}``,
+``fc.{0..4}``) and ``forward(x) -> (logit, int_act)`` contract, including the
+per-layer random phase shift drawn from python's ``random`` in the reference's order
+(``randint`` then ``random`` per layer, discriminator.py:159-172) so a seeded run
+takes the same shifts.
+"""
+import random
+
+import torch
+import torch.nn as nn
+
+from .. import functional as Fn
+from .. import ops
+from .core import Model
+from .modules import GConv1DBlock
+
+
+class _LazyIntAct(dict):
+    """int_act of the reference holds every layer's activation; they are only
+    materialised (one affine+PReLU kernel each) when somebody actually reads them."""
+
+    def __init__(self, disc, logit):
+        super().__init__()
+        self._cs, self._xfs = disc._last_fwd
+        self._slopes = [blk.act.weight.detach() for blk in disc.enc_blocks]
+        dict.__setitem__(self, 'logit', logit)
+        self._pending = set('h_{}'.format(i) for i in range(len(self._cs)))
+
+    def __missing__(self, key):
+        if key in self._pending:
+            i = int(key.split('_')[1])
+            with torch.no_grad():
+                v = ops.affine_prelu(self._cs[i], self._xfs[i][0], self._xfs[i][1], self._slopes[i])
+            dict.__setitem__(self, key, v)
+            self._pending.discard(key)
+            return v
+        raise KeyError(key)
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in self._pending
+
+    def keys(self):
+        return ['h_{}'.format(i) for i in range(len(self._cs))] + ['logit']
+
+
+class Discriminator(Model):
+
+    def __init__(self, ninputs, fmaps, kwidth, poolings, pool_type='none', pool_slen=None,
+                 norm_type='bnorm', bias=True, phase_shift=None, sinc_conv=False):
+        super().__init__(name='Discriminator')
+        self.phase_shift = phase_shift
+        if phase_shift is not None:
+            assert isinstance(phase_shift, int), type(phase_shift)
+            assert phase_shift > 1, phase_shift
+        if pool_slen is None:
+            raise ValueError('Please specify D network pool seq len (pool_slen) in the end of '
+                             'the conv stack: [inp_len // (total_pooling_factor)]')
+        if sinc_conv:
+            raise NotImplementedError('sinc_conv is not implemented in segan_pytorch_amd (and is '
+                                      'broken in the reference: discriminator.py:90-95)')
+        if norm_type not in ('bnorm', None):
+            raise NotImplementedError("Discriminator norm_type {!r} is not implemented yet "
+                                      "(only 'bnorm' and None)".format(norm_type))
+        ninp = ninputs
+        self.enc_blocks = nn.ModuleList()
+        for fmap, pool in zip(fmaps, poolings):
+            self.enc_blocks.append(GConv1DBlock(ninp, fmap, kwidth, stride=pool, bias=bias,
+                                                norm_type=norm_type))
+            ninp = fmap
+        self.pool_type = pool_type
+        if pool_type == 'none':
+            pool_slen *= fmaps[-1]
+            self.fc = nn.Sequential(nn.Linear(pool_slen, 256), nn.PReLU(256),
+                                    nn.Linear(256, 128), nn.PReLU(128), nn.Linear(128, 1))
+        else:
+            raise NotImplementedError("Discriminator pool_type {!r} is not implemented (only "
+                                      "'none', the SEGAN+/WSEGAN setting)".format(pool_type))
+        self._total_pool = 1
+        for p in poolings:
+            self._total_pool *= p
+
+    def _fn_params(self):
+        return [p for p in nn.Module.parameters(self)]
+
+    def draw_rolls(self):
+        """One signed circular shift per layer, consuming python's `random` exactly as
+        discriminator.py:159-163 does (roll > 0: shift right)."""
+        rolls = []
+        for _ in self.enc_blocks:
+            if self.phase_shift is None:
+                rolls.append(0)
+                continue
+            shift = random.randint(1, self.phase_shift)
+            right = random.random() > 0.5
+            rolls.append(shift if right else -shift)
+        return rolls
+
+    def forward(self, x):
+        if x.dim() != 3 or x.shape[1] != self.enc_blocks[0].conv.in_channels:
+            raise ValueError('Discriminator expects [B, {}, L], got {}'.format(
+                self.enc_blocks[0].conv.in_channels, tuple(x.shape)))
+        L = x.shape[2]
+        if L % self._total_pool != 0 or \
+                (L // self._total_pool) * self.enc_blocks[-1].conv.out_channels != \
+                self.fc[0].in_features:
+            raise ValueError('input length {} does not match the dense head ({} features after '
+                             'pooling by {})'.format(L, self.fc[0].in_features, self._total_pool))
+        rolls = self.draw_rolls()
+        y = Fn.DiscriminatorFn.apply(self, rolls, x, *self._fn_params())
+        return y, _LazyIntAct(self, y)

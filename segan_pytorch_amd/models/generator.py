@@ -1,0 +1,163 @@
+"""SEGAN generator on the HIP path.
+
+API mirror of ``GSkip`` (segan/models/generator.py:18-78) and ``Generator``
+(generator.py:80-230): same constructor signature and defaults, same attribute and
+sub-module names (``enc_blocks``, ``dec_blocks``, ``alpha_<i>``, ``skips``, ``z``,
+``no_z``, ``z_dim``, ``dec_poolings``) and therefore the same ``state_dict`` keys, same
+``forward(x, z=None, ret_hid=False)`` contract.  The forward is ONE autograd node
+(``functional.GeneratorFn``) that chains the HIP kernels.
+"""
+import torch
+import torch.nn as nn
+
+from .. import functional as Fn
+from .core import Model
+from .modules import GConv1DBlock, GDeconv1DBlock
+
+
+class GSkip(nn.Module):
+    """Learnable per-channel skip scale (generator.py:18-78).  Parameter container:
+    the multiply and the concat happen inside the consuming deconv kernel."""
+
+    def __init__(self, skip_type, size, skip_init, skip_dropout=0, merge_mode='sum',
+                 kwidth=11, bias=True):
+        super().__init__()
+        self.merge_mode = merge_mode
+        if skip_type in ('alpha', 'constant'):
+            if skip_init == 'zero':
+                alpha_ = torch.zeros(size)
+            elif skip_init == 'randn':
+                alpha_ = torch.randn(size)
+            elif skip_init == 'one':
+                alpha_ = torch.ones(size)
+            else:
+                raise TypeError('Unrecognized alpha init scheme: ', skip_init)
+            self.skip_k = nn.Parameter(alpha_.view(1, -1, 1))
+            if skip_type == 'constant':
+                self.skip_k.requires_grad = False
+        elif skip_type == 'conv':
+            raise NotImplementedError("skip_type='conv' (generator.py:42-49) is not implemented "
+                                      "in segan_pytorch_amd")
+        else:
+            raise TypeError('Unrecognized GSkip scheme: ', skip_type)
+        self.skip_type = skip_type
+        if skip_dropout > 0:
+            raise NotImplementedError('skip_dropout > 0 is not implemented in segan_pytorch_amd')
+        if merge_mode not in ('sum', 'concat'):
+            raise TypeError('Unrecognized skip merge mode: ', merge_mode)
+        if merge_mode == 'sum':
+            raise NotImplementedError(
+                "skip_merge='sum' is not implemented yet in segan_pytorch_amd; SEGAN+/WSEGAN "
+                "train with --skip_merge concat (train.py:184)")
+
+    def __repr__(self):
+        if self.skip_type == 'alpha':
+            return self._get_name() + '(Alpha(1))'
+        elif self.skip_type == 'constant':
+            return self._get_name() + '(Constant(1))'
+        return super().__repr__()
+
+    def forward(self, hj, hi):
+        raise RuntimeError('GSkip is applied inside the fused decoder kernels; call the '
+                           'Generator instead')
+
+
+class Generator(Model):
+
+    def __init__(self, ninputs, fmaps, kwidth, poolings, dec_fmaps=None, dec_kwidth=None,
+                 dec_poolings=None, z_dim=None, no_z=False, skip=True, bias=False,
+                 skip_init='one', skip_dropout=0, skip_type='alpha', norm_type=None,
+                 skip_merge='sum', skip_kwidth=11, name='Generator'):
+        super().__init__(name=name)
+        self.skip = skip
+        self.bias = bias
+        self.no_z = no_z
+        self.z_dim = z_dim
+        self.enc_blocks = nn.ModuleList()
+        assert isinstance(fmaps, list), type(fmaps)
+        assert isinstance(poolings, list), type(poolings)
+        if isinstance(kwidth, int):
+            kwidth = [kwidth] * len(fmaps)
+        assert isinstance(kwidth, list), type(kwidth)
+        if norm_type is not None:
+            raise NotImplementedError('Generator norm layers are not implemented (the reference '
+                                      'training never enables them: model.py:82-96)')
+        skips = {}
+        ninp = ninputs
+        for pi, (fmap, pool, kw) in enumerate(zip(fmaps, poolings, kwidth), start=1):
+            if skip and pi < len(fmaps):
+                # a skip connection for all but the last hidden layer (generator.py:113-123)
+                gskip = GSkip(skip_type, fmap, skip_init, skip_dropout, merge_mode=skip_merge,
+                              kwidth=skip_kwidth, bias=bias)
+                l_i = pi - 1
+                skips[l_i] = {'alpha': gskip}
+                setattr(self, 'alpha_{}'.format(l_i), skips[l_i]['alpha'])
+            self.enc_blocks.append(GConv1DBlock(ninp, fmap, kw, stride=pool, bias=bias,
+                                                norm_type=norm_type))
+            ninp = fmap
+        self.skips = skips
+        if not no_z and z_dim is None:
+            z_dim = fmaps[-1]
+            self.z_dim = z_dim
+        if not no_z:
+            ninp += z_dim
+        if dec_fmaps is None:
+            dec_fmaps = fmaps[::-1][1:] + [1]
+        else:
+            assert isinstance(dec_fmaps, list), type(dec_fmaps)
+        if dec_poolings is None:
+            dec_poolings = poolings[:]
+        else:
+            assert isinstance(dec_poolings, list), type(dec_poolings)
+        self.dec_poolings = dec_poolings
+        if dec_kwidth is None:
+            dec_kwidth = kwidth[:]
+        elif isinstance(dec_kwidth, int):
+            dec_kwidth = [dec_kwidth] * len(dec_fmaps)
+        assert isinstance(dec_kwidth, list), type(dec_kwidth)
+        self.dec_blocks = nn.ModuleList()
+        for pi, (fmap, pool, kw) in enumerate(zip(dec_fmaps, dec_poolings, dec_kwidth), start=1):
+            if skip and pi > 1 and pool > 1 and skip_merge == 'concat':
+                ninp *= 2
+            act = 'Tanh' if pi >= len(dec_fmaps) else None
+            if pool > 1:
+                blk = GDeconv1DBlock(ninp, fmap, kw, stride=pool, norm_type=norm_type, bias=bias,
+                                     act=act)
+            else:
+                raise NotImplementedError('decoder layers with pooling 1 (plain convs, '
+                                          'generator.py:171-176) are not implemented')
+            self.dec_blocks.append(blk)
+            ninp = fmap
+        self._total_pool = 1
+        for p in poolings:
+            self._total_pool *= p
+
+    def _fn_params(self):
+        return [p for p in nn.Module.parameters(self)]
+
+    def forward(self, x, z=None, ret_hid=False):
+        if x.dim() != 3:
+            raise ValueError('Generator expects [B, C, L], got {}'.format(tuple(x.shape)))
+        if x.shape[2] % self._total_pool != 0:
+            raise ValueError('input length {} is not divisible by the total pooling {}'.format(
+                x.shape[2], self._total_pool))
+        if not self.no_z:
+            if z is None:
+                # drawn on the host like the reference (generator.py:197-199)
+                z = torch.randn(x.size(0), self.z_dim, x.shape[2] // self._total_pool)
+                if x.is_cuda:
+                    z = z.to(x.device)
+            if z.dim() != x.dim():
+                raise ValueError('len(z.size) {} != len(hi.size) {}'.format(z.dim(), x.dim()))
+            if not hasattr(self, 'z'):
+                self.z = z
+        else:
+            z = None
+        out = Fn.GeneratorFn.apply(self, bool(ret_hid), x, z, *self._fn_params())
+        if not ret_hid:
+            return out
+        keys = ['enc_{}'.format(i) for i in range(len(self.enc_blocks))]
+        if not self.no_z:
+            keys.append('enc_zc')
+        keys += ['dec_{}'.format(i) for i in range(len(self.dec_blocks))]
+        return out[0], dict(zip(keys, out[1:]))

@@ -1,0 +1,264 @@
+"""SEGAN / WSEGAN training and inference engines on the HIP path.
+
+Mirror of ``SEGAN`` (segan/models/model.py:71-507): same constructor (an ``opts``
+attribute bag), ``infer_G`` / ``infer_D`` / ``generate`` / ``discriminate`` /
+``build_optimizers`` / ``train`` signatures, same initialisation
+(``weights_init``, model.py:28-43) and the same order of operations inside the GAN
+step (model.py:292-321).  What differs, by design:
+
+* G and D forward/backward run as the HIP autograd nodes of ``functional.py``;
+* the optimizers are the fused flat-arena ones of ``optim.py``;
+* during the generator update the discriminator's parameters are frozen, so the D
+  weight gradients the reference computes and then discards (its next
+  ``Dopt.zero_grad()``) are not computed at all — same results, 1/9 of D's work less;
+* under ``torch.distributed`` (one process per GPU) gradients are averaged with one
+  RCCL all-reduce per network per step (``distributed.py``).
+"""
+import os
+import random
+import timeit
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import distributed as sdist
+from .. import losses
+from .. import optim as soptim
+from ..datasets import de_emphasize
+from .core import Model, Saver
+from .discriminator import Discriminator
+from .generator import Generator
+
+try:  # logging is optional plumbing (not installed in every image)
+    from tensorboardX import SummaryWriter
+except Exception:  # pragma: no cover
+    class SummaryWriter(object):
+        def __init__(self, *a, **k):
+            pass
+
+        def add_scalar(self, *a, **k):
+            pass
+
+        def add_histogram(self, *a, **k):
+            pass
+
+
+def weights_init(m):
+    """model.py:28-43: Conv1d ~ N(0, 0.02) with zero bias; Linear Xavier-uniform;
+    ConvTranspose1d / BatchNorm1d / PReLU keep torch defaults (the class-name test
+    'Conv1d' does not match them)."""
+    classname = m.__class__.__name__
+    if classname.find('Conv1d') != -1:
+        m.weight.data.normal_(0.0, 0.02)
+        if getattr(m, 'bias', None) is not None:
+            m.bias.data.fill_(0)
+    elif classname.find('Linear') != -1:
+        nn.init.xavier_uniform_(m.weight.data)
+
+
+def wsegan_weights_init(m):
+    """model.py:45-60: Xavier-uniform for Conv1d, ConvTranspose1d and Linear."""
+    classname = m.__class__.__name__
+    if classname.find('Conv1d') != -1 or classname.find('ConvTranspose1d') != -1 or \
+            classname.find('Linear') != -1:
+        nn.init.xavier_uniform_(m.weight.data)
+
+
+class _frozen(object):
+    """Context manager: parameters of `module` do not require grad inside."""
+
+    def __init__(self, module):
+        self.params = [p for p in nn.Module.parameters(module) if p.requires_grad]
+
+    def __enter__(self):
+        for p in self.params:
+            p.requires_grad_(False)
+
+    def __exit__(self, *exc):
+        for p in self.params:
+            p.requires_grad_(True)
+
+
+class SEGAN(Model):
+
+    def __init__(self, opts, name='SEGAN', generator=None, discriminator=None):
+        super(SEGAN, self).__init__(name)
+        self.save_path = opts.save_path
+        self.preemph = opts.preemph
+        reg = getattr(opts, 'reg_loss', 'l1_loss')
+        if reg != 'l1_loss':
+            raise NotImplementedError("reg_loss {!r}: only 'l1_loss' is implemented".format(reg))
+        self.reg_loss = losses.l1_loss
+        if generator is None:
+            self.G = Generator(1, opts.genc_fmaps, opts.gkwidth, opts.genc_poolings,
+                               opts.gdec_fmaps, opts.gdec_kwidth, opts.gdec_poolings,
+                               z_dim=opts.z_dim, no_z=opts.no_z, skip=(not opts.no_skip),
+                               bias=opts.bias, skip_init=opts.skip_init,
+                               skip_type=opts.skip_type, skip_merge=opts.skip_merge,
+                               skip_kwidth=opts.skip_kwidth)
+        else:
+            self.G = generator
+        self.G.apply(self._init_fn())
+        if discriminator is None:
+            dkwidth = opts.gkwidth if opts.dkwidth is None else opts.dkwidth
+            self.D = Discriminator(2, opts.denc_fmaps, dkwidth, poolings=opts.denc_poolings,
+                                   pool_type=opts.dpool_type, pool_slen=opts.dpool_slen,
+                                   norm_type=opts.dnorm_type, phase_shift=opts.phase_shift,
+                                   sinc_conv=opts.sinc_conv)
+        else:
+            self.D = discriminator
+        self.D.apply(self._init_fn())
+
+    def _init_fn(self):
+        return weights_init
+
+    # ---- inference --------------------------------------------------------------------
+    def generate(self, inwav, z=None, device='cpu'):
+        """Chunked enhancement of a whole utterance (model.py:116-157)."""
+        self.G.eval()
+        N = 16384
+        c_res = None
+        g_c = None
+        T = inwav.shape[2]
+        with torch.no_grad():
+            for beg_i in range(0, T, N):
+                length = min(N, T - beg_i)
+                pad = N - length
+                x = torch.zeros(1, 1, N, device=device, dtype=torch.float32)
+                x[0, 0, :length] = torch.as_tensor(inwav[0, 0, beg_i:beg_i + length]).to(device)
+                canvas_w, hall = self.infer_G(x, z=z, ret_hid=True)
+                nums = [int(k.split('_')[1]) for k in hall.keys() if 'enc' in k and 'zc' not in k]
+                g_c = hall['enc_{}'.format(max(nums))]
+                if z is None and hasattr(self.G, 'z'):
+                    z = self.G.z            # z of the first chunk is re-used (model.py:144-146)
+                if pad > 0:
+                    canvas_w = canvas_w[0, 0, :-pad]
+                canvas_w = canvas_w.data.cpu().numpy().squeeze()
+                c_res = canvas_w if c_res is None else np.concatenate((c_res, canvas_w))
+        c_res = de_emphasize(c_res, self.preemph)
+        return c_res, g_c
+
+    def discriminate(self, cwav, nwav):
+        self.D.eval()
+        d_veredict, _ = self.D(torch.cat((cwav, nwav), dim=1))
+        return d_veredict
+
+    def infer_G(self, nwav, cwav=None, z=None, ret_hid=False):
+        return self.G(nwav, z=z, ret_hid=ret_hid)
+
+    def infer_D(self, x_, ref):
+        return self.D(torch.cat((x_, ref), dim=1))
+
+    # ---- training ---------------------------------------------------------------------
+    def build_optimizers(self, opts):
+        if opts.opt == 'rmsprop':
+            Gopt = soptim.RMSprop(self.G.parameters(), lr=opts.g_lr)
+            Dopt = soptim.RMSprop(self.D.parameters(), lr=opts.d_lr)
+        elif opts.opt == 'adam':
+            Gopt = soptim.Adam(self.G.parameters(), lr=opts.g_lr, betas=(0, 0.9))
+            Dopt = soptim.Adam(self.D.parameters(), lr=opts.d_lr, betas=(0, 0.9))
+        else:
+            raise ValueError('Unrecognized optimizer {}'.format(opts.opt))
+        return Gopt, Dopt
+
+    def gan_step(self, clean, noisy, Gopt, Dopt, criterion, l1_weight, z=None):
+        """One LSGAN step, model.py:292-321 (from ``Dopt.zero_grad()`` to
+        ``Gopt.step()``).  clean / noisy: [B, 1, T] on the device.  Returns the four
+        losses as 0-dim device tensors (no host sync)."""
+        # (1) D real update
+        Dopt.zero_grad()
+        Genh = self.infer_G(noisy, clean, z=z)
+        d_real, _ = self.infer_D(clean, noisy)
+        d_real_loss = criterion(d_real.view(-1), 1.0)
+        d_real_loss.backward()
+        # (2) D fake update
+        d_fake, _ = self.infer_D(Genh.detach(), noisy)
+        d_fake_loss = criterion(d_fake.view(-1), 0.0)
+        d_fake_loss.backward()
+        sdist.allreduce_grads(Dopt)
+        Dopt.step()
+        # (3) G update through the (updated) D
+        Gopt.zero_grad()
+        with _frozen(self.D):
+            d_fake_, _ = self.infer_D(Genh, noisy)
+            g_adv_loss = criterion(d_fake_.view(-1), 1.0)
+            g_l1_loss = l1_weight * self.reg_loss(Genh, clean)
+            g_loss = g_adv_loss + g_l1_loss
+            g_loss.backward()
+        sdist.allreduce_grads(Gopt)
+        Gopt.step()
+        return d_real_loss, d_fake_loss, g_adv_loss, g_l1_loss
+
+    def train(self, opts, dloader, criterion, l1_init, l1_dec_step, l1_dec_epoch, log_freq,
+              va_dloader=None, device='cpu'):
+        """Train the SEGAN (model.py:230-437)."""
+        if va_dloader is not None:
+            raise NotImplementedError('validation with CompositeEval (PESQ binary, model.py:'
+                                      '440-507) is outside the accelerated path')
+        if criterion is None or isinstance(criterion, nn.MSELoss):
+            criterion = losses.MSELoss()
+        self.writer = SummaryWriter(os.path.join(self.save_path, 'train'))
+        Gopt, Dopt = self.build_optimizers(opts)
+        self.G.optim = Gopt
+        self.D.optim = Dopt
+        sdist.broadcast_params(self.G)
+        sdist.broadcast_params(self.D)
+        is_main = sdist.rank() == 0
+        eoe_g_saver = Saver(self.G, opts.save_path, max_ckpts=3, optimizer=self.G.optim,
+                            prefix='EOE_G-')
+        eoe_d_saver = Saver(self.D, opts.save_path, max_ckpts=3, optimizer=self.D.optim,
+                            prefix='EOE_D-')
+        l1_weight = l1_init
+        iteration = 1
+        timings = []
+        for epoch in range(1, opts.epoch + 1):
+            beg_t = timeit.default_timer()
+            self.G.train()
+            self.D.train()
+            for bidx, batch in enumerate(dloader, start=1):
+                if epoch >= l1_dec_epoch and l1_weight > 0:
+                    l1_weight = max(0, l1_weight - l1_dec_step)
+                if len(batch) != 4:
+                    raise ValueError('Returned {} elements per sample?'.format(len(batch)))
+                uttname, clean, noisy, slice_idx = batch
+                clean = clean.unsqueeze(1).to(device)
+                noisy = noisy.unsqueeze(1).to(device)
+                d_real_loss, d_fake_loss, g_adv_loss, g_l1_loss = self.gan_step(
+                    clean, noisy, Gopt, Dopt, criterion, l1_weight)
+                end_t = timeit.default_timer()
+                timings.append(end_t - beg_t)
+                beg_t = timeit.default_timer()
+                if is_main and (bidx % log_freq == 0 or bidx >= len(dloader)):
+                    vals = [v.cpu().item() for v in
+                            (d_real_loss, d_fake_loss, g_adv_loss, g_l1_loss)]
+                    print('(Iter {}) Batch {}/{} (Epoch {}) d_real:{:.4f}, d_fake:{:.4f}, '
+                          'g_adv:{:.4f}, g_l1:{:.4f} l1_w: {:.2f}, btime: {:.4f} s, '
+                          'mbtime: {:.4f} s'.format(iteration, bidx, len(dloader), epoch,
+                                                    vals[0], vals[1], vals[2], vals[3],
+                                                    l1_weight, timings[-1], np.mean(timings)))
+                    for k, v in zip(('D_real', 'D_fake', 'G_adv', 'G_l1'), vals):
+                        self.writer.add_scalar(k, v, iteration)
+                iteration += 1
+            if is_main:
+                self.G.save(self.save_path, iteration, saver=eoe_g_saver)
+                self.D.save(self.save_path, iteration, saver=eoe_d_saver)
+
+
+class WSEGAN(SEGAN):
+    """Placeholder for the WSEGAN variant (model.py:509-766)."""
+
+    def __init__(self, opts, name='WSEGAN', generator=None, discriminator=None):
+        self.misalign_pair = opts.misalign_pair
+        self.interf_pair = opts.interf_pair
+        self.pow_weight = opts.pow_weight
+        self.vanilla_gan = opts.vanilla_gan
+        self.n_fft = opts.n_fft
+        super(WSEGAN, self).__init__(opts, name=name, generator=generator,
+                                     discriminator=discriminator)
+
+    def _init_fn(self):
+        return wsegan_weights_init
+
+    def train(self, *args, **kwargs):
+        raise NotImplementedError('WSEGAN.train (model.py:537-753) is not implemented yet')

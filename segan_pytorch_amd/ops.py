@@ -1,0 +1,405 @@
+"""Tensor-level wrappers over the C ABI (one function per entry point).
+
+Every wrapper takes contiguous fp32 CUDA(HIP) tensors, allocates outputs with torch
+(plumbing only: the caching allocator and the current stream), and enqueues the HIP
+kernel on ``torch.cuda.current_stream()``.  There is no CPU or ATen fallback: a CPU
+tensor raises.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from . import layout
+from ._lib import ACT_NONE, ACT_TANH, PAD_REFLECT, PAD_ZERO, SeganSrc, check
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _chk(t, name, ndim=None):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError('{} must be a tensor, got {}'.format(name, type(t)))
+    if not t.is_cuda:
+        raise RuntimeError(
+            '{} is on {}: segan_pytorch_amd runs only on an MI355X (HIP) device; '
+            'there is no CPU path'.format(name, t.device))
+    if t.dtype != torch.float32:
+        raise TypeError('{} must be float32, got {}'.format(name, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError('{} must be contiguous'.format(name))
+    if ndim is not None and t.dim() != ndim:
+        raise ValueError('{} must have {} dims, got {}'.format(name, ndim, tuple(t.shape)))
+    return t
+
+
+class Src(object):
+    """A logical [B, C0+C1, L] activation with an on-load transform (``segan_src``).
+
+    ``t0``/``t1``: the channel segments; ``scale``/``shift``/``slope``: optional
+    per-channel vectors over the concatenated channel axis.
+    """
+
+    def __init__(self, t0, t1=None, scale=None, shift=None, slope=None):
+        _chk(t0, 'src.t0', 3)
+        self.t0, self.t1 = t0, t1
+        self.C0 = t0.shape[1]
+        self.C1 = 0
+        if t1 is not None:
+            _chk(t1, 'src.t1', 3)
+            if t1.shape[0] != t0.shape[0] or t1.shape[2] != t0.shape[2]:
+                raise ValueError('src segments disagree: {} vs {}'.format(
+                    tuple(t0.shape), tuple(t1.shape)))
+            self.C1 = t1.shape[1]
+        self.C = self.C0 + self.C1
+        for name, v in (('scale', scale), ('shift', shift), ('slope', slope)):
+            if v is not None:
+                _chk(v, 'src.' + name)
+                if v.numel() != self.C:
+                    raise ValueError('src.{} has {} entries for {} channels'.format(
+                        name, v.numel(), self.C))
+        self.scale, self.shift, self.slope = scale, shift, slope
+        self.B, self.L = t0.shape[0], t0.shape[2]
+
+    def c_struct(self):
+        s = SeganSrc()
+        s.p0 = self.t0.data_ptr()
+        s.p1 = self.t1.data_ptr() if self.t1 is not None else None
+        s.C0, s.C1 = self.C0, self.C1
+        s.scale = self.scale.data_ptr() if self.scale is not None else None
+        s.shift = self.shift.data_ptr() if self.shift is not None else None
+        s.slope = self.slope.data_ptr() if self.slope is not None else None
+        return s
+
+
+def conv_pad(K, S):
+    return layout.conv_pad(K, S)
+
+
+def deconv_pad(K, S):
+    return layout.deconv_pad(K, S)
+
+
+# ---------------------------------------------------------------------------------
+# weight packing
+# ---------------------------------------------------------------------------------
+_weights_epoch = 0
+
+
+def bump_weights_epoch():
+    """Invalidate every WeightPack: call after weights were modified through raw
+    pointers (the fused optimizers, DP broadcast), which torch's version counter
+    cannot see."""
+    global _weights_epoch
+    _weights_epoch += 1
+
+
+class WeightPack(object):
+    """Polyphase-packed copies of ONE weight tensor [m, n, K] (see layout.py), owned by
+    the module that owns the weight and refreshed when the weight changes."""
+
+    def __init__(self):
+        self._buf = {}
+        self._key = {}
+
+    def _get(self, w, S, pad_t, want):
+        _chk(w, 'weight', 3)
+        key = (w.data_ptr(), w._version, _weights_epoch, tuple(w.shape), S, pad_t)
+        if self._key.get(want) == key:
+            return self._buf[want]
+        lib = _lib.load()
+        M, N, K = w.shape
+        nbytes = (lib.segan_packed_f_bytes if want == 'f' else lib.segan_packed_t_bytes)(M, N, S)
+        if nbytes == 0:
+            raise ValueError('unsupported stride {} (must be 1, 2 or 4)'.format(S))
+        buf = self._buf.get(want)
+        if buf is None or buf.numel() * 4 != nbytes or buf.device != w.device:
+            buf = torch.empty(nbytes // 4, device=w.device, dtype=torch.float32)
+        check(lib.segan_pack_weights(_ptr(w), _ptr(buf) if want == 'f' else None,
+                                     _ptr(buf) if want == 't' else None, M, N, K, S, pad_t,
+                                     _stream()), 'pack_weights')
+        self._buf[want] = buf
+        self._key[want] = key
+        return buf
+
+    def f(self, w, S):
+        return self._get(w, S, 0, 'f')
+
+    def t(self, w, S, pad_t):
+        return self._get(w, S, pad_t, 't')
+
+
+# ---------------------------------------------------------------------------------
+# contractions
+# ---------------------------------------------------------------------------------
+def conv1d_fwd(src, w, bias, S, roll=0, pad_mode=PAD_REFLECT, padL=None, pack=None):
+    """Pre-activation of GConv1DBlock: conv(reflect_pad(roll(src)), w) + bias."""
+    M, N, K = w.shape
+    if src.C != N:
+        raise ValueError('conv1d_fwd: input has {} channels, weight expects {}'.format(src.C, N))
+    B, L = src.B, src.L
+    if L % S != 0:
+        raise ValueError('conv1d_fwd: length {} not divisible by stride {}'.format(L, S))
+    if padL is None:
+        padL = conv_pad(K, S)[0]
+    out = torch.empty((B, M, L // S), device=w.device, dtype=torch.float32)
+    cs = src.c_struct()
+    check(_lib.load().segan_conv1d_fwd(ctypes.byref(cs), _ptr((pack or WeightPack()).f(w, S)),
+                                       _ptr(bias), _ptr(out),
+                                       B, N, M, L, K, S, padL, pad_mode, roll, _stream()),
+          'conv1d_fwd')
+    return out
+
+
+def conv1d_dgrad(da, w, L, S, roll=0, padL=None, pack=None):
+    """Gradient of conv1d_fwd w.r.t. its (un-rolled, un-padded) input: [B, N, L]."""
+    _chk(da, 'da', 3)
+    M, N, K = w.shape
+    B = da.shape[0]
+    if da.shape[1] != M or da.shape[2] * S != L:
+        raise ValueError('conv1d_dgrad: da {} inconsistent with weight {} / L {}'.format(
+            tuple(da.shape), tuple(w.shape), L))
+    if padL is None:
+        padL = conv_pad(K, S)[0]
+    dx = torch.empty((B, N, L), device=da.device, dtype=torch.float32)
+    halo = torch.empty((B * N * max(K - 1, 1),), device=da.device, dtype=torch.float32)
+    check(_lib.load().segan_conv1d_dgrad(_ptr(da), _ptr((pack or WeightPack()).t(w, S, 0)),
+                                         _ptr(dx), _ptr(halo), B,
+                                         N, M, L, K, S, padL, roll, _stream()), 'conv1d_dgrad')
+    return dx
+
+
+def wgrad(lo, hi, dw, K, S, padL, pad_mode, roll=0):
+    """dw[m,n,k] += sum lo[b,m,t] * pad(roll(hi))[b,n,S*t+k]  (accumulates into dw)."""
+    _chk(dw, 'dw', 3)
+    M, N = lo.C, hi.C
+    if tuple(dw.shape) != (M, N, K):
+        raise ValueError('wgrad: dw {} != ({}, {}, {})'.format(tuple(dw.shape), M, N, K))
+    if lo.B != hi.B or lo.L * S != hi.L:
+        raise ValueError('wgrad: lo [{}x{}] / hi [{}x{}] inconsistent for stride {}'.format(
+            lo.B, lo.L, hi.B, hi.L, S))
+    cl, ch = lo.c_struct(), hi.c_struct()
+    check(_lib.load().segan_wgrad(ctypes.byref(cl), ctypes.byref(ch), _ptr(dw), lo.B, M, N, lo.L,
+                                  K, S, padL, pad_mode, roll, _stream()), 'wgrad')
+
+
+def deconv1d_fwd(src, w, bias, S, act=ACT_NONE, pack=None):
+    """GDeconv1DBlock pre-activation (or tanh output): [B, N, S*Ls]."""
+    M, N, K = w.shape
+    if src.C != M:
+        raise ValueError('deconv1d_fwd: input has {} channels, weight expects {}'.format(src.C, M))
+    pad = deconv_pad(K, S)
+    B, Ls = src.B, src.L
+    y = torch.empty((B, N, S * Ls), device=w.device, dtype=torch.float32)
+    cs = src.c_struct()
+    check(_lib.load().segan_deconv1d_fwd(ctypes.byref(cs), _ptr((pack or WeightPack()).t(w, S, pad)),
+                                         _ptr(bias),
+                                         _ptr(y), B, M, N, Ls, K, S, pad, act, _stream()),
+          'deconv1d_fwd')
+    return y
+
+
+def deconv1d_dgrad(dy, w, S, M0=0, need0=True, need1=True, pack=None):
+    """Gradient w.r.t. the deconv input, split at channel M0 into (dx0, dx1)."""
+    _chk(dy, 'dy', 3)
+    M, N, K = w.shape
+    B = dy.shape[0]
+    if dy.shape[1] != N or dy.shape[2] % S != 0:
+        raise ValueError('deconv1d_dgrad: dy {} inconsistent with weight {}'.format(
+            tuple(dy.shape), tuple(w.shape)))
+    Ls = dy.shape[2] // S
+    pad = deconv_pad(K, S)
+    dx0 = dx1 = None
+    if M0 > 0 and need0:
+        dx0 = torch.empty((B, M0, Ls), device=dy.device, dtype=torch.float32)
+    if M - M0 > 0 and need1:
+        dx1 = torch.empty((B, M - M0, Ls), device=dy.device, dtype=torch.float32)
+    if dx0 is None and dx1 is None:
+        return None, None
+    check(_lib.load().segan_deconv1d_dgrad(_ptr(dy), _ptr((pack or WeightPack()).f(w, S)),
+                                           _ptr(dx0), _ptr(dx1), B, M,
+                                           M0, N, Ls, K, S, pad, _stream()), 'deconv1d_dgrad')
+    return dx0, dx1
+
+
+# ---------------------------------------------------------------------------------
+# per-channel kernels
+# ---------------------------------------------------------------------------------
+def _ws(B, C, L, per_split, extra, device):
+    ns = _lib.load().segan_bn_nsplit(B, C, L)
+    return torch.empty((per_split * ns * C + extra * C,), device=device, dtype=torch.float32)
+
+
+def bn_stats(x, gamma, beta, eps, momentum, running_mean, running_var):
+    """Training-mode BatchNorm1d statistics; returns (mean, rstd, scale, shift)."""
+    _chk(x, 'x', 3)
+    B, C, L = x.shape
+    mean = torch.empty(C, device=x.device, dtype=torch.float32)
+    rstd = torch.empty_like(mean)
+    scale = torch.empty_like(mean)
+    shift = torch.empty_like(mean)
+    ws = _ws(B, C, L, 3, 0, x.device)
+    check(_lib.load().segan_bn_stats(_ptr(x), _ptr(gamma), _ptr(beta), eps, momentum,
+                                     _ptr(running_mean), _ptr(running_var), _ptr(mean), _ptr(rstd),
+                                     _ptr(scale), _ptr(shift), _ptr(ws), B, C, L, _stream()),
+          'bn_stats')
+    return mean, rstd, scale, shift
+
+
+def affine_prelu(x, scale=None, shift=None, slope=None):
+    _chk(x, 'x', 3)
+    B, C, L = x.shape
+    y = torch.empty_like(x)
+    check(_lib.load().segan_affine_prelu(_ptr(x), _ptr(scale), _ptr(shift), _ptr(slope), _ptr(y),
+                                         B, C, L, _stream()), 'affine_prelu')
+    return y
+
+
+def act_bwd(a, dh, dskip=None, slope=None, alpha=None, bn=None, dslope=None, dalpha=None,
+            dgamma=None, dbeta=None, dbias=None):
+    """Backward of (BN+)PReLU(+alpha skip) on pre-activation a; returns da.
+
+    bn = (mean, rstd, gamma, beta) or None.  The d* tensors are accumulated into."""
+    _chk(a, 'a', 3)
+    B, C, L = a.shape
+    da = torch.empty_like(a)
+    ws = _ws(B, C, L, 4, 2, a.device)
+    mean = rstd = gamma = beta = None
+    if bn is not None:
+        mean, rstd, gamma, beta = bn
+    check(_lib.load().segan_act_bwd(_ptr(a), _ptr(dh), _ptr(dskip), _ptr(slope), _ptr(alpha),
+                                    _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(da),
+                                    _ptr(dslope), _ptr(dalpha), _ptr(dgamma), _ptr(dbeta),
+                                    _ptr(dbias), _ptr(ws), B, C, L, _stream()), 'act_bwd')
+    return da
+
+
+def tanh_bwd(y, dy, clean=None, l1_scale=0.0, dbias=None):
+    _chk(y, 'y', 3)
+    B, C, L = y.shape
+    da = torch.empty_like(y)
+    ws = _ws(B, C, L, 1, 0, y.device)
+    check(_lib.load().segan_tanh_bwd(_ptr(y), _ptr(dy), _ptr(clean), float(l1_scale), _ptr(da),
+                                     _ptr(dbias), _ptr(ws), B, C, L, _stream()), 'tanh_bwd')
+    return da
+
+
+# ---------------------------------------------------------------------------------
+# dense head
+# ---------------------------------------------------------------------------------
+def gemm(A, sam, sak, Bm, sbk, sbn, C, M, N, K, overwrite):
+    check(_lib.load().segan_gemm(_ptr(A), sam, sak, _ptr(Bm), sbk, sbn, _ptr(C), C.stride(0), M, N,
+                                 K, 1 if overwrite else 0, _stream()), 'gemm')
+
+
+def linear_fwd(x, w):
+    """x [B, I] @ w[O, I]^T -> [B, O] (no bias)."""
+    _chk(x, 'x', 2)
+    _chk(w, 'w', 2)
+    Bn, I = x.shape
+    O = w.shape[0]
+    y = torch.empty((Bn, O), device=x.device, dtype=torch.float32)
+    gemm(x, I, 1, w, 1, I, y, Bn, O, I, True)
+    return y
+
+
+def linear_dgrad(dy, w):
+    """dy [B, O] @ w[O, I] -> [B, I]."""
+    Bn, O = dy.shape
+    I = w.shape[1]
+    dx = torch.empty((Bn, I), device=dy.device, dtype=torch.float32)
+    gemm(dy, O, 1, w, I, 1, dx, Bn, I, O, True)
+    return dx
+
+
+def linear_wgrad(dy, x, dw):
+    """dw[O, I] += dy[B, O]^T @ x[B, I]."""
+    Bn, O = dy.shape
+    I = x.shape[1]
+    gemm(dy, 1, O, x, I, 1, dw, O, I, Bn, False)
+
+
+def bias_prelu_rows(x, bias, slope):
+    _chk(x, 'x', 2)
+    y = torch.empty_like(x)
+    check(_lib.load().segan_bias_prelu_rows(_ptr(x), _ptr(bias), _ptr(slope), _ptr(y), x.shape[0],
+                                            x.shape[1], _stream()), 'bias_prelu_rows')
+    return y
+
+
+def bias_prelu_rows_bwd(x, bias, slope, dy, dslope, dbias):
+    dx = torch.empty_like(x)
+    check(_lib.load().segan_bias_prelu_rows_bwd(_ptr(x), _ptr(bias), _ptr(slope), _ptr(dy),
+                                                _ptr(dx), _ptr(dslope), _ptr(dbias), x.shape[0],
+                                                x.shape[1], _stream()), 'bias_prelu_rows_bwd')
+    return dx
+
+
+# ---------------------------------------------------------------------------------
+# losses / optimizers / utilities
+# ---------------------------------------------------------------------------------
+def mse_const(x, target):
+    """mean((x - target)^2) for a constant target (LSGAN labels, model.py:298,305,316)."""
+    _chk(x, 'x')
+    loss = torch.empty((), device=x.device, dtype=torch.float32)
+    check(_lib.load().segan_mse_const(_ptr(x), float(target), _ptr(loss), None, None, 1.0,
+                                      x.numel(), _stream()), 'mse_const')
+    return loss
+
+
+def mse_const_bwd(x, target, gout=None, gscale=1.0):
+    """Gradient of mse_const times the (device-resident) upstream scalar gout."""
+    _chk(x, 'x')
+    grad = torch.empty_like(x)
+    check(_lib.load().segan_mse_const(_ptr(x), float(target), None, _ptr(grad), _ptr(gout),
+                                      float(gscale), x.numel(), _stream()), 'mse_const_bwd')
+    return grad
+
+
+def l1_bwd(x, y, gout=None, gscale=1.0):
+    _chk(x, 'x')
+    grad = torch.empty_like(x)
+    check(_lib.load().segan_l1_bwd(_ptr(x), _ptr(y), _ptr(gout), float(gscale), _ptr(grad),
+                                   x.numel(), _stream()), 'l1_bwd')
+    return grad
+
+
+def l1_mean(x, y):
+    _chk(x, 'x')
+    _chk(y, 'y')
+    if x.shape != y.shape:
+        raise ValueError('l1_mean: shapes differ {} vs {}'.format(tuple(x.shape), tuple(y.shape)))
+    loss = torch.empty((), device=x.device, dtype=torch.float32)
+    ws = torch.empty(1024, device=x.device, dtype=torch.float32)
+    check(_lib.load().segan_l1_mean(_ptr(x), _ptr(y), _ptr(loss), _ptr(ws), x.numel(), _stream()),
+          'l1_mean')
+    return loss
+
+
+def rmsprop_step(p, g, sq, lr, alpha, eps):
+    check(_lib.load().segan_rmsprop_step(_ptr(p), _ptr(g), _ptr(sq), lr, alpha, eps, p.numel(),
+                                         _stream()), 'rmsprop_step')
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step):
+    check(_lib.load().segan_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), lr, beta1, beta2, eps,
+                                      step, p.numel(), _stream()), 'adam_step')
+
+
+def fill_(t, value):
+    _chk(t, 't')
+    check(_lib.load().segan_fill(_ptr(t), float(value), t.numel(), _stream()), 'fill')
+    return t
+
+
+def scale_(t, s):
+    _chk(t, 't')
+    check(_lib.load().segan_scale(_ptr(t), float(s), t.numel(), _stream()), 'scale')
+    return t
