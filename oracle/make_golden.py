@@ -1,0 +1,210 @@
+"""Generate tests/golden/*.pt by running the REAL reference on CPU (build container only).
+
+    python oracle/make_golden.py
+
+Fixtures (all fp32, oneDNN disabled, deterministic seeds):
+
+tiny_step.pt     a 3-layer SEGAN (fmaps 8/16/32, k31, s4, L=1024, B=3): full weights,
+                 inputs, z, rolls, every output / loss / gradient of one GAN step made
+                 with the reference's own modules + torch.optim.RMSprop in the order of
+                 model.py:292-321, and the weights after it.
+tiny_train2.pt   the same net driven through the reference's literal ``SEGAN.train``
+                 for two batches (its own z draws and phase-shift draws, replayable
+                 from the recorded seeds): final weights.
+tiny_s2.pt       a stride-2 variant (vanilla-SEGAN style, fmaps 4/8/8/16, L=256) forward
+                 and gradients.
+segan_plus_b2.pt the default SEGAN+ net (ckpt_segan+/train.opts, seed 111) at B=2:
+                 per-tensor init checksums, G output, D logits, losses, and
+                 checksums/samples of every gradient.
+"""
+import json
+import os
+import random
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_harness  # noqa: E402
+
+OUT = os.path.join(HERE, '..', 'tests', 'golden')
+
+
+def base_opts():
+    with open(os.path.join(ref_harness.REF_ROOT, 'ckpt_segan+', 'train.opts')) as f:
+        o = json.load(f)
+    o['reg_loss'] = 'l1_loss'       # the shipped file predates model.py:79
+    return o
+
+
+def tiny_opts(save_path='/tmp/segan_golden_ckpt'):
+    o = base_opts()
+    o.update(dict(genc_fmaps=[8, 16, 32], denc_fmaps=[8, 16, 32], genc_poolings=[4, 4, 4],
+                  denc_poolings=[4, 4, 4], z_dim=32, dpool_slen=16, batch_size=3, epoch=1,
+                  save_path=save_path, slice_size=1024, save_freq=1000, no_train_gen=True))
+    return o
+
+
+def seed_all(s):
+    random.seed(s)
+    np.random.seed(s)
+    torch.manual_seed(s)
+
+
+def synth(B, T, seed):
+    g = torch.Generator().manual_seed(seed)
+    clean = torch.rand(B, T, generator=g) * 2 - 1
+    noisy = (clean + 0.1 * torch.randn(B, T, generator=g)).clamp(-1, 1)
+    return clean, noisy
+
+
+def clone_sd(m):
+    return {k: v.detach().clone() for k, v in m.state_dict().items()}
+
+
+def grads_of(m):
+    return {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+
+
+def manual_step(ref, segan, clean, noisy, z, roll_seed, l1_weight=100.0, lr=5e-5):
+    """model.py:292-321 with the reference's modules, explicit z, seeded shifts."""
+    Gopt = torch.optim.RMSprop(segan.G.parameters(), lr=lr)
+    Dopt = torch.optim.RMSprop(segan.D.parameters(), lr=lr)
+    criterion = nn.MSELoss()
+    segan.G.train()
+    segan.D.train()
+    B = clean.size(0)
+    label = torch.ones(B)
+    out = {}
+    random.seed(roll_seed)
+    Dopt.zero_grad()
+    Genh = segan.infer_G(noisy, clean, z=z)
+    d_real, _ = segan.infer_D(clean, noisy)
+    d_real_loss = criterion(d_real.view(-1), label)
+    d_real_loss.backward()
+    d_fake, _ = segan.infer_D(Genh.detach(), noisy)
+    d_fake_loss = criterion(d_fake.view(-1), label.clone().fill_(0))
+    d_fake_loss.backward()
+    out['d_grads'] = grads_of(segan.D)
+    Dopt.step()
+    Gopt.zero_grad()
+    d_fake_, _ = segan.infer_D(Genh, noisy)
+    g_adv = criterion(d_fake_.view(-1), label.clone().fill_(1))
+    g_l1 = l1_weight * F.l1_loss(Genh, clean)
+    (g_adv + g_l1).backward()
+    out['g_grads'] = grads_of(segan.G)
+    Gopt.step()
+    out['G_after'] = clone_sd(segan.G)
+    out['D_after'] = clone_sd(segan.D)     # incl. BN buffers after all three D forwards
+    out.update(Genh=Genh.detach().clone(), d_real=d_real.detach().clone(),
+               d_fake=d_fake.detach().clone(), d_fake_=d_fake_.detach().clone(),
+               d_real_loss=d_real_loss.detach().clone(), d_fake_loss=d_fake_loss.detach().clone(),
+               g_adv_loss=g_adv.detach().clone(), g_l1_loss=g_l1.detach().clone())
+    return out
+
+
+def checksum(t):
+    t = t.detach().double().reshape(-1)
+    idx = torch.arange(0, t.numel(), max(1, t.numel() // 257))[:257]
+    return {'sum': t.sum().item(), 'abs': t.abs().sum().item(), 'sq': (t * t).sum().item(),
+            'n': t.numel(), 'sample_idx': idx, 'sample': t[idx].float().clone()}
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    ref = ref_harness.import_reference()
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+
+    # ---------------- tiny_step ----------------
+    o = tiny_opts()
+    seed_all(111)
+    segan = ref.SEGAN(SimpleNamespace(**o))
+    clean, noisy = synth(3, 1024, 0)
+    clean, noisy = clean.unsqueeze(1), noisy.unsqueeze(1)
+    z = torch.randn(3, 32, 16, generator=torch.Generator().manual_seed(5))
+    fx = {'opts': o, 'G0': clone_sd(segan.G), 'D0': clone_sd(segan.D), 'clean': clean,
+          'noisy': noisy, 'z': z, 'roll_seed': 7,
+          'rolls': ref_harness.ReplayRandom(7).rolls(3, o['phase_shift'], 3)}
+    # forward-only extras: hidden activations of G and D in train mode (before the step)
+    with torch.no_grad():
+        y, hall = segan.G(noisy, z=z, ret_hid=True)
+        fx['G_hall'] = {k: v.clone() for k, v in hall.items()}
+    d_tmp = ref.Discriminator(2, o['denc_fmaps'], o['gkwidth'], o['denc_poolings'],
+                              pool_type='none', pool_slen=16, norm_type='bnorm', phase_shift=5)
+    d_tmp.load_state_dict(segan.D.state_dict())
+    d_tmp.train()
+    random.seed(7)
+    with torch.no_grad():
+        yd, acts = d_tmp(torch.cat((clean, noisy), 1))
+    fx['D_acts'] = {k: v.clone() for k, v in acts.items()}
+    fx.update(manual_step(ref, segan, clean, noisy, z, 7))
+    torch.save(fx, os.path.join(OUT, 'tiny_step.pt'))
+    print('tiny_step.pt', {k: (tuple(v.shape) if torch.is_tensor(v) else type(v).__name__)
+                           for k, v in fx.items() if k in ('Genh', 'd_real', 'g_l1_loss')})
+
+    # ---------------- tiny_train2: the literal SEGAN.train ----------------
+    seed_all(111)
+    segan = ref.SEGAN(SimpleNamespace(**o))
+    c1, n1 = synth(3, 1024, 1)
+    c2, n2 = synth(3, 1024, 2)
+    loader = [[['u'] * 3, c1, n1, torch.zeros(3)], [['u'] * 3, c2, n2, torch.zeros(3)]]
+    fx2 = {'opts': o, 'G0': clone_sd(segan.G), 'D0': clone_sd(segan.D),
+           'batches': [(c1, n1), (c2, n2)], 'seed': 23}
+    seed_all(23)
+    opts_ns = SimpleNamespace(**o)
+    segan.train(opts_ns, loader, nn.MSELoss(), o['l1_weight'], o['l1_dec_step'],
+                o['l1_dec_epoch'], 1000, va_dloader=None, device='cpu')
+    fx2['G_final'] = clone_sd(segan.G)
+    fx2['D_final'] = clone_sd(segan.D)
+    torch.save(fx2, os.path.join(OUT, 'tiny_train2.pt'))
+    print('tiny_train2.pt done')
+
+    # ---------------- tiny_s2: stride-2 (vanilla SEGAN style) ----------------
+    o2 = tiny_opts()
+    o2.update(dict(genc_fmaps=[4, 8, 8, 16], denc_fmaps=[4, 8, 8, 16], genc_poolings=[2] * 4,
+                   denc_poolings=[2] * 4, z_dim=16, dpool_slen=16, slice_size=256))
+    seed_all(111)
+    segan = ref.SEGAN(SimpleNamespace(**o2))
+    clean, noisy = synth(2, 256, 3)
+    clean, noisy = clean.unsqueeze(1), noisy.unsqueeze(1)
+    z = torch.randn(2, 16, 16, generator=torch.Generator().manual_seed(6))
+    fx3 = {'opts': o2, 'G0': clone_sd(segan.G), 'D0': clone_sd(segan.D), 'clean': clean,
+           'noisy': noisy, 'z': z, 'roll_seed': 9,
+           'rolls': ref_harness.ReplayRandom(9).rolls(4, o2['phase_shift'], 3)}
+    fx3.update(manual_step(ref, segan, clean, noisy, z, 9))
+    torch.save(fx3, os.path.join(OUT, 'tiny_s2.pt'))
+    print('tiny_s2.pt done')
+
+    # ---------------- segan_plus_b2: the default net ----------------
+    ob = base_opts()
+    ob['save_path'] = '/tmp/segan_golden_ckpt'
+    seed_all(111)
+    segan = ref.SEGAN(SimpleNamespace(**ob))
+    clean, noisy = synth(2, 16384, 0)
+    clean, noisy = clean.unsqueeze(1), noisy.unsqueeze(1)
+    z = torch.randn(2, 1024, 16, generator=torch.Generator().manual_seed(0))
+    fx4 = {'opts': ob, 'seed': 111, 'roll_seed': 3, 'z_seed': 0, 'data_seed': 0,
+           'rolls': ref_harness.ReplayRandom(3).rolls(5, ob['phase_shift'], 3),
+           'init_G': {k: checksum(v) for k, v in segan.G.state_dict().items()},
+           'init_D': {k: checksum(v) for k, v in segan.D.state_dict().items()}}
+    res = manual_step(ref, segan, clean, noisy, z, 3)
+    for k in ('Genh', 'd_real', 'd_fake', 'd_fake_', 'd_real_loss', 'd_fake_loss', 'g_adv_loss',
+              'g_l1_loss'):
+        fx4[k] = res[k]
+    fx4['d_grads'] = {k: checksum(v) for k, v in res['d_grads'].items()}
+    fx4['g_grads'] = {k: checksum(v) for k, v in res['g_grads'].items()}
+    fx4['small_d_grads'] = {k: v for k, v in res['d_grads'].items() if v.numel() <= 4096}
+    fx4['small_g_grads'] = {k: v for k, v in res['g_grads'].items() if v.numel() <= 4096}
+    fx4['G_after'] = {k: checksum(v) for k, v in res['G_after'].items()}
+    fx4['D_after'] = {k: checksum(v) for k, v in res['D_after'].items()}
+    torch.save(fx4, os.path.join(OUT, 'segan_plus_b2.pt'))
+    print('segan_plus_b2.pt done', res['Genh'].shape, res['g_l1_loss'])
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,201 @@
+"""CPU ORACLE for the SEGAN+ GAN training step — TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg
+may import this file; the product (``segan_pytorch_amd``) never does.
+
+It is a line-by-line functional restatement of the reference's hot path
+(santi-pdp/segan_pytorch @ /root/reference), written against plain state_dicts so that
+it can be fed the weights of the reference modules or of the HIP modules alike:
+
+* ``gconv_block``        segan/models/modules.py:91-105   (reflect pad, Conv1d, norm, PReLU)
+* ``gdeconv_block``      segan/models/modules.py:135-141  (ConvTranspose1d, trim, PReLU/Tanh)
+* ``generator_forward``  segan/models/generator.py:180-230 (+ GSkip.forward 64-78)
+* ``roll``               segan/models/discriminator.py:160-172 (phase shift)
+* ``discriminator_forward`` segan/models/discriminator.py:150-194
+* ``gan_step``           segan/models/model.py:292-321 with nn.MSELoss (train.py:94),
+                         F.l1_loss (model.py:79) and optim.RMSprop (model.py:221-222)
+
+The arithmetic itself lives in PyTorch (third-party; the reference pins torch==0.4.1 in
+requirements.txt:6, this image has 2.10): the restatement calls the same
+``torch.nn.functional`` ops the reference's nn modules dispatch to, on CPU, with oneDNN
+disabled (this build's multi-threaded oneDNN ConvTranspose1d is
+numerically wrong).
+
+PINNING: ``tests/golden/*.pt`` hold outputs of the REAL reference run in the build
+container (``oracle/make_golden.py`` imports it from /root/reference);
+``tests/test_oracle.py`` checks this restatement against them.
+"""
+import torch
+import torch.nn.functional as F
+
+torch.backends.mkldnn.enabled = False
+
+
+def roll(h, r):
+    """Circular phase shift, discriminator.py:160-172.  r > 0: 'right'
+    (cat(h[-r:], h[:-r])), r < 0: 'left' (cat(h[s:], h[:s]) with s = -r)."""
+    if r == 0:
+        return h
+    if r > 0:
+        return torch.cat((h[:, :, -r:], h[:, :, :-r]), dim=2)
+    s = -r
+    return torch.cat((h[:, :, s:], h[:, :, :s]), dim=2)
+
+
+def gconv_block(x, w, b, slope, stride, bn=None, training=True):
+    """modules.py:91-105.  Returns (h, a, bn_batch_stats)."""
+    K = w.shape[2]
+    P = (K // 2 - 1, K // 2) if stride > 1 else (K // 2, K // 2)
+    a = F.conv1d(F.pad(x, P, mode='reflect'), w, b, stride=stride)
+    if bn is not None:
+        a = F.batch_norm(a, bn['running_mean'], bn['running_var'], bn['weight'], bn['bias'],
+                         training, 0.1, 1e-5)
+    h = F.prelu(a, slope)
+    return h, a
+
+
+def gdeconv_block(x, w, b, slope, stride, tanh=False):
+    """modules.py:135-141 (pad from modules.py:115)."""
+    K = w.shape[2]
+    pad = max(0, (stride - K) // -2)
+    h = F.conv_transpose1d(x, w, b, stride=stride, padding=pad)
+    if K % 2 != 0:
+        h = h[:, :, :-1]
+    return torch.tanh(h) if tanh else F.prelu(h, slope)
+
+
+def _count(sd, prefix):
+    n = 0
+    while '{}.{}.act.weight'.format(prefix, n) in sd or \
+            '{}.{}.deconv.weight'.format(prefix, n) in sd:
+        n += 1
+    return n
+
+
+def generator_forward(sd, x, z, strides, dec_strides=None, ret_hid=False):
+    """generator.py:180-230 with skip_type alpha, skip_merge concat."""
+    n_enc = _count(sd, 'enc_blocks')
+    n_dec = _count(sd, 'dec_blocks')
+    dec_strides = dec_strides or list(strides)
+    hall = {}
+    hi = x
+    skips = {}
+    for l in range(n_enc):
+        p = 'enc_blocks.{}.'.format(l)
+        hi, lin = gconv_block(hi, sd[p + 'conv.weight'], sd.get(p + 'conv.bias'),
+                              sd[p + 'act.weight'], strides[l])
+        if l < n_enc - 1 and 'alpha_{}.skip_k'.format(l) in sd:
+            skips[l] = lin                       # the PRE-activation (generator.py:185,191)
+        hall['enc_{}'.format(l)] = hi
+    if z is not None:
+        hi = torch.cat((z, hi), dim=1)           # generator.py:205
+        hall['enc_zc'] = hi
+    enc_idx = n_enc - 1
+    for l in range(n_dec):
+        if enc_idx in skips and dec_strides[l] > 1:
+            alpha = sd['alpha_{}.skip_k'.format(enc_idx)]
+            sk = alpha.repeat(hi.size(0), 1, skips[enc_idx].size(2)) * skips[enc_idx]
+            hi = torch.cat((hi, sk), dim=1)      # GSkip concat, generator.py:64-76
+        p = 'dec_blocks.{}.'.format(l)
+        last = (p + 'act.weight') not in sd
+        hi = gdeconv_block(hi, sd[p + 'deconv.weight'], sd[p + 'deconv.bias'],
+                           sd.get(p + 'act.weight'), dec_strides[l], tanh=last)
+        enc_idx -= 1
+        hall['dec_{}'.format(l)] = hi
+    return (hi, hall) if ret_hid else hi
+
+
+def discriminator_forward(sd, x, rolls, strides, training=True, ret_act=False):
+    """discriminator.py:150-194 (pool_type 'none', norm 'bnorm' or none).  `sd` must hold
+    the BN running buffers when bnorm; they are updated in place like nn.BatchNorm1d."""
+    n = _count(sd, 'enc_blocks')
+    h = x
+    acts = {}
+    for l in range(n):
+        p = 'enc_blocks.{}.'.format(l)
+        h = roll(h, rolls[l])
+        bn = None
+        if p + 'norm.weight' in sd:
+            bn = {'weight': sd[p + 'norm.weight'], 'bias': sd[p + 'norm.bias'],
+                  'running_mean': sd[p + 'norm.running_mean'],
+                  'running_var': sd[p + 'norm.running_var']}
+        h, _ = gconv_block(h, sd[p + 'conv.weight'], sd.get(p + 'conv.bias'),
+                           sd[p + 'act.weight'], strides[l], bn=bn, training=training)
+        acts['h_{}'.format(l)] = h
+    h = h.view(h.size(0), -1)
+    h = F.prelu(F.linear(h, sd['fc.0.weight'], sd['fc.0.bias']), sd['fc.1.weight'])
+    h = F.prelu(F.linear(h, sd['fc.2.weight'], sd['fc.2.bias']), sd['fc.3.weight'])
+    y = F.linear(h, sd['fc.4.weight'], sd['fc.4.bias'])
+    acts['logit'] = y
+    return (y, acts) if ret_act else y
+
+
+_BUFFERS = ('running_mean', 'running_var', 'num_batches_tracked')
+
+
+def _leafs(sd):
+    out = {}
+    for k, v in sd.items():
+        if k.split('.')[-1] in _BUFFERS:
+            out[k] = v.clone()
+        else:
+            out[k] = v.clone().requires_grad_(True)
+    return out
+
+
+def _is_param(k):
+    return k.split('.')[-1] not in _BUFFERS
+
+
+def rmsprop_update(p, g, sq, lr, alpha=0.99, eps=1e-8):
+    """torch.optim.RMSprop single-tensor rule (momentum 0, not centered)."""
+    sq.mul_(alpha).addcmul_(g, g, value=1 - alpha)
+    p.addcdiv_(g, sq.sqrt().add_(eps), value=-lr)
+
+
+def gan_step(g_sd, d_sd, clean, noisy, z, rolls3, strides, l1_weight=100.0, lr=5e-5,
+             g_sq=None, d_sq=None, update=True):
+    """One SEGAN step, model.py:292-321.  rolls3 = three roll lists (D real, D fake,
+    D fake-for-G).  Returns a dict with outputs, losses, gradients and (when `update`)
+    the updated parameters / RMSprop state."""
+    G = _leafs(g_sd)
+    D = _leafs(d_sd)
+    out = {}
+    # (1)+(2) discriminator update
+    Genh = generator_forward(G, noisy, z, strides)
+    d_real = discriminator_forward(D, torch.cat((clean, noisy), 1), rolls3[0], strides)
+    d_real_loss = F.mse_loss(d_real.view(-1), torch.ones(clean.size(0), dtype=clean.dtype))
+    d_fake = discriminator_forward(D, torch.cat((Genh.detach(), noisy), 1), rolls3[1], strides)
+    d_fake_loss = F.mse_loss(d_fake.view(-1), torch.zeros(clean.size(0), dtype=clean.dtype))
+    dkeys = [k for k in D if _is_param(k)]
+    dgr = torch.autograd.grad(d_real_loss + d_fake_loss, [D[k] for k in dkeys])
+    out['Genh'] = Genh.detach()
+    out['d_real'] = d_real.detach()
+    out['d_fake'] = d_fake.detach()
+    out['d_real_loss'] = d_real_loss.detach()
+    out['d_fake_loss'] = d_fake_loss.detach()
+    out['d_grads'] = {k: g for k, g in zip(dkeys, dgr)}
+    d_sq = d_sq or {k: torch.zeros_like(D[k]) for k in dkeys}
+    if update:
+        with torch.no_grad():
+            for k, g in zip(dkeys, dgr):
+                rmsprop_update(D[k], g, d_sq[k], lr)
+    # (3) generator update through the updated D
+    d_fake_ = discriminator_forward(D, torch.cat((Genh, noisy), 1), rolls3[2], strides)
+    g_adv = F.mse_loss(d_fake_.view(-1), torch.ones(clean.size(0), dtype=clean.dtype))
+    g_l1 = l1_weight * F.l1_loss(Genh, clean)
+    gkeys = [k for k in G if G[k].requires_grad]
+    ggr = torch.autograd.grad(g_adv + g_l1, [G[k] for k in gkeys])
+    out['d_fake_'] = d_fake_.detach()
+    out['g_adv_loss'] = g_adv.detach()
+    out['g_l1_loss'] = g_l1.detach()
+    out['g_grads'] = {k: g for k, g in zip(gkeys, ggr)}
+    g_sq = g_sq or {k: torch.zeros_like(G[k]) for k in gkeys}
+    if update:
+        with torch.no_grad():
+            for k, g in zip(gkeys, ggr):
+                rmsprop_update(G[k], g, g_sq[k], lr)
+    out['G'] = {k: v.detach() for k, v in G.items()}
+    out['D'] = {k: v.detach() for k, v in D.items()}
+    out['g_sq'], out['d_sq'] = g_sq, d_sq
+    return out

@@ -1,0 +1,47 @@
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'oracle')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs an MI355X (run with -m gpu on the GPU box)')
+
+
+def load_golden(name):
+    return torch.load(os.path.join(GOLDEN, name), map_location='cpu', weights_only=False)
+
+
+@pytest.fixture(scope='session')
+def tiny_step():
+    return load_golden('tiny_step.pt')
+
+
+@pytest.fixture(scope='session')
+def tiny_train2():
+    return load_golden('tiny_train2.pt')
+
+
+@pytest.fixture(scope='session')
+def tiny_s2():
+    return load_golden('tiny_s2.pt')
+
+
+@pytest.fixture(scope='session')
+def segan_plus_b2():
+    return load_golden('segan_plus_b2.pt')
+
+
+def max_rel(a, b):
+    """max |a-b| / max(|b|) — scale-aware error for tensors."""
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    den = b.abs().max().item()
+    return (a - b).abs().max().item() / (den if den > 0 else 1.0)

@@ -1,0 +1,355 @@
+"""Parity of every HIP entry point with the CPU oracle / torch fp64 on seeded inputs.
+
+Tolerance: the kernels are exact fp32 (MFMA f32 == fmaf chain); against an fp64
+reference the error is fp32 accumulation roundoff.  Bar used here: max|err| <= 3e-5 *
+max|ref| for the contractions (K' up to ~16k terms), 1e-5 for pointwise kernels.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import segan_oracle as O
+from conftest import max_rel
+
+pytestmark = pytest.mark.gpu
+
+TOL = 3e-5
+DEV = 'cuda'
+
+
+def _ops():
+    from segan_pytorch_amd import ops
+    return ops
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).float()
+
+
+def xform_ref(x, scale=None, shift=None, slope=None):
+    x = x.double()
+    if scale is not None:
+        x = x * scale.double().view(1, -1, 1)
+    if shift is not None:
+        x = x + shift.double().view(1, -1, 1)
+    if slope is not None:
+        x = torch.where(x > 0, x, x * slope.double().view(1, -1, 1))
+    return x
+
+
+def conv_ref(x, w, b, S, roll=0):
+    K = w.shape[2]
+    P = (K // 2 - 1, K // 2) if S > 1 else (K // 2, K // 2)
+    xr = O.roll(x, roll)
+    return F.conv1d(F.pad(xr, P, mode='reflect'), w, b, stride=S)
+
+
+CONV_CASES = [
+    # B, N(Cin), M(Cout), L, S, K, roll
+    (2, 3, 5, 64, 4, 31, 0),
+    (3, 64, 128, 256, 4, 31, 2),
+    (2, 2, 64, 1024, 4, 31, -3),
+    (5, 1, 64, 256, 4, 31, 0),
+    (9, 32, 200, 64, 4, 31, 5),
+    (2, 16, 24, 128, 2, 31, -1),
+    (3, 8, 8, 64, 1, 31, 0),
+    (2, 6, 7, 128, 4, 5, 1),
+    (2, 256, 130, 512, 4, 31, 0),
+    (1, 12, 40, 4096, 4, 31, 4),
+]
+
+
+@pytest.mark.parametrize('B,N,M,L,S,K,roll', CONV_CASES)
+def test_conv1d_fwd_dgrad_wgrad(B, N, M, L, S, K, roll):
+    ops = _ops()
+    x = rnd(B, N, L, seed=1)
+    w = rnd(M, N, K, seed=2, scale=0.1)
+    b = rnd(M, seed=3)
+    xd = x.double().requires_grad_(True)
+    wd = w.double().requires_grad_(True)
+    ref = conv_ref(xd, wd, b.double(), S, roll)
+    xg, wg, bg = x.to(DEV), w.to(DEV), b.to(DEV)
+    out = ops.conv1d_fwd(ops.Src(xg), wg, bg, S, roll=roll)
+    assert out.shape == ref.shape
+    assert max_rel(out, ref) < TOL
+    da = rnd(*ref.shape, seed=4)
+    ref.backward(da.double())
+    dag = da.to(DEV)
+    dx = ops.conv1d_dgrad(dag, wg, L, S, roll=roll)
+    assert max_rel(dx, xd.grad) < TOL
+    dw = torch.zeros_like(wg)
+    padL = ops.conv_pad(K, S)[0]
+    ops.wgrad(ops.Src(dag), ops.Src(xg), dw, K, S, padL, ops.PAD_REFLECT, roll=roll)
+    assert max_rel(dw, wd.grad) < TOL
+    # accumulation semantics: a second call doubles the gradient
+    ops.wgrad(ops.Src(dag), ops.Src(xg), dw, K, S, padL, ops.PAD_REFLECT, roll=roll)
+    assert max_rel(dw, 2 * wd.grad) < TOL
+
+
+def test_conv1d_fwd_dual_source_and_transform():
+    """D.enc0-style two pointers + BN/PReLU-on-load (segan_src)."""
+    ops = _ops()
+    B, L, S, K, M = 3, 256, 4, 31, 20
+    x0, x1 = rnd(B, 5, L, seed=1), rnd(B, 3, L, seed=2)
+    sc, sh, sl = rnd(8, seed=3), rnd(8, seed=4), rnd(8, seed=5).abs() * 0.3
+    w, b = rnd(M, 8, K, seed=6, scale=0.1), rnd(M, seed=7)
+    xin = xform_ref(torch.cat((x0, x1), 1), sc, sh, sl)
+    ref = conv_ref(xin, w.double(), b.double(), S, roll=-2)
+    src = ops.Src(x0.to(DEV), x1.to(DEV), scale=sc.to(DEV), shift=sh.to(DEV), slope=sl.to(DEV))
+    out = ops.conv1d_fwd(src, w.to(DEV), b.to(DEV), S, roll=-2)
+    assert max_rel(out, ref) < TOL
+    # and as the `hi` operand of the weight gradient
+    da = rnd(*ref.shape, seed=8)
+    wd = w.double().requires_grad_(True)
+    conv_ref(xin, wd, None, S, roll=-2).backward(da.double())
+    dw = torch.zeros(M, 8, K, device=DEV)
+    ops.wgrad(ops.Src(da.to(DEV)), src, dw, K, S, ops.conv_pad(K, S)[0], ops.PAD_REFLECT, roll=-2)
+    assert max_rel(dw, wd.grad) < TOL
+
+
+def deconv_ref(x, w, b, S):
+    K = w.shape[2]
+    pad = max(0, (S - K) // -2)
+    y = F.conv_transpose1d(x, w, b, stride=S, padding=pad)
+    return y[:, :, :-1] if K % 2 else y
+
+
+DECONV_CASES = [
+    # B, M(Cin), N(Cout), Ls, S, K
+    (2, 6, 5, 16, 4, 31),
+    (3, 128, 64, 64, 4, 31),
+    (2, 16, 1, 256, 4, 31),
+    (9, 40, 33, 16, 4, 31),
+    (2, 8, 12, 32, 2, 31),
+    (1, 24, 130, 1024, 4, 31),
+]
+
+
+@pytest.mark.parametrize('B,M,N,Ls,S,K', DECONV_CASES)
+def test_deconv1d_fwd_dgrad_wgrad(B, M, N, Ls, S, K):
+    ops = _ops()
+    x = rnd(B, M, Ls, seed=1)
+    w = rnd(M, N, K, seed=2, scale=0.1)
+    b = rnd(N, seed=3)
+    xd = x.double().requires_grad_(True)
+    wd = w.double().requires_grad_(True)
+    ref = deconv_ref(xd, wd, b.double(), S)
+    xg, wg, bg = x.to(DEV), w.to(DEV), b.to(DEV)
+    y = ops.deconv1d_fwd(ops.Src(xg), wg, bg, S)
+    assert y.shape == ref.shape
+    assert max_rel(y, ref) < TOL
+    yt = ops.deconv1d_fwd(ops.Src(xg), wg, bg, S, act=ops.ACT_TANH)
+    assert (yt.cpu().double() - torch.tanh(ref.detach())).abs().max().item() < 1e-5
+    dy = rnd(*ref.shape, seed=4)
+    ref.backward(dy.double())
+    dyg = dy.to(DEV)
+    _d0, dx = ops.deconv1d_dgrad(dyg, wg, S, 0)
+    assert max_rel(dx, xd.grad) < TOL
+    if M >= 2:
+        M0 = M // 2
+        dx0, dx1 = ops.deconv1d_dgrad(dyg, wg, S, M0)
+        assert max_rel(dx0, xd.grad[:, :M0]) < TOL
+        assert max_rel(dx1, xd.grad[:, M0:]) < TOL
+        n0, d1 = ops.deconv1d_dgrad(dyg, wg, S, M0, need0=False)
+        assert n0 is None and max_rel(d1, xd.grad[:, M0:]) < TOL
+    dw = torch.zeros_like(wg)
+    ops.wgrad(ops.Src(xg), ops.Src(dyg), dw, K, S, ops.deconv_pad(K, S), ops.PAD_ZERO)
+    assert max_rel(dw, wd.grad) < TOL
+
+
+def test_deconv1d_skip_concat_alpha_on_load():
+    """Decoder input = cat(prelu(prev), alpha * skip) folded into the load
+    (generator.py:64-76, 212-222)."""
+    ops = _ops()
+    B, C, Ls, S, K, N = 3, 24, 64, 4, 31, 10
+    prev, skip = rnd(B, C, Ls, seed=1), rnd(B, C, Ls, seed=2)
+    s_prev, alpha = rnd(C, seed=3).abs() * 0.2, rnd(C, seed=4)
+    w, b = rnd(2 * C, N, K, seed=5, scale=0.1), rnd(N, seed=6)
+    ones = torch.ones(C)
+    xin = torch.cat((xform_ref(prev, slope=s_prev), xform_ref(skip, scale=alpha)), 1)
+    xin.requires_grad_(True)
+    wd = w.double().requires_grad_(True)
+    ref = deconv_ref(xin, wd, b.double(), S)
+    src = ops.Src(prev.to(DEV), skip.to(DEV), scale=torch.cat((ones, alpha)).to(DEV),
+                  slope=torch.cat((s_prev, ones)).to(DEV))
+    y = ops.deconv1d_fwd(src, w.to(DEV), b.to(DEV), S)
+    assert max_rel(y, ref) < TOL
+    dy = rnd(*ref.shape, seed=7)
+    ref.backward(dy.double())
+    dw = torch.zeros(2 * C, N, K, device=DEV)
+    ops.wgrad(src, ops.Src(dy.to(DEV)), dw, K, S, ops.deconv_pad(K, S), ops.PAD_ZERO)
+    assert max_rel(dw, wd.grad) < TOL
+
+
+def test_bn_stats_and_affine_prelu():
+    ops = _ops()
+    B, C, L = 7, 40, 48
+    x = rnd(B, C, L, seed=1) * 3 + 1.5
+    gamma, beta, slope = rnd(C, seed=2), rnd(C, seed=3), rnd(C, seed=4).abs() * 0.3
+    rm, rv = torch.zeros(C), torch.ones(C)
+    ref = F.batch_norm(x.double(), rm.double().clone(), rv.double().clone(), gamma.double(),
+                       beta.double(), True, 0.1, 1e-5)
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    F.batch_norm(x, rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5)
+    rmg, rvg = rm.to(DEV), rv.to(DEV)
+    xg = x.to(DEV)
+    mean, rstd, scale, shift = ops.bn_stats(xg, gamma.to(DEV), beta.to(DEV), 1e-5, 0.1, rmg, rvg)
+    assert max_rel(mean, x.double().mean((0, 2))) < 1e-6
+    assert max_rel(rmg, rm_ref) < 1e-6 and max_rel(rvg, rv_ref) < 1e-6
+    y = ops.affine_prelu(xg, scale, shift, None)
+    assert max_rel(y, ref) < 1e-5
+    h = ops.affine_prelu(xg, scale, shift, slope.to(DEV))
+    assert max_rel(h, F.prelu(ref, slope.double())) < 1e-5
+
+
+@pytest.mark.parametrize('B,C,L', [(6, 24, 32), (300, 8, 16), (3, 70, 1000)])
+def test_act_bwd_bn_prelu(B, C, L):
+    """Backward through BatchNorm(train) + PReLU incl. gamma/beta/slope/bias grads."""
+    ops = _ops()
+    c = rnd(B, C, L, seed=1) * 2 + 0.3
+    gamma, beta = rnd(C, seed=2) + 1.5, rnd(C, seed=3)
+    slope = rnd(C, seed=4).abs() * 0.3
+    dh = rnd(B, C, L, seed=5)
+    cd = c.double().requires_grad_(True)
+    gd, bd, sd = (t.double().requires_grad_(True) for t in (gamma, beta, slope))
+    a = F.batch_norm(cd, None, None, gd, bd, True, 0.1, 1e-5)
+    F.prelu(a, sd).backward(dh.double())
+    cg = c.to(DEV)
+    mean, rstd, scale, shift = ops.bn_stats(cg, gamma.to(DEV), beta.to(DEV), 1e-5, 0.1, None, None)
+    dsl, dga, dbe, dbi = (torch.zeros(C, device=DEV) for _ in range(4))
+    dc = ops.act_bwd(cg, dh.to(DEV), slope=slope.to(DEV),
+                     bn=(mean, rstd, gamma.to(DEV), beta.to(DEV)),
+                     dslope=dsl, dgamma=dga, dbeta=dbe, dbias=dbi)
+    assert max_rel(dc, cd.grad) < 2e-5
+    assert max_rel(dsl, sd.grad) < 2e-5
+    assert max_rel(dga, gd.grad) < 2e-5
+    assert max_rel(dbe, bd.grad) < 2e-5
+    # a bias in front of BatchNorm has a mathematically zero gradient
+    assert dbi.abs().max().item() < 1e-3 * dh.abs().sum().item() / C
+
+
+def test_act_bwd_prelu_skip():
+    """G encoder backward: da = dh*prelu'(a) + alpha*dskip; dslope, dalpha, dbias."""
+    ops = _ops()
+    B, C, L = 5, 33, 64
+    a, dh, dsk = rnd(B, C, L, seed=1), rnd(B, C, L, seed=2), rnd(B, C, L, seed=3)
+    slope, alpha = rnd(C, seed=4).abs() * 0.3, rnd(C, seed=5)
+    ad = a.double().requires_grad_(True)
+    sd, al = slope.double().requires_grad_(True), alpha.double().requires_grad_(True)
+    h = F.prelu(ad, sd)
+    sk = al.view(1, -1, 1) * ad
+    ((h * dh.double()).sum() + (sk * dsk.double()).sum()).backward()
+    dsl, dal, dbi = (torch.zeros(C, device=DEV) for _ in range(3))
+    da = ops.act_bwd(a.to(DEV), dh.to(DEV), dskip=dsk.to(DEV), slope=slope.to(DEV),
+                     alpha=alpha.to(DEV), dslope=dsl, dalpha=dal, dbias=dbi)
+    assert max_rel(da, ad.grad) < 1e-5
+    assert max_rel(dsl, sd.grad) < 1e-5
+    assert max_rel(dal, al.grad) < 1e-5
+    assert max_rel(dbi, ad.grad.sum((0, 2))) < 1e-5
+    # PReLU initialised at 0 (modules.py:81): slope 0, and a == 0 exactly
+    a0 = a.clone()
+    a0[0, 0, :5] = 0.0
+    z = torch.zeros(C)
+    da0 = ops.act_bwd(a0.to(DEV), dh.to(DEV), slope=z.to(DEV))
+    want = torch.where(a0 > 0, dh, torch.zeros_like(dh))
+    assert max_rel(da0, want) < 1e-6
+
+
+def test_tanh_bwd_with_l1():
+    ops = _ops()
+    B, L = 4, 512
+    y = torch.tanh(rnd(B, 1, L, seed=1))
+    dy, clean = rnd(B, 1, L, seed=2), rnd(B, 1, L, seed=3).clamp(-1, 1)
+    db = torch.zeros(1, device=DEV)
+    da = ops.tanh_bwd(y.to(DEV), dy.to(DEV), clean=clean.to(DEV), l1_scale=0.25, dbias=db)
+    want = (dy.double() + 0.25 * torch.sign(y.double() - clean.double())) * (1 - y.double() ** 2)
+    assert max_rel(da, want) < 1e-5
+    assert max_rel(db, want.sum().view(1)) < 1e-5
+    da2 = ops.tanh_bwd(y.to(DEV), dy.to(DEV))
+    assert max_rel(da2, dy.double() * (1 - y.double() ** 2)) < 1e-5
+
+
+@pytest.mark.parametrize('Bn,I,Oo', [(5, 512, 256), (300, 16384, 256), (7, 256, 128), (3, 128, 1)])
+def test_dense_head_gemms(Bn, I, Oo):
+    ops = _ops()
+    x, w, dy = rnd(Bn, I, seed=1), rnd(Oo, I, seed=2, scale=0.05), rnd(Bn, Oo, seed=3)
+    xg, wg, dyg = x.to(DEV), w.to(DEV), dy.to(DEV)
+    assert max_rel(ops.linear_fwd(xg, wg), x.double() @ w.double().t()) < TOL
+    assert max_rel(ops.linear_dgrad(dyg, wg), dy.double() @ w.double()) < TOL
+    dw = torch.zeros_like(wg)
+    ops.linear_wgrad(dyg, xg, dw)
+    ops.linear_wgrad(dyg, xg, dw)
+    assert max_rel(dw, 2 * dy.double().t() @ x.double()) < TOL
+
+
+def test_bias_prelu_rows_fwd_bwd():
+    ops = _ops()
+    R, Cc = 9, 256
+    x, b, s, dy = rnd(R, Cc, seed=1), rnd(Cc, seed=2), rnd(Cc, seed=3).abs() * 0.3, rnd(R, Cc, seed=4)
+    xd = x.double().requires_grad_(True)
+    bd, sd = b.double().requires_grad_(True), s.double().requires_grad_(True)
+    ref = F.prelu(xd + bd, sd)
+    ref.backward(dy.double())
+    y = ops.bias_prelu_rows(x.to(DEV), b.to(DEV), s.to(DEV))
+    assert max_rel(y, ref) < 1e-6
+    ds, db = torch.zeros(Cc, device=DEV), torch.zeros(Cc, device=DEV)
+    dx = ops.bias_prelu_rows_bwd(x.to(DEV), b.to(DEV), s.to(DEV), dy.to(DEV), ds, db)
+    assert max_rel(dx, xd.grad) < 1e-6 and max_rel(ds, sd.grad) < 1e-5
+    assert max_rel(db, bd.grad) < 1e-5
+
+
+def test_losses():
+    ops = _ops()
+    from segan_pytorch_amd import losses
+    d = rnd(300, seed=1).to(DEV).requires_grad_(True)
+    l = losses.MSELoss()(d, 1.0)
+    (3.0 * l).backward()
+    dd = d.detach().cpu().double().requires_grad_(True)
+    lr = F.mse_loss(dd, torch.ones(300, dtype=torch.float64))
+    (3.0 * lr).backward()
+    assert abs(l.item() - lr.item()) < 1e-6 * max(1, abs(lr.item()))
+    assert max_rel(d.grad, dd.grad) < 1e-6
+    x = rnd(3, 1, 4096, seed=2).to(DEV).requires_grad_(True)
+    y = rnd(3, 1, 4096, seed=3).to(DEV)
+    l1 = losses.l1_loss(x, y)
+    (100.0 * l1).backward()
+    xd = x.detach().cpu().double().requires_grad_(True)
+    l1r = F.l1_loss(xd, y.cpu().double())
+    (100.0 * l1r).backward()
+    assert abs(l1.item() - l1r.item()) < 1e-6
+    assert max_rel(x.grad, xd.grad) < 1e-6
+
+
+def test_fused_optimizers_match_torch():
+    from segan_pytorch_amd import optim as soptim
+    shapes = [(5, 3, 31), (7,), (1, 6, 1), (130, 4)]
+    for kind in ('rmsprop', 'adam'):
+        ps = [torch.nn.Parameter(rnd(*s, seed=i)) for i, s in enumerate(shapes)]
+        qs = [torch.nn.Parameter(p.detach().clone().to(DEV)) for p in ps]
+        if kind == 'rmsprop':
+            ref = torch.optim.RMSprop(ps, lr=5e-5)
+            opt = soptim.RMSprop(qs, lr=5e-5)
+        else:
+            ref = torch.optim.Adam(ps, lr=5e-5, betas=(0, 0.9))
+            opt = soptim.Adam(qs, lr=5e-5, betas=(0, 0.9))
+        for it in range(3):
+            for i, (p, q) in enumerate(zip(ps, qs)):
+                g = rnd(*p.shape, seed=100 + 10 * it + i)
+                p.grad = g.clone()
+                q.grad.copy_(g.to(DEV))
+            ref.step()
+            opt.step()
+        for p, q in zip(ps, qs):
+            assert (q.detach().cpu() - p.detach()).abs().max().item() < 2e-7, kind
+        assert set(opt.state_dict()['state'][0].keys()) == set(ref.state_dict()['state'][0].keys())
+        opt.zero_grad()
+        assert all(float(q.grad.abs().max()) == 0.0 for q in qs)
+
+
+def test_cpu_tensor_raises_no_fallback():
+    ops = _ops()
+    with pytest.raises(RuntimeError):
+        ops.Src(torch.zeros(1, 1, 64))
+    with pytest.raises(RuntimeError):
+        ops.conv1d_fwd(ops.Src(torch.zeros(1, 1, 64, device=DEV)), torch.zeros(4, 1, 31), None, 4)

@@ -1,0 +1,275 @@
+"""Network-level parity on the MI355X: the HIP Generator / Discriminator / GAN step
+against golden outputs of the REAL reference (tests/golden, see oracle/make_golden.py).
+
+Stated fp32 tolerances: activations/logits/losses 2e-5 relative to the tensor's max;
+gradients 1e-4 relative; weights after an RMSprop step within 10 % of a step (5e-5 abs);
+north-star bar: generator-output MSE < 1e-4 (measured: ~1e-13).
+"""
+import random
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+import segan_oracle as O
+from conftest import max_rel
+
+# RMSprop's first step moves every weight by lr*g/(0.1|g|+1e-8) = +-10*lr = 5e-4 wherever
+# |g| >> 1e-7 and is ill-conditioned where the gradient is at roundoff level (|g| ~ 1e-8):
+# weights after a step are compared to 10 % of a full step.
+STEP_TOL = 5e-5
+# A conv bias in front of BatchNorm has a mathematically zero gradient; what autograd returns
+# is roundoff noise that RMSprop normalises into +-10*lr random steps, so that bias (which
+# BatchNorm cancels exactly) and the running_mean that tracks it are implementation noise.
+NOISE_KEYS = ('conv.bias', 'norm.running_mean')
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+ACT_TOL = 2e-5
+GRAD_TOL = 1e-4
+
+
+def build(fx, seed=None):
+    from segan_pytorch_amd.models import SEGAN
+    if seed is not None:
+        random.seed(seed)
+        np.random.seed(seed)
+        torch.manual_seed(seed)
+    m = SEGAN(SimpleNamespace(**fx['opts']))
+    if 'G0' in fx:
+        m.G.load_state_dict(fx['G0'])
+        m.D.load_state_dict(fx['D0'])
+    return m.to(DEV)
+
+
+def run_step(m, fx, clean, noisy, z):
+    from segan_pytorch_amd import losses
+    opts = SimpleNamespace(**fx['opts'])
+    Gopt, Dopt = m.build_optimizers(opts)
+    m.G.train()
+    m.D.train()
+    random.seed(fx['roll_seed'])
+    out = m.gan_step(clean.to(DEV), noisy.to(DEV), Gopt, Dopt, losses.MSELoss(), 100.0,
+                     z=z.to(DEV))
+    torch.cuda.synchronize()
+    return out, Gopt, Dopt
+
+
+def check_step_against_golden(fx):
+    m = build(fx)
+    (d_real_loss, d_fake_loss, g_adv, g_l1), Gopt, Dopt = run_step(
+        m, fx, fx['clean'], fx['noisy'], fx['z'])
+    for got, key in ((d_real_loss, 'd_real_loss'), (d_fake_loss, 'd_fake_loss'),
+                     (g_adv, 'g_adv_loss'), (g_l1, 'g_l1_loss')):
+        assert max_rel(got, fx[key]) < ACT_TOL, key
+    for name, net, grads in (('D', m.D, fx['d_grads']), ('G', m.G, fx['g_grads'])):
+        named = dict(net.named_parameters())
+        for k, g in grads.items():
+            if name == 'D' and k.endswith('conv.bias'):
+                continue   # zero-mean-gradient biases in front of BatchNorm: roundoff only
+            assert max_rel(named[k].grad, g) < GRAD_TOL, (name, k)
+    for name, net, after in (('G', m.G, fx['G_after']), ('D', m.D, fx['D_after'])):
+        sd = net.state_dict()
+        for k, v in after.items():
+            if not torch.is_floating_point(v) or (name == 'D' and k.endswith(NOISE_KEYS)):
+                continue
+            err = (sd[k].cpu() - v).abs().max().item()
+            assert err < STEP_TOL, (name, k, err)
+
+
+def test_tiny_gan_step_matches_reference(tiny_step):
+    check_step_against_golden(tiny_step)
+
+
+def test_tiny_stride2_gan_step_matches_reference(tiny_s2):
+    check_step_against_golden(tiny_s2)
+
+
+def test_tiny_forward_hidden_and_int_act(tiny_step):
+    fx = tiny_step
+    m = build(fx)
+    m.G.train()
+    m.D.train()
+    with torch.no_grad():
+        y, hall = m.G(fx['noisy'].to(DEV), z=fx['z'].to(DEV), ret_hid=True)
+        assert set(hall.keys()) == set(fx['G_hall'].keys())
+        for k, v in fx['G_hall'].items():
+            assert max_rel(hall[k], v) < ACT_TOL, k
+        assert max_rel(y, fx['G_hall']['dec_2']) < ACT_TOL
+        random.seed(fx['roll_seed'])
+        yd, acts = m.D(torch.cat((fx['clean'], fx['noisy']), 1).to(DEV))
+        for k, v in fx['D_acts'].items():
+            assert k in acts
+            assert max_rel(acts[k], v) < ACT_TOL, k
+
+
+def test_tiny_literal_train_matches_reference(tiny_train2, tmp_path):
+    """Our SEGAN.train on the same two batches, same global seeds: z is drawn on the host
+    by Generator.forward (generator.py:197) and the shifts by python's random, so the
+    trajectories coincide."""
+    fx = tiny_train2
+    o = dict(fx['opts'])
+    o['save_path'] = str(tmp_path)
+    m = build({'opts': o, 'G0': fx['G0'], 'D0': fx['D0']})
+    loader = [[['u'] * 3, c, n, torch.zeros(3)] for c, n in fx['batches']]
+    random.seed(fx['seed'])
+    np.random.seed(fx['seed'])
+    torch.manual_seed(fx['seed'])
+    opts = SimpleNamespace(**o)
+    m.train(opts, loader, None, o['l1_weight'], o['l1_dec_step'], o['l1_dec_epoch'], 1000,
+            va_dloader=None, device=DEV)
+    for name, net, fin in (('G', m.G, fx['G_final']), ('D', m.D, fx['D_final'])):
+        sd = net.state_dict()
+        for k, v in fin.items():
+            if not torch.is_floating_point(v) or (name == 'D' and k.endswith(NOISE_KEYS)):
+                continue
+            err = (sd[k].cpu() - v).abs().max().item()
+            assert err < 2 * STEP_TOL, (name, k, err)
+    # checkpoints were written in the reference's format
+    import os
+    names = os.listdir(str(tmp_path))
+    assert any(n.startswith('weights_EOE_G-Generator-') for n in names)
+    assert 'EOE_D-checkpoints' in names
+
+
+def _chk(t, c, tol):
+    t = t.detach().double().cpu().reshape(-1)
+    scale = max(c['abs'], 1e-30)
+    assert abs(t.sum().item() - c['sum']) / scale < tol
+    assert abs(t.abs().sum().item() - c['abs']) / scale < tol
+    got = t[c['sample_idx']].float()
+    den = max(c['sample'].abs().max().item(), 1e-30)
+    assert (got - c['sample']).abs().max().item() / den < tol
+
+
+def test_default_segan_plus_step_matches_reference(segan_plus_b2):
+    """The full SEGAN+ net (64.8 M + 25.8 M parameters), built from seed 111 by OUR
+    constructors, one GAN step at B=2 against the reference's outputs."""
+    from segan_pytorch_amd.datasets import synthetic_pairs
+    fx = segan_plus_b2
+    m = build(fx, seed=fx['seed'])
+    clean, noisy = synthetic_pairs(2, 16384, fx['data_seed'])
+    clean, noisy = clean.unsqueeze(1), noisy.unsqueeze(1)
+    z = torch.randn(2, 1024, 16, generator=torch.Generator().manual_seed(fx['z_seed']))
+    with torch.no_grad():
+        m.G.train()
+        y = m.G(noisy.to(DEV), z=z.to(DEV))
+    mse = ((y.cpu().double() - fx['Genh'].double()) ** 2).mean().item()
+    assert mse < 1e-4          # the north-star bar
+    assert mse < 1e-10         # what exact fp32 actually gives
+    assert (y.cpu() - fx['Genh']).abs().max().item() < 1e-5
+    (d_real_loss, d_fake_loss, g_adv, g_l1), Gopt, Dopt = run_step(m, fx, clean, noisy, z)
+    for got, key in ((d_real_loss, 'd_real_loss'), (d_fake_loss, 'd_fake_loss'),
+                     (g_adv, 'g_adv_loss'), (g_l1, 'g_l1_loss')):
+        assert max_rel(got, fx[key]) < ACT_TOL, key
+    dn, gn = dict(m.D.named_parameters()), dict(m.G.named_parameters())
+    for k, c in fx['d_grads'].items():
+        if not k.endswith('conv.bias'):
+            _chk(dn[k].grad, c, GRAD_TOL)
+    for k, c in fx['g_grads'].items():
+        _chk(gn[k].grad, c, GRAD_TOL)
+    for k, v in fx['small_g_grads'].items():
+        assert max_rel(gn[k].grad, v) < GRAD_TOL, k
+    for k, v in fx['small_d_grads'].items():
+        if not k.endswith('conv.bias'):
+            assert max_rel(dn[k].grad, v) < GRAD_TOL, k
+
+
+def test_generator_full_batch_is_per_sample_independent():
+    """BASELINE size (B=300, 16384 samples): G has no cross-sample coupling, so every
+    row of a batch-300 forward must equal the same row run alone (size-independent
+    property; the oracle cannot run B=300 in seconds)."""
+    from segan_pytorch_amd.models import Generator
+    torch.manual_seed(1)
+    G = Generator(1, [64, 128, 256, 512, 1024], 31, [4] * 5, z_dim=1024, skip_merge='concat',
+                  bias=True).to(DEV)
+    for p in G.parameters():
+        if p.dim() == 1:
+            p.data.uniform_(0.05, 0.3)
+    from segan_pytorch_amd import ops
+    ops.bump_weights_epoch()
+    g = torch.Generator().manual_seed(0)
+    x = (torch.rand(300, 1, 16384, generator=g) * 2 - 1).to(DEV)
+    z = torch.randn(300, 1024, 16, generator=g).to(DEV)
+    with torch.no_grad():
+        y = G(x, z=z)
+        assert torch.isfinite(y).all()
+        for rows in ((0, 2), (151, 153), (298, 300)):
+            ys = G(x[rows[0]:rows[1]].contiguous(), z=z[rows[0]:rows[1]].contiguous())
+            assert (ys - y[rows[0]:rows[1]]).abs().max().item() < 1e-6
+
+
+def test_generator_grads_are_batch_shardable():
+    """Data-parallel identity: the gradient of the mean loss over a batch equals
+    the average of the two half-batch gradients (what the RCCL all-reduce computes)."""
+    from segan_pytorch_amd.models import Generator
+    from segan_pytorch_amd import losses
+    torch.manual_seed(3)
+    G = Generator(1, [8, 16, 32], 31, [4] * 3, z_dim=32, skip_merge='concat', bias=True).to(DEV)
+    g = torch.Generator().manual_seed(0)
+    x = (torch.rand(4, 1, 1024, generator=g) * 2 - 1).to(DEV)
+    c = (torch.rand(4, 1, 1024, generator=g) * 2 - 1).to(DEV)
+    z = torch.randn(4, 32, 16, generator=g).to(DEV)
+
+    def grads(sl):
+        for p in G.parameters():
+            p.grad = None
+        losses.l1_loss(G(x[sl].contiguous(), z=z[sl].contiguous()), c[sl].contiguous()).backward()
+        return [p.grad.clone() for p in G.parameters()]
+
+    full = grads(slice(0, 4))
+    a, b = grads(slice(0, 2)), grads(slice(2, 4))
+    for f, ga, gb in zip(full, a, b):
+        assert max_rel((ga + gb) / 2, f) < 1e-4
+
+
+def test_blocks_standalone_match_oracle():
+    from segan_pytorch_amd.models import GConv1DBlock, GDeconv1DBlock
+    torch.manual_seed(5)
+    blk = GConv1DBlock(6, 10, 31, stride=4, bias=True, norm_type=None).to(DEV)
+    blk.act.weight.data.uniform_(0.1, 0.3)
+    x = torch.randn(3, 6, 128)
+    xg = x.to(DEV).requires_grad_(True)
+    h, a = blk(xg, True)
+    (h.sum() * 2 + (a * a).sum()).backward()
+    sd = {k: v.detach().cpu().double().requires_grad_(True) for k, v in blk.state_dict().items()}
+    xd = x.double().requires_grad_(True)
+    hr, ar = O.gconv_block(xd, sd['conv.weight'], sd['conv.bias'], sd['act.weight'], 4)
+    (hr.sum() * 2 + (ar * ar).sum()).backward()
+    assert max_rel(h, hr) < ACT_TOL and max_rel(a, ar) < ACT_TOL
+    assert max_rel(xg.grad, xd.grad) < GRAD_TOL
+    for k, p in blk.named_parameters():
+        assert max_rel(p.grad, sd[k].grad) < GRAD_TOL, k
+    # with BatchNorm
+    bnb = GConv1DBlock(6, 10, 31, stride=4, bias=True, norm_type='bnorm').to(DEV)
+    bnb.act.weight.data.uniform_(0.1, 0.3)
+    xg2 = x.to(DEV).requires_grad_(True)
+    hb = bnb(xg2)
+    hb.square().sum().backward()
+    sd = {k: v.detach().cpu().double() for k, v in bnb.state_dict().items()}
+    for k in ('conv.weight', 'conv.bias', 'act.weight', 'norm.weight', 'norm.bias'):
+        sd[k].requires_grad_(True)
+    xd2 = x.double().requires_grad_(True)
+    bn = {'weight': sd['norm.weight'], 'bias': sd['norm.bias'],
+          'running_mean': torch.zeros(10, dtype=torch.float64),
+          'running_var': torch.ones(10, dtype=torch.float64)}
+    hr2, _ = O.gconv_block(xd2, sd['conv.weight'], sd['conv.bias'], sd['act.weight'], 4, bn=bn)
+    hr2.square().sum().backward()
+    assert max_rel(hb, hr2) < ACT_TOL
+    assert max_rel(xg2.grad, xd2.grad) < GRAD_TOL
+    assert max_rel(bnb.conv.weight.grad, sd['conv.weight'].grad) < GRAD_TOL
+    # deconv block
+    db = GDeconv1DBlock(10, 4, 31, stride=4).to(DEV)
+    db.act.weight.data.uniform_(0.1, 0.3)
+    xq = torch.randn(2, 10, 32)
+    xqg = xq.to(DEV).requires_grad_(True)
+    yq = db(xqg)
+    yq.square().sum().backward()
+    sd = {k: v.detach().cpu().double().requires_grad_(True) for k, v in db.state_dict().items()}
+    xqd = xq.double().requires_grad_(True)
+    yr = O.gdeconv_block(xqd, sd['deconv.weight'], sd['deconv.bias'], sd['act.weight'], 4)
+    yr.square().sum().backward()
+    assert max_rel(yq, yr) < ACT_TOL
+    assert max_rel(xqg.grad, xqd.grad) < GRAD_TOL
+    assert max_rel(db.deconv.weight.grad, sd['deconv.weight'].grad) < GRAD_TOL

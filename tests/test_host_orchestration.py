@@ -1,0 +1,155 @@
+"""Host logic end to end on CPU: the autograd nodes, the flat-arena optimizers, the GAN
+step and SEGAN.train, run with the TEST-ONLY CPU emulation of the kernel entry points
+(tests/emu_ops.py) against the golden outputs of the real reference.  The HIP kernels
+themselves are checked on the GPU box by tests/test_gpu_*.py."""
+import random
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+import emu_ops
+from conftest import max_rel
+
+# RMSprop's first step moves every weight by lr*g/(0.1|g|+1e-8) = +-10*lr = 5e-4 wherever
+# |g| >> 1e-7 and is ill-conditioned where the gradient is at roundoff level (|g| ~ 1e-8):
+# weights after a step are compared to 10 % of a full step.
+STEP_TOL = 5e-5
+# A conv bias in front of BatchNorm has a mathematically zero gradient; what autograd returns
+# is roundoff noise that RMSprop normalises into +-10*lr random steps, so that bias (which
+# BatchNorm cancels exactly) and the running_mean that tracks it are implementation noise.
+NOISE_KEYS = ('conv.bias', 'norm.running_mean')
+
+
+@pytest.fixture(autouse=True)
+def _emulate():
+    emu_ops.install()
+    yield
+    emu_ops.uninstall()
+
+
+def build(fx):
+    from segan_pytorch_amd.models import SEGAN
+    m = SEGAN(SimpleNamespace(**fx['opts']))
+    m.G.load_state_dict(fx['G0'])
+    m.D.load_state_dict(fx['D0'])
+    return m
+
+
+def check_step(fx):
+    from segan_pytorch_amd import losses
+    m = build(fx)
+    Gopt, Dopt = m.build_optimizers(SimpleNamespace(**fx['opts']))
+    m.G.train()
+    m.D.train()
+    random.seed(fx['roll_seed'])
+    out = m.gan_step(fx['clean'], fx['noisy'], Gopt, Dopt, losses.MSELoss(), 100.0, z=fx['z'])
+    for got, key in zip(out, ('d_real_loss', 'd_fake_loss', 'g_adv_loss', 'g_l1_loss')):
+        assert max_rel(got, fx[key]) < 2e-5, key
+    for name, net, grads in (('D', m.D, fx['d_grads']), ('G', m.G, fx['g_grads'])):
+        named = dict(net.named_parameters())
+        for k, g in grads.items():
+            if name == 'D' and k.endswith('conv.bias'):
+                continue
+            assert max_rel(named[k].grad, g) < 1e-4, (name, k)
+    for name, net, after in (('G', m.G, fx['G_after']), ('D', m.D, fx['D_after'])):
+        sd = net.state_dict()
+        for k, v in after.items():
+            if not torch.is_floating_point(v) or (name == 'D' and k.endswith(NOISE_KEYS)):
+                continue
+            assert (sd[k] - v).abs().max().item() < STEP_TOL, (name, k)
+
+
+def test_gan_step_orchestration(tiny_step):
+    check_step(tiny_step)
+
+
+def test_gan_step_orchestration_stride2(tiny_s2):
+    check_step(tiny_s2)
+
+
+def test_hidden_outputs(tiny_step):
+    fx = tiny_step
+    m = build(fx)
+    m.G.train()
+    m.D.train()
+    with torch.no_grad():
+        y, hall = m.G(fx['noisy'], z=fx['z'], ret_hid=True)
+    assert list(hall.keys()) == list(fx['G_hall'].keys())
+    for k, v in fx['G_hall'].items():
+        assert max_rel(hall[k], v) < 2e-5, k
+    random.seed(fx['roll_seed'])
+    with torch.no_grad():
+        yd, acts = m.D(torch.cat((fx['clean'], fx['noisy']), 1))
+    assert sorted(acts.keys()) == sorted(fx['D_acts'].keys())
+    for k, v in fx['D_acts'].items():
+        assert max_rel(acts[k], v) < 2e-5, k
+
+
+def test_literal_train_and_checkpoints(tiny_train2, tmp_path):
+    fx = tiny_train2
+    o = dict(fx['opts'])
+    o['save_path'] = str(tmp_path)
+    m = build({'opts': o, 'G0': fx['G0'], 'D0': fx['D0']})
+    loader = [[['u'] * 3, c, n, torch.zeros(3)] for c, n in fx['batches']]
+    random.seed(fx['seed'])
+    np.random.seed(fx['seed'])
+    torch.manual_seed(fx['seed'])
+    m.train(SimpleNamespace(**o), loader, None, o['l1_weight'], o['l1_dec_step'],
+            o['l1_dec_epoch'], 1000, va_dloader=None, device='cpu')
+    for name, net, fin in (('G', m.G, fx['G_final']), ('D', m.D, fx['D_final'])):
+        sd = net.state_dict()
+        for k, v in fin.items():
+            if not torch.is_floating_point(v) or (name == 'D' and k.endswith(NOISE_KEYS)):
+                continue
+            assert (sd[k] - v).abs().max().item() < 2 * STEP_TOL, (name, k)
+    # reference checkpoint format (core.py:61-70) and index (core.py:26-59)
+    import json
+    import os
+    idx = json.load(open(os.path.join(str(tmp_path), 'EOE_G-checkpoints')))
+    assert idx['current'] == 'EOE_G-Generator-3.ckpt' and idx['latest'] == [idx['current']]
+    ck = torch.load(os.path.join(str(tmp_path), 'weights_' + idx['current']), weights_only=False)
+    assert set(ck.keys()) == {'step', 'state_dict', 'optimizer'}
+    assert set(ck['optimizer']['state'][0].keys()) == {'step', 'square_avg'}
+    # a fresh generator restores from it (Model.load_pretrained, core.py:187-190)
+    from segan_pytorch_amd.models import SEGAN
+    m2 = SEGAN(SimpleNamespace(**o))
+    m2.G.load_pretrained(os.path.join(str(tmp_path), 'weights_' + idx['current']), True)
+    for k, v in m.G.state_dict().items():
+        assert torch.equal(m2.G.state_dict()[k], v), k
+
+
+def test_blocks_standalone(tiny_step):
+    import segan_oracle as O
+    from segan_pytorch_amd.models import GConv1DBlock, GDeconv1DBlock
+    torch.manual_seed(5)
+    blk = GConv1DBlock(6, 10, 31, stride=4, bias=True, norm_type='bnorm')
+    blk.act.weight.data.uniform_(0.1, 0.3)
+    x = torch.randn(3, 6, 128)
+    xg = x.clone().requires_grad_(True)
+    h = blk(xg)
+    h.square().sum().backward()
+    sd = {k: v.detach().double() for k, v in blk.state_dict().items()}
+    for k in ('conv.weight', 'conv.bias', 'act.weight', 'norm.weight', 'norm.bias'):
+        sd[k].requires_grad_(True)
+    xd = x.double().requires_grad_(True)
+    bn = {'weight': sd['norm.weight'], 'bias': sd['norm.bias'],
+          'running_mean': torch.zeros(10, dtype=torch.float64),
+          'running_var': torch.ones(10, dtype=torch.float64)}
+    hr, _ = O.gconv_block(xd, sd['conv.weight'], sd['conv.bias'], sd['act.weight'], 4, bn=bn)
+    hr.square().sum().backward()
+    assert max_rel(h, hr) < 2e-5 and max_rel(xg.grad, xd.grad) < 1e-4
+    assert max_rel(blk.conv.weight.grad, sd['conv.weight'].grad) < 1e-4
+    assert max_rel(blk.norm.weight.grad, sd['norm.weight'].grad) < 1e-4
+    db = GDeconv1DBlock(10, 4, 31, stride=4)
+    db.act.weight.data.uniform_(0.1, 0.3)
+    xq = torch.randn(2, 10, 32)
+    xqg = xq.clone().requires_grad_(True)
+    db(xqg).square().sum().backward()
+    sd = {k: v.detach().double().requires_grad_(True) for k, v in db.state_dict().items()}
+    xqd = xq.double().requires_grad_(True)
+    O.gdeconv_block(xqd, sd['deconv.weight'], sd['deconv.bias'], sd['act.weight'],
+                    4).square().sum().backward()
+    assert max_rel(xqg.grad, xqd.grad) < 1e-4
+    assert max_rel(db.deconv.weight.grad, sd['deconv.weight'].grad) < 1e-4

@@ -1,0 +1,139 @@
+"""Pin the CPU oracle (oracle/segan_oracle.py) against outputs of the REAL reference
+(tests/golden/*.pt, produced by oracle/make_golden.py from /root/reference)."""
+import random
+from types import SimpleNamespace
+
+import torch
+
+import segan_oracle as O
+from conftest import max_rel
+
+TOL = 2e-5   # fp32 restatement vs fp32 reference modules: same ops, same order
+
+
+def _check_dict(got, want, tol=TOL, what=''):
+    assert set(want.keys()) <= set(got.keys()), (what, set(want) - set(got))
+    for k, v in want.items():
+        if not torch.is_floating_point(v):
+            continue
+        err = max_rel(got[k], v)
+        assert err < tol, '{} {}: rel err {:.3e}'.format(what, k, err)
+
+
+def test_tiny_forward_hidden(tiny_step):
+    fx = tiny_step
+    st = fx['opts']['genc_poolings']
+    y, hall = O.generator_forward(fx['G0'], fx['noisy'], fx['z'], st, ret_hid=True)
+    _check_dict(hall, fx['G_hall'], what='G hall')
+    d0 = {k: v.clone() for k, v in fx['D0'].items()}
+    yd, acts = O.discriminator_forward(d0, torch.cat((fx['clean'], fx['noisy']), 1),
+                                       fx['rolls'][0], st, ret_act=True)
+    _check_dict(acts, fx['D_acts'], what='D acts')
+
+
+def _check_step(fx, tol=TOL):
+    st = fx['opts']['genc_poolings']
+    res = O.gan_step(fx['G0'], fx['D0'], fx['clean'], fx['noisy'], fx['z'], fx['rolls'], st,
+                     l1_weight=100.0, lr=5e-5)
+    for k in ('Genh', 'd_real', 'd_fake', 'd_fake_', 'd_real_loss', 'd_fake_loss', 'g_adv_loss',
+              'g_l1_loss'):
+        assert max_rel(res[k], fx[k]) < tol, k
+    _check_dict(res['d_grads'], fx['d_grads'], tol=1e-4, what='d_grads')
+    _check_dict(res['g_grads'], fx['g_grads'], tol=1e-4, what='g_grads')
+    # RMSprop normalises the gradient, so roundoff-level gradients (conv biases in front of
+    # BatchNorm are mathematically zero) move by +-lr: compare with an absolute tolerance of
+    # a fraction of one lr step.
+    for name, got, want in (('G', res['G'], fx['G_after']), ('D', res['D'], fx['D_after'])):
+        for k, v in want.items():
+            if not torch.is_floating_point(v):
+                continue
+            if name == 'D' and k.endswith('conv.bias'):
+                continue
+            err = (got[k] - v).abs().max().item()
+            assert err < 2e-6, '{} after-step {}: abs err {:.3e}'.format(name, k, err)
+
+
+def test_tiny_step(tiny_step):
+    _check_step(tiny_step)
+
+
+def test_tiny_stride2_step(tiny_s2):
+    _check_step(tiny_s2)
+
+
+def test_tiny_literal_train_replay(tiny_train2):
+    """Replay the reference's literal SEGAN.train (two batches): z comes from the global
+    torch RNG (generator.py:197), the phase shifts from python's random
+    (discriminator.py:159-163)."""
+    fx = tiny_train2
+    o = fx['opts']
+    st = o['genc_poolings']
+    random.seed(fx['seed'])
+    torch.manual_seed(fx['seed'])
+    G, D = fx['G0'], fx['D0']
+    g_sq = d_sq = None
+    for clean, noisy in fx['batches']:
+        clean, noisy = clean.unsqueeze(1), noisy.unsqueeze(1)
+        z = torch.randn(clean.size(0), o['z_dim'], 16)
+        rolls = []
+        for _ in range(3):
+            r = []
+            for _ in st:
+                s = random.randint(1, o['phase_shift'])
+                r.append(s if random.random() > 0.5 else -s)
+            rolls.append(r)
+        res = O.gan_step(G, D, clean, noisy, z, rolls, st, l1_weight=o['l1_weight'],
+                         lr=o['g_lr'], g_sq=g_sq, d_sq=d_sq)
+        G, D, g_sq, d_sq = res['G'], res['D'], res['g_sq'], res['d_sq']
+    for k, v in fx['G_final'].items():
+        assert (G[k] - v).abs().max().item() < 4e-6, k
+    for k, v in fx['D_final'].items():
+        if not torch.is_floating_point(v) or k.endswith('conv.bias'):
+            continue
+        assert (D[k] - v).abs().max().item() < 4e-6, k
+
+
+def _chk(t, c, tol):
+    t = t.detach().double().reshape(-1)
+    assert t.numel() == c['n']
+    scale = max(c['abs'], 1e-30)
+    assert abs(t.sum().item() - c['sum']) / scale < tol
+    assert abs(t.abs().sum().item() - c['abs']) / scale < tol
+    got = t[c['sample_idx']].float()
+    den = max(c['sample'].abs().max().item(), 1e-30)
+    assert (got - c['sample']).abs().max().item() / den < max(tol, 1e-5)
+
+
+def test_default_net_init_and_step(segan_plus_b2):
+    """The default SEGAN+ net: OUR constructors under seed 111 must reproduce the
+    reference's initial weights, and the oracle its outputs/gradients at B=2."""
+    import random as pyrandom
+    import numpy as np
+    from segan_pytorch_amd.models import SEGAN
+    from segan_pytorch_amd.datasets import synthetic_pairs
+    fx = segan_plus_b2
+    pyrandom.seed(fx['seed'])
+    np.random.seed(fx['seed'])
+    torch.manual_seed(fx['seed'])
+    m = SEGAN(SimpleNamespace(**fx['opts']))
+    gsd, dsd = m.G.state_dict(), m.D.state_dict()
+    assert list(gsd.keys()) == list(fx['init_G'].keys())
+    assert list(dsd.keys()) == list(fx['init_D'].keys())
+    for k, c in fx['init_G'].items():
+        _chk(gsd[k], c, 1e-12)
+    for k, c in fx['init_D'].items():
+        if torch.is_floating_point(dsd[k]):
+            _chk(dsd[k], c, 1e-12)
+    clean, noisy = synthetic_pairs(2, 16384, fx['data_seed'])
+    clean, noisy = clean.unsqueeze(1), noisy.unsqueeze(1)
+    z = torch.randn(2, 1024, 16, generator=torch.Generator().manual_seed(fx['z_seed']))
+    st = fx['opts']['genc_poolings']
+    res = O.gan_step(gsd, dsd, clean, noisy, z, fx['rolls'], st, 100.0, 5e-5)
+    for k in ('Genh', 'd_real', 'd_fake', 'd_fake_', 'g_l1_loss', 'g_adv_loss'):
+        assert max_rel(res[k], fx[k]) < TOL, k
+    for k, c in fx['d_grads'].items():
+        if k.endswith('conv.bias'):
+            continue
+        _chk(res['d_grads'][k], c, 1e-4)
+    for k, c in fx['g_grads'].items():
+        _chk(res['g_grads'][k], c, 1e-4)
