@@ -331,7 +331,7 @@ def test_fused_optimizers_match_torch():
             ref = torch.optim.RMSprop(ps, lr=5e-5)
             opt = soptim.RMSprop(qs, lr=5e-5)
         else:
-            ref = torch.optim.Adam(ps, lr=5e-5, betas=(0, 0.9))
+            ref = torch.optim.Adam(ps, lr=5e-5, betas=(0.0, 0.9))
             opt = soptim.Adam(qs, lr=5e-5, betas=(0, 0.9))
         for it in range(3):
             for i, (p, q) in enumerate(zip(ps, qs)):

@@ -159,21 +159,39 @@ def test_default_segan_plus_step_matches_reference(segan_plus_b2):
     assert mse < 1e-4          # the north-star bar
     assert mse < 1e-10         # what exact fp32 actually gives
     assert (y.cpu() - fx['Genh']).abs().max().item() < 1e-5
+    g0 = {k: v.detach().cpu().clone() for k, v in m.G.state_dict().items()}
     (d_real_loss, d_fake_loss, g_adv, g_l1), Gopt, Dopt = run_step(m, fx, clean, noisy, z)
     for got, key in ((d_real_loss, 'd_real_loss'), (d_fake_loss, 'd_fake_loss'),
                      (g_adv, 'g_adv_loss'), (g_l1, 'g_l1_loss')):
         assert max_rel(got, fx[key]) < ACT_TOL, key
     dn, gn = dict(m.D.named_parameters()), dict(m.G.named_parameters())
+    # (1) discriminator-phase gradients against the reference: strict
     for k, c in fx['d_grads'].items():
         if not k.endswith('conv.bias'):
             _chk(dn[k].grad, c, GRAD_TOL)
-    for k, c in fx['g_grads'].items():
-        _chk(gn[k].grad, c, GRAD_TOL)
-    for k, v in fx['small_g_grads'].items():
-        assert max_rel(gn[k].grad, v) < GRAD_TOL, k
     for k, v in fx['small_d_grads'].items():
         if not k.endswith('conv.bias'):
             assert max_rel(dn[k].grad, v) < GRAD_TOL, k
+    # (2) generator-phase gradients against the reference.  They are taken through the
+    # discriminator AFTER its RMSprop step, whose first update lr*g/(0.1|g|+1e-8) is
+    # ill-conditioned wherever |g| is at roundoff level (at B=2 a sizeable share of D's
+    # 25.8 M weights): two correct fp32 implementations end up with post-step weights that
+    # differ by up to a full step (5e-4) on those elements, and the generator gradient
+    # inherits ~1e-3 of that.  Loose bound here, strict bound in (3).
+    for k, c in fx['g_grads'].items():
+        _chk(gn[k].grad, c, 1e-2)
+    # (3) strict: the same generator-phase gradients against the CPU oracle evaluated with
+    # the discriminator weights the GPU actually stepped to.
+    import torch.nn.functional as F
+    d_after = {k: v.detach().cpu().clone() for k, v in m.D.state_dict().items()}
+    G = {k: v.clone().requires_grad_(True) for k, v in g0.items()}
+    st = fx['opts']['genc_poolings']
+    genh = O.generator_forward(G, noisy, z, st)
+    d = O.discriminator_forward(d_after, torch.cat((genh, noisy), 1), fx['rolls'][2], st)
+    loss = F.mse_loss(d.view(-1), torch.ones(2)) + 100.0 * F.l1_loss(genh, clean)
+    keys = list(G.keys())
+    for k, g in zip(keys, torch.autograd.grad(loss, [G[k] for k in keys])):
+        assert max_rel(gn[k].grad, g) < GRAD_TOL, k
 
 
 def test_generator_full_batch_is_per_sample_independent():
