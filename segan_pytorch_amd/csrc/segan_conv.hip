@@ -20,6 +20,7 @@
 // BatchNorm-normalise and PReLU are all applied while the tile is staged
 // (segan_src), so none of those tensors is ever materialised in HBM.
 #include "segan_common.h"
+#include <stdlib.h>
 
 #define KCH 64  // contraction elements per LDS chunk (= 32 MFMA k-steps of 2)
 
@@ -62,7 +63,7 @@ __device__ __forceinline__ void lds_pos_decode(const ColTile& ct, int j, int Tco
 // ====================================================================================
 struct CorrArgs {
   segan_src in;
-  const float* wp;  // packed weights [Ktot][RP]
+  const float* wp;  // packed weights [KtotP][RP] (zero padded: no guards on the loads)
   float* out0;
   float* out1;
   const float* bias;
@@ -78,18 +79,22 @@ struct CorrArgs {
   int o_padL, o_roll, o_padR;  // HI store (conv dgrad: reflect halo)
 };
 
-template <int MB, int NB, int U, bool IN_HI, bool OUT_HI>
+// Staging discipline (both kernels): load_chunk() only ISSUES global loads — every
+// address is clamped to a valid element, so there is no branch and no wait between
+// them and they stay in flight under the MFMA loop; masking, the segan_src transform
+// and the LDS writes happen in store_chunk(), after the compute of the previous chunk.
+template <int MB, int NB, int U, bool IN_HI, bool OUT_HI, int MAXPOS, int KC>
 __global__ __launch_bounds__(256, 2) void corr_kernel(const CorrArgs a) {
   constexpr int S = 32 / U;
-  constexpr int CV = KCH / U;  // virtual channels per chunk
+  constexpr int SI = IN_HI ? S : 1;   // indices per staged position
+  constexpr int CV = KC / U;          // virtual channels per chunk
   constexpr int NI = MB / 64;
   constexpr int NJ = NB / 64;
-  constexpr int MAXPOS = 2;  // RLs <= 512
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int RLs = a.RLs;
-  float* Wl0 = smem;                  // [2][KCH*MB]
-  float* Il0 = smem + 2 * KCH * MB;   // [2][CV*RLs]
+  float* Wl0 = smem;                  // [2][KC*MB]
+  float* Il0 = smem + 2 * KC * MB;   // [2][CV*RLs]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -108,27 +113,36 @@ __global__ __launch_bounds__(256, 2) void corr_kernel(const CorrArgs a) {
   const ColTile ct = make_coltile(coltile * NB, a.Tcols, NB);
 
   // ---- per-thread staging positions of the activation tile (fixed for all chunks) ----
-  int pos_b[MAXPOS];
-  int pos_idx[MAXPOS][S];
+  // pos_off: element offset inside a channel row (clamped to 0 when masked)
+  // pos_bo0/1: element offset of the sample inside segment 0 / 1
+  int pos_off[MAXPOS][SI];
+  unsigned pos_ok[MAXPOS];
+  int pos_bo0[MAXPOS], pos_bo1[MAXPOS];
 #pragma unroll
   for (int pp = 0; pp < MAXPOS; ++pp) {
     const int j = tid + 256 * pp;
-    pos_b[pp] = -1;
+    pos_ok[pp] = 0u;
+    pos_bo0[pp] = 0;
+    pos_bo1[pp] = 0;
 #pragma unroll
-    for (int r = 0; r < S; ++r) pos_idx[pp][r] = -1;
+    for (int r = 0; r < SI; ++r) pos_off[pp][r] = 0;
     if (j < RLs) {
       int s, tau;
       lds_pos_decode(ct, j, a.Tcols, a.H, s, tau);
       const int b = ct.b0 + s;
       if (b < a.B) {
-        pos_b[pp] = b;
+        pos_bo0[pp] = b * a.in.C0 * a.Lin;
+        pos_bo1[pp] = b * a.in.C1 * a.Lin;
         const int wq = tau + a.win_start;
         if (IN_HI) {
 #pragma unroll
-          for (int r = 0; r < S; ++r)
-            pos_idx[pp][r] = segan_hi_index(S * wq + r, a.Lin, a.padL, a.mode, a.roll);
-        } else {
-          pos_idx[pp][0] = (wq >= 0 && wq < a.Lin) ? wq : -1;
+          for (int r = 0; r < SI; ++r) {
+            const int idx = segan_hi_index(S * wq + r, a.Lin, a.padL, a.mode, a.roll);
+            if (idx >= 0) { pos_off[pp][r] = idx; pos_ok[pp] |= 1u << r; }
+          }
+        } else if (wq >= 0 && wq < a.Lin) {
+          pos_off[pp][0] = wq;
+          pos_ok[pp] = 1u;
         }
       }
     }
@@ -174,96 +188,98 @@ __global__ __launch_bounds__(256, 2) void corr_kernel(const CorrArgs a) {
   // ---- staging registers ----
   constexpr int F4R = MB / 4;        // float4 per weight row
   constexpr int RPP = 256 / F4R;     // rows per pass
-  constexpr int NPASS = KCH / RPP;
-  float4 wreg[NPASS];
+  constexpr int NPASS = KC / RPP;
+  f32x4 wreg[NPASS];
   float ireg[CV][MAXPOS];
   const int wrow = tid / F4R, wc4 = tid % F4R;
+  const float* wbase = a.wp + (size_t)wrow * a.RP + m0 + 4 * wc4;
 
   auto load_chunk = [&](int ch) {
-    const int kbase = ch * KCH;
+    const float* wsrc = wbase + (size_t)(ch * KC) * a.RP;
 #pragma unroll
-    for (int p = 0; p < NPASS; ++p) {
-      const int gk = kbase + wrow + RPP * p;
-      const int gm = m0 + 4 * wc4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (gk < a.Ktot && gm < a.RP)
-        v = *reinterpret_cast<const float4*>(a.wp + (size_t)gk * a.RP + gm);
-      wreg[p] = v;
+    for (int p = 0; p < NPASS; ++p)
+      wreg[p] = *reinterpret_cast<const f32x4*>(wsrc + (size_t)(RPP * p) * a.RP);
+#pragma unroll
+    for (int c = 0; c < CV; ++c) {
+      int cv = ch * CV + c;
+      cv = cv < a.Cv ? cv : 0;
+      const int n = IN_HI ? cv / S : cv;
+      const int r = IN_HI ? c % S : 0;  // CV is a multiple of S
+      const bool seg1 = n >= a.in.C0;
+      const float* rowp = seg1 ? a.in.p1 + (size_t)(n - a.in.C0) * a.Lin
+                               : a.in.p0 + (size_t)n * a.Lin;
+#pragma unroll
+      for (int pp = 0; pp < MAXPOS; ++pp)
+        ireg[c][pp] = rowp[(seg1 ? pos_bo1[pp] : pos_bo0[pp]) + pos_off[pp][r]];
     }
+  };
+  auto store_chunk = [&](int ch, int buf) {
+    float* Wl = Wl0 + buf * (KC * MB);
+    float* Il = Il0 + buf * (CV * RLs);
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p)
+      *reinterpret_cast<f32x4*>(Wl + (wrow + RPP * p) * MB + 4 * wc4) = wreg[p];
 #pragma unroll
     for (int c = 0; c < CV; ++c) {
       const int cv = ch * CV + c;
-      const int n = IN_HI ? cv / S : cv;
-      const int r = IN_HI ? c % S : 0;  // CV is a multiple of S
       const bool cvalid = cv < a.Cv;
+      const int n = IN_HI ? cv / S : cv;
+      const int r = IN_HI ? c % S : 0;
       ChanXf xf;
       xf.sc = 1.f; xf.sh = 0.f; xf.sl = 1.f; xf.has_sl = false;
       if (cvalid) xf = segan_chan_xf(a.in, n);
 #pragma unroll
       for (int pp = 0; pp < MAXPOS; ++pp) {
-        float v = 0.0f;
-        const int idx = pos_idx[pp][r];
-        if (cvalid && pos_b[pp] >= 0 && idx >= 0) {
-          const float* row = segan_src_row(a.in, pos_b[pp], n, a.Lin);
-          v = segan_apply_xf(xf, row[idx]);
-        }
-        ireg[c][pp] = v;
+        const int j = tid + 256 * pp;
+        const bool ok = cvalid && ((pos_ok[pp] >> r) & 1u);
+        const float v = ok ? segan_apply_xf(xf, ireg[c][pp]) : 0.0f;
+        if (j < RLs) Il[c * RLs + j] = v;
       }
     }
   };
-  auto store_chunk = [&](int buf) {
-    float* Wl = Wl0 + buf * (KCH * MB);
-    float* Il = Il0 + buf * (CV * RLs);
-#pragma unroll
-    for (int p = 0; p < NPASS; ++p)
-      *reinterpret_cast<float4*>(Wl + (wrow + RPP * p) * MB + 4 * wc4) = wreg[p];
-#pragma unroll
-    for (int c = 0; c < CV; ++c)
-#pragma unroll
-      for (int pp = 0; pp < MAXPOS; ++pp) {
-        const int j = tid + 256 * pp;
-        if (j < RLs) Il[c * RLs + j] = ireg[c][pp];
-      }
-  };
 
-  const int nch = (a.Ktot + KCH - 1) / KCH;
+  const int nch = (a.Ktot + KC - 1) / KC;
   load_chunk(0);
-  store_chunk(0);
+  store_chunk(0, 0);
   __syncthreads();
   for (int ch = 0; ch < nch; ++ch) {
     const int buf = ch & 1;
     if (ch + 1 < nch) load_chunk(ch + 1);
-    const float* Wl = Wl0 + buf * (KCH * MB);
+    const float* Wl = Wl0 + buf * (KC * MB);
     const float* Il = Il0 + buf * (CV * RLs);
-#pragma unroll
-    for (int s = 0; s < KCH / 2; ++s) {
+    // operands of step s+1 are read from LDS before the MFMAs of step s are issued
+    // (two named register sets; everything is unrolled so all indices are static)
+    constexpr int NBI = OUT_HI ? NI : 1;
+    float av0[NI], av1[NI], bv0[NBI][NJ], bv1[NBI][NJ];
+    auto read_step = [&](int s, float (&av)[NI], float (&bv)[NBI][NJ]) {
       const int kk = 2 * s;
       const int c = kk / U, u = kk % U;
       const float* wr = Wl + kk * MB;
       const float* ir = Il + c * RLs + u;
-      float av[NI];
 #pragma unroll
       for (int i = 0; i < NI; ++i) av[i] = wr[aoff[i]];
-      if (OUT_HI) {
 #pragma unroll
-        for (int i = 0; i < NI; ++i)
+      for (int i = 0; i < NBI; ++i)
 #pragma unroll
-          for (int j = 0; j < NJ; ++j) {
-            const float bv = ir[boff[j] + rsh[i]];
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv, acc[i][j], 0, 0, 0);
-          }
-      } else {
-        float bv[NJ];
+        for (int j = 0; j < NJ; ++j) bv[i][j] = ir[boff[j] + (OUT_HI ? rsh[i] : 0)];
+    };
+    auto mma_step = [&](const float (&av)[NI], const float (&bv)[NBI][NJ]) {
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) bv[j] = ir[boff[j]];
+      for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int i = 0; i < NI; ++i)
+        for (int j = 0; j < NJ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[OUT_HI ? i : 0][j], acc[i][j],
+                                                           0, 0, 0);
+    };
+    read_step(0, av0, bv0);
 #pragma unroll
-          for (int j = 0; j < NJ; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
-      }
+    for (int s = 0; s < KC / 2; s += 2) {
+      read_step(s + 1, av1, bv1);
+      mma_step(av0, bv0);
+      if (s + 2 < KC / 2) read_step(s + 2, av0, bv0);
+      mma_step(av1, bv1);
     }
-    if (ch + 1 < nch) store_chunk(buf ^ 1);
+    if (ch + 1 < nch) store_chunk(ch + 1, buf ^ 1);
     __syncthreads();
   }
 
@@ -338,26 +354,49 @@ __global__ void fold_halo_kernel(float* dx, const float* halo, int rows, int L, 
   }
 }
 
-template <int MB, int U, bool IN_HI, bool OUT_HI>
+// packed-weight geometry (shared by the pack kernels and the launchers)
+static inline int f_pitch(int M) { return M <= 64 ? 64 : round_up(M, 128); }
+static inline int f_rows(int N) { return round_up(N * 32, KCH); }
+static inline int t_pitch(int N, int S) {
+  const int r = S * round_up(N, 32);
+  return r <= 64 ? 64 : round_up(r, 128);
+}
+static inline int t_rows(int M, int S) { return round_up(M * (32 / S), KCH); }
+
+template <int MB, int U, bool IN_HI, bool OUT_HI, int MAXPOS, int KC = KCH>
 static int launch_corr_t(const CorrArgs& a, hipStream_t st) {
   constexpr int NB = 128;
-  constexpr int CV = KCH / U;
+  constexpr int CV = KC / U;
   const int nrowtiles = ceil_div(a.Rvalid, MB);
-  const size_t lds = (size_t)(2 * KCH * MB + 2 * CV * a.RLs) * sizeof(float);
+  const size_t lds = (size_t)(2 * KC * MB + 2 * CV * a.RLs) * sizeof(float);
   if (lds > 160 * 1024) {
     segan_set_error("corr: LDS tile %zu B too large (RLs=%d)", lds, a.RLs);
     return SEGAN_EUNSUPPORTED;
   }
-  auto kern = corr_kernel<MB, NB, U, IN_HI, OUT_HI>;
+  auto kern = corr_kernel<MB, NB, U, IN_HI, OUT_HI, MAXPOS, KC>;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
   dim3 grid((unsigned)(nrowtiles * a.ncoltiles));
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
   return segan_check_launch("corr_kernel");
+}
+
+template <int U, bool IN_HI, bool OUT_HI>
+static int launch_corr_u(const CorrArgs& a, hipStream_t st) {
+  const bool small = a.Rvalid <= 64;
+  static const int kc_env = [] { const char* e = getenv("SEGAN_CORR_KC"); return e ? atoi(e) : 0; }();
+  if (a.RLs <= 256) {
+    if (!small && kc_env == 32 && U <= 16)
+      return launch_corr_t<128, U, IN_HI, OUT_HI, 1, 32>(a, st);
+    return small ? launch_corr_t<64, U, IN_HI, OUT_HI, 1>(a, st)
+                 : launch_corr_t<128, U, IN_HI, OUT_HI, 1>(a, st);
+  }
+  return small ? launch_corr_t<64, U, IN_HI, OUT_HI, 2>(a, st)
+               : launch_corr_t<128, U, IN_HI, OUT_HI, 2>(a, st);
 }
 
 template <bool IN_HI, bool OUT_HI>
@@ -374,17 +413,15 @@ static int launch_corr(CorrArgs& a, int U, hipStream_t st) {
                     a.RLs);
     return SEGAN_EUNSUPPORTED;
   }
-  const bool small = a.Rvalid <= 64;
+  const long in_elems = (long)a.B * (a.in.C0 + a.in.C1) * a.Lin;
+  if (in_elems >= (1L << 31)) {
+    segan_set_error("corr: input of %ld elements exceeds the 2^31 indexing limit", in_elems);
+    return SEGAN_EUNSUPPORTED;
+  }
   switch (U) {
-    case 8:
-      return small ? launch_corr_t<64, 8, IN_HI, OUT_HI>(a, st)
-                   : launch_corr_t<128, 8, IN_HI, OUT_HI>(a, st);
-    case 16:
-      return small ? launch_corr_t<64, 16, IN_HI, OUT_HI>(a, st)
-                   : launch_corr_t<128, 16, IN_HI, OUT_HI>(a, st);
-    case 32:
-      return small ? launch_corr_t<64, 32, IN_HI, OUT_HI>(a, st)
-                   : launch_corr_t<128, 32, IN_HI, OUT_HI>(a, st);
+    case 8: return launch_corr_u<8, IN_HI, OUT_HI>(a, st);
+    case 16: return launch_corr_u<16, IN_HI, OUT_HI>(a, st);
+    case 32: return launch_corr_u<32, IN_HI, OUT_HI>(a, st);
   }
   segan_set_error("corr: unsupported stride (U=%d)", U);
   return SEGAN_EUNSUPPORTED;
@@ -451,63 +488,64 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
   // A staging: thread owns 4 consecutive columns (one float4; Ls % 4 == 0 keeps them in
-  // one sample) of rows tid/16 + 16*i
+  // one sample) of rows tid/16 + 16*i.  Loads are unconditional (clamped addresses) and
+  // masked / transformed when they are written to LDS.
   const int kc4 = tid & 15, ar0 = tid >> 4;
-  float4 areg[MB / 16];
+  f32x4 areg[MB / 16];
   float breg[CVW];
   int posreg = 0;
+  bool a_ok = false;
+  unsigned b_ok = 0u;
 
   auto load_chunk = [&](int ch) {
     const int col0 = split_beg + ch * TK;
     // ---- A: lo[m][col] ----
     {
       const int col = col0 + 4 * kc4;
-      const bool cok = col < split_end;
-      int b = 0, t = 0;
-      if (cok) { b = col / a.Ls; t = col - b * a.Ls; }
+      a_ok = col < split_end;
+      const int colc = a_ok ? col : 0;
+      const int b = colc / a.Ls;
+      const int t = colc - b * a.Ls;
+      const int bo0 = b * a.lo.C0 * a.Ls + t, bo1 = b * a.lo.C1 * a.Ls + t;
 #pragma unroll
       for (int i = 0; i < MB / 16; ++i) {
-        const int m = m0 + ar0 + 16 * i;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (cok && m < a.M) {
-          const ChanXf xf = segan_chan_xf(a.lo, m);
-          v = *reinterpret_cast<const float4*>(segan_src_row(a.lo, b, m, a.Ls) + t);
-          v.x = segan_apply_xf(xf, v.x);
-          v.y = segan_apply_xf(xf, v.y);
-          v.z = segan_apply_xf(xf, v.z);
-          v.w = segan_apply_xf(xf, v.w);
-        }
-        areg[i] = v;
+        int m = m0 + ar0 + 16 * i;
+        m = m < a.M ? m : 0;
+        const bool seg1 = m >= a.lo.C0;
+        const float* rowp = seg1 ? a.lo.p1 + (size_t)(m - a.lo.C0) * a.Ls + bo1
+                                 : a.lo.p0 + (size_t)m * a.Ls + bo0;
+        areg[i] = *reinterpret_cast<const f32x4*>(rowp);
       }
     }
     // ---- B: hi phases (RLw <= 256: one position per thread) ----
     const ColTile ct = make_coltile(col0, a.Ls, TK);
-    int pb = -1, pidx[S];
+    int pbo0 = 0, pbo1 = 0, poff[S];
+    b_ok = 0u;
 #pragma unroll
-    for (int r = 0; r < S; ++r) pidx[r] = -1;
+    for (int r = 0; r < S; ++r) poff[r] = 0;
     if (tid < RLw) {
       int s, tau;
       lds_pos_decode(ct, tid, a.Ls, a.H, s, tau);
       const int b = ct.b0 + s;
       if (b < a.B) {
-        pb = b;
+        pbo0 = b * a.hi.C0 * a.Lhi;
+        pbo1 = b * a.hi.C1 * a.Lhi;
 #pragma unroll
-        for (int r = 0; r < S; ++r)
-          pidx[r] = segan_hi_index(S * tau + r, a.Lhi, a.padL, a.mode, a.roll);
+        for (int r = 0; r < S; ++r) {
+          const int idx = segan_hi_index(S * tau + r, a.Lhi, a.padL, a.mode, a.roll);
+          if (idx >= 0) { poff[r] = idx; b_ok |= 1u << r; }
+        }
       }
     }
 #pragma unroll
     for (int c = 0; c < CVW; ++c) {
-      const int cv = cv0 + c;
+      int cv = cv0 + c;
+      cv = cv < a.Cv ? cv : 0;
       const int n = cv / S, r = c % S;  // cv0 is a multiple of S
-      const bool cvalid = cv < a.Cv;
-      float v = 0.0f;
-      const int idx = pidx[r];
-      if (cvalid && pb >= 0 && idx >= 0) {
-        const ChanXf xf = segan_chan_xf(a.hi, n);
-        v = segan_apply_xf(xf, segan_src_row(a.hi, pb, n, a.Lhi)[idx]);
-      }
-      breg[c] = v;
+      const bool seg1 = n >= a.hi.C0;
+      const float* rowp = seg1 ? a.hi.p1 + (size_t)(n - a.hi.C0) * a.Lhi + pbo1
+                               : a.hi.p0 + (size_t)n * a.Lhi + pbo0;
+      breg[c] = rowp[poff[r]];
     }
     // position table for the contraction columns of this chunk
     if (tid < TK) {
@@ -519,12 +557,30 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
   auto store_chunk = [&]() {
 #pragma unroll
     for (int i = 0; i < MB / 16; ++i) {
+      const int m = m0 + ar0 + 16 * i;
+      float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+      if (a_ok && m < a.M) {
+        const ChanXf xf = segan_chan_xf(a.lo, m);
+        v0 = segan_apply_xf(xf, areg[i][0]);
+        v1 = segan_apply_xf(xf, areg[i][1]);
+        v2 = segan_apply_xf(xf, areg[i][2]);
+        v3 = segan_apply_xf(xf, areg[i][3]);
+      }
       float* d = Al + (ar0 + 16 * i) * AST + 4 * kc4;
-      d[0] = areg[i].x; d[1] = areg[i].y; d[2] = areg[i].z; d[3] = areg[i].w;
+      d[0] = v0; d[1] = v1; d[2] = v2; d[3] = v3;
     }
     if (tid < RLw) {
 #pragma unroll
-      for (int c = 0; c < CVW; ++c) Bl[c * RLw + tid] = breg[c];
+      for (int c = 0; c < CVW; ++c) {
+        const int cv = cv0 + c;
+        const int n = cv / S, r = c % S;
+        float v = 0.0f;
+        if (cv < a.Cv && ((b_ok >> r) & 1u)) {
+          const ChanXf xf = segan_chan_xf(a.hi, n);
+          v = segan_apply_xf(xf, breg[c]);
+        }
+        Bl[c * RLw + tid] = v;
+      }
     }
     if (tid < TK) posT[tid] = posreg;
   };
@@ -534,20 +590,29 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
   __syncthreads();
   for (int ch = 0; ch < nch; ++ch) {
     if (ch + 1 < nch) load_chunk(ch + 1);
-#pragma unroll
-    for (int s = 0; s < TK / 2; ++s) {
+    float av0[2], av1[2], bv0[2], bv1[2];
+    auto read_step = [&](int s, float (&av)[2], float (&bv)[2]) {
       const int kk = 2 * s;
       const int pz = posT[kk + h];
-      float av[2], bv[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) av[i] = Al[aoff[i] + kk];
 #pragma unroll
       for (int j = 0; j < 2; ++j) bv[j] = Bl[bch[j] + pz + bu[j]];
+    };
+    auto mma_step = [&](const float (&av)[2], const float (&bv)[2]) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+    };
+    read_step(0, av0, bv0);
+#pragma unroll
+    for (int s = 0; s < TK / 2; s += 2) {
+      read_step(s + 1, av1, bv1);
+      mma_step(av0, bv0);
+      if (s + 2 < TK / 2) read_step(s + 2, av0, bv0);
+      mma_step(av1, bv1);
     }
     __syncthreads();
     if (ch + 1 < nch) {
@@ -589,6 +654,10 @@ static int launch_wgrad_t(WgradArgs& a, hipStream_t st) {
                     "and >= %d)", a.Ls, 32 / U, U / 2);
     return SEGAN_EUNSUPPORTED;
   }
+  if ((long)a.B * a.M * a.Ls >= (1L << 31) || (long)a.B * a.N * a.Lhi >= (1L << 31)) {
+    segan_set_error("wgrad: operand exceeds the 2^31 element indexing limit");
+    return SEGAN_EUNSUPPORTED;
+  }
   const int ncol = ceil_div(a.Cv, CVW);
   const int nrow = ceil_div(a.M, 128);
   // split the (b,t) contraction so the grid has ~2 waves of workgroups
@@ -616,38 +685,39 @@ static int launch_wgrad_t(WgradArgs& a, hipStream_t st) {
 // weight packing
 // ====================================================================================
 __global__ void pack_f_kernel(const float* __restrict__ w, float* __restrict__ wf, int M, int N,
-                              int K, int S, int U, int MP) {
-  const size_t total = (size_t)N * S * U * MP;
+                              int K, int S, int U, int pitch, int rows) {
+  const size_t total = (size_t)rows * pitch;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
        i += (size_t)gridDim.x * blockDim.x) {
-    const int m = (int)(i % MP);
-    size_t t = i / MP;
+    const int m = (int)(i % pitch);
+    size_t t = i / pitch;          // row = (n*S + r)*U + u
     const int u = (int)(t % U);
     t /= U;
     const int r = (int)(t % S);
     const int n = (int)(t / S);
     const int k = S * u + r;
     float v = 0.0f;
-    if (m < M && k < K) v = w[((size_t)m * N + n) * K + k];
+    if (m < M && n < N && k < K) v = w[((size_t)m * N + n) * K + k];
     wf[i] = v;
   }
 }
 
 __global__ void pack_t_kernel(const float* __restrict__ w, float* __restrict__ wt, int M, int N,
-                              int K, int S, int U, int NP, int pad) {
-  const int RP = S * NP;
-  const size_t total = (size_t)M * U * RP;
+                              int K, int S, int U, int NP, int pad, int pitch, int rows) {
+  const size_t total = (size_t)rows * pitch;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
        i += (size_t)gridDim.x * blockDim.x) {
-    const int col = (int)(i % RP);
-    size_t t = i / RP;
+    const int col = (int)(i % pitch);
+    size_t t = i / pitch;          // row = m*U + u'
     const int up = (int)(t % U);
     const int m = (int)(t / U);
     const int r = col / NP, n = col % NP;
-    const int rho = (r + pad) % S;
-    const int k = S * (U - 1 - up) + rho;
     float v = 0.0f;
-    if (n < N && k < K) v = w[((size_t)m * N + n) * K + k];
+    if (r < S && m < M && n < N) {
+      const int rho = (r + pad) % S;
+      const int k = S * (U - 1 - up) + rho;
+      if (k < K) v = w[((size_t)m * N + n) * K + k];
+    }
     wt[i] = v;
   }
 }
@@ -659,11 +729,11 @@ static bool stride_ok(int S) { return S == 1 || S == 2 || S == 4; }
 
 extern "C" size_t segan_packed_f_bytes(int M, int N, int S) {
   if (!stride_ok(S) || M <= 0 || N <= 0) return 0;
-  return (size_t)N * 32 * round_up(M, 32) * sizeof(float);
+  return (size_t)f_rows(N) * f_pitch(M) * sizeof(float);
 }
 extern "C" size_t segan_packed_t_bytes(int M, int N, int S) {
   if (!stride_ok(S) || M <= 0 || N <= 0) return 0;
-  return (size_t)M * (32 / S) * S * round_up(N, 32) * sizeof(float);
+  return (size_t)t_rows(M, S) * t_pitch(N, S) * sizeof(float);
 }
 
 extern "C" int segan_pack_weights(const float* w, float* wf, float* wt, int M, int N, int K, int S,
@@ -676,17 +746,19 @@ extern "C" int segan_pack_weights(const float* w, float* wf, float* wt, int M, i
   hipStream_t st = (hipStream_t)stream;
   const int U = 32 / S;
   if (wf) {
-    const int MP = round_up(M, 32);
-    const size_t total = (size_t)N * 32 * MP;
+    const int pitch = f_pitch(M), rows = f_rows(N);
+    const size_t total = (size_t)rows * pitch;
     const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
-    hipLaunchKernelGGL(pack_f_kernel, dim3(blocks), dim3(256), 0, st, w, wf, M, N, K, S, U, MP);
+    hipLaunchKernelGGL(pack_f_kernel, dim3(blocks), dim3(256), 0, st, w, wf, M, N, K, S, U, pitch,
+                       rows);
   }
   if (wt) {
     const int NP = round_up(N, 32);
-    const size_t total = (size_t)M * U * S * NP;
+    const int pitch = t_pitch(N, S), rows = t_rows(M, S);
+    const size_t total = (size_t)rows * pitch;
     const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
     hipLaunchKernelGGL(pack_t_kernel, dim3(blocks), dim3(256), 0, st, w, wt, M, N, K, S, U, NP,
-                       pad_t);
+                       pad_t, pitch, rows);
   }
   return segan_check_launch("pack_weights");
 }
@@ -717,7 +789,7 @@ extern "C" int segan_conv1d_fwd(const segan_src* x, const float* wf, const float
   a.in = *x;
   a.wp = wf;
   a.out0 = out; a.out1 = nullptr; a.bias = bias; a.halo = nullptr;
-  a.B = B; a.Cv = N * S; a.Ktot = N * 32; a.RP = round_up(M, 32); a.Rvalid = M;
+  a.B = B; a.Cv = N * S; a.Ktot = N * 32; a.RP = f_pitch(M); a.Rvalid = M;
   a.Tcols = L / S; a.Ctot = B * a.Tcols;
   a.Lin = L; a.padL = padL; a.mode = mode; a.roll = roll;
   a.win_start = 0; a.H = U - 1;
@@ -741,7 +813,7 @@ extern "C" int segan_deconv1d_dgrad(const float* dy, const float* wf, float* dx0
   a.in.scale = a.in.shift = a.in.slope = nullptr;
   a.wp = wf;
   a.bias = nullptr; a.halo = nullptr;
-  a.B = B; a.Cv = N * S; a.Ktot = N * 32; a.RP = round_up(M, 32); a.Rvalid = M;
+  a.B = B; a.Cv = N * S; a.Ktot = N * 32; a.RP = f_pitch(M); a.Rvalid = M;
   a.Tcols = Ls; a.Ctot = B * Ls;
   a.Lin = S * Ls; a.padL = pad; a.mode = SEGAN_PAD_ZERO; a.roll = 0;
   a.win_start = 0; a.H = U - 1;
@@ -769,7 +841,7 @@ extern "C" int segan_deconv1d_fwd(const segan_src* x, const float* wt, const flo
   a.wp = wt;
   a.out0 = y; a.out1 = nullptr; a.bias = bias; a.halo = nullptr;
   a.NP = round_up(N, 32); a.Nout = N;
-  a.B = B; a.Cv = M; a.Ktot = M * U; a.RP = S * a.NP; a.Rvalid = S * a.NP;
+  a.B = B; a.Cv = M; a.Ktot = M * U; a.RP = t_pitch(N, S); a.Rvalid = S * a.NP;
   a.Tcols = Ls; a.Ctot = B * Ls;
   a.Lin = Ls; a.padL = 0; a.mode = SEGAN_PAD_ZERO; a.roll = 0;
   int cmin = 1 << 30, cmax = 0;
@@ -805,7 +877,7 @@ extern "C" int segan_conv1d_dgrad(const float* da, const float* wt, float* dx, f
   a.wp = wt;
   a.out0 = dx; a.out1 = nullptr; a.bias = nullptr; a.halo = halo;
   a.NP = round_up(N, 32); a.Nout = N;
-  a.B = B; a.Cv = M; a.Ktot = M * U; a.RP = S * a.NP; a.Rvalid = S * a.NP;
+  a.B = B; a.Cv = M; a.Ktot = M * U; a.RP = t_pitch(N, S); a.Rvalid = S * a.NP;
   // padded coordinates P = S*q + r in [0, L + padL + padR)
   a.Tcols = (L + padL + padR - 1) / S + 1;
   a.Ctot = B * a.Tcols;
