@@ -22,3 +22,46 @@ int segan_check_launch(const char* what) {
 
 extern "C" int segan_abi_version(void) { return SEGAN_ABI_VERSION; }
 extern "C" const char* segan_last_error(void) { return g_err; }
+
+// ---- default transform vectors (ones / zeros) for NULL segan_src members -----------------
+__device__ float g_xf_ones[SEGAN_MAX_XF_CH];
+__device__ float g_xf_zeros[SEGAN_MAX_XF_CH];
+
+__global__ void xf_defaults_init_kernel() {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < SEGAN_MAX_XF_CH;
+       i += gridDim.x * blockDim.x) {
+    g_xf_ones[i] = 1.0f;
+    g_xf_zeros[i] = 0.0f;
+  }
+}
+
+int segan_src_defaults(segan_src* s, hipStream_t st, const char* what) {
+  if (s->scale && s->shift && s->slope) return SEGAN_OK;
+  static float* ones = nullptr;
+  static float* zeros = nullptr;
+  if (!ones) {
+    void *po = nullptr, *pz = nullptr;
+    if (hipGetSymbolAddress(&po, HIP_SYMBOL(g_xf_ones)) != hipSuccess ||
+        hipGetSymbolAddress(&pz, HIP_SYMBOL(g_xf_zeros)) != hipSuccess) {
+      segan_set_error("%s: cannot resolve the default transform vectors", what);
+      return SEGAN_ELAUNCH;
+    }
+    hipLaunchKernelGGL(xf_defaults_init_kernel, dim3(16), dim3(256), 0, st);
+    // make the constants visible to every stream before first use
+    if (hipStreamSynchronize(st) != hipSuccess) {
+      segan_set_error("%s: initialising the default transform vectors failed", what);
+      return SEGAN_ELAUNCH;
+    }
+    ones = (float*)po;
+    zeros = (float*)pz;
+  }
+  if (s->C0 + s->C1 > SEGAN_MAX_XF_CH) {
+    segan_set_error("%s: %d channels exceed the supported %d", what, s->C0 + s->C1,
+                    SEGAN_MAX_XF_CH);
+    return SEGAN_EUNSUPPORTED;
+  }
+  if (!s->scale) s->scale = ones;
+  if (!s->shift) s->shift = zeros;
+  if (!s->slope) s->slope = ones;
+  return SEGAN_OK;
+}

@@ -48,18 +48,20 @@ __host__ __device__ static inline int segan_hi_index(int p, int L, int padL, int
   return i;
 }
 
-// transform-on-load of a segan_src channel
+// transform-on-load of a segan_src channel.  The launchers replace NULL vectors by
+// device-resident ones / zeros (segan_src_defaults), so the kernels load the three
+// per-channel scalars unconditionally: no pointer tests, no branches in the staging code.
+#define SEGAN_MAX_XF_CH 16384
+
 struct ChanXf {
   float sc, sh, sl;
-  bool has_sl;
 };
 
 __device__ __forceinline__ ChanXf segan_chan_xf(const segan_src& s, int c) {
   ChanXf x;
-  x.sc = s.scale ? s.scale[c] : 1.0f;
-  x.sh = s.shift ? s.shift[c] : 0.0f;
-  x.has_sl = s.slope != nullptr;
-  x.sl = x.has_sl ? s.slope[c] : 1.0f;
+  x.sc = s.scale[c];
+  x.sh = s.shift[c];
+  x.sl = s.slope[c];
   return x;
 }
 
@@ -67,6 +69,9 @@ __device__ __forceinline__ float segan_apply_xf(const ChanXf& x, float v) {
   v = fmaf(v, x.sc, x.sh);
   return v > 0.0f ? v : v * x.sl;
 }
+
+// fills the NULL transform vectors of `s` with defaults; returns nonzero on error
+int segan_src_defaults(segan_src* s, hipStream_t st, const char* what);
 
 // row base pointer of logical channel n of sample b
 __device__ __forceinline__ const float* segan_src_row(const segan_src& s, int b, int n, int L) {

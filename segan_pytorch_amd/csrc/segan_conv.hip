@@ -225,9 +225,7 @@ __global__ __launch_bounds__(256, 2) void corr_kernel(const CorrArgs a) {
       const bool cvalid = cv < a.Cv;
       const int n = IN_HI ? cv / S : cv;
       const int r = IN_HI ? c % S : 0;
-      ChanXf xf;
-      xf.sc = 1.f; xf.sh = 0.f; xf.sl = 1.f; xf.has_sl = false;
-      if (cvalid) xf = segan_chan_xf(a.in, n);
+      const ChanXf xf = segan_chan_xf(a.in, cvalid ? n : 0);
 #pragma unroll
       for (int pp = 0; pp < MAXPOS; ++pp) {
         const int j = tid + 256 * pp;
@@ -387,10 +385,24 @@ static int launch_corr_t(const CorrArgs& a, hipStream_t st) {
 
 template <int U, bool IN_HI, bool OUT_HI>
 static int launch_corr_u(const CorrArgs& a, hipStream_t st) {
-  const bool small = a.Rvalid <= 64;
+  // Tile choice.  All workgroups of a launch do the same amount of work and up to 3 are
+  // resident per CU sharing its MFMA pipes, so the launch takes ceil(blocks / 256) block
+  // times; 64-row tiles (half the work each) are used when that quantisation is better
+  // (the deep layers: few, long tiles).  SEGAN_CORR_MB / SEGAN_CORR_KC override for tuning.
   static const int kc_env = [] { const char* e = getenv("SEGAN_CORR_KC"); return e ? atoi(e) : 0; }();
+  static const int mb_env = [] { const char* e = getenv("SEGAN_CORR_MB"); return e ? atoi(e) : 0; }();
+  bool small = a.Rvalid <= 64;
+  if (!small) {
+    const int nb128 = ceil_div(a.Rvalid, 128) * a.ncoltiles;
+    const int nb64 = ceil_div(a.Rvalid, 64) * a.ncoltiles;
+    const double t128 = (double)ceil_div(nb128, 256);
+    const double t64 = 0.5 * 1.06 * (double)ceil_div(nb64, 256);   // 6 % tile-size penalty
+    small = t64 < t128;
+    if (mb_env == 64) small = true;
+    if (mb_env == 128) small = false;
+  }
   if (a.RLs <= 256) {
-    if (!small && kc_env == 32 && U <= 16)
+    if (!small && kc_env != 64 && U <= 16)
       return launch_corr_t<128, U, IN_HI, OUT_HI, 1, 32>(a, st);
     return small ? launch_corr_t<64, U, IN_HI, OUT_HI, 1>(a, st)
                  : launch_corr_t<128, U, IN_HI, OUT_HI, 1>(a, st);
@@ -413,6 +425,7 @@ static int launch_corr(CorrArgs& a, int U, hipStream_t st) {
                     a.RLs);
     return SEGAN_EUNSUPPORTED;
   }
+  if (int e = segan_src_defaults(&a.in, st, "corr")) return e;
   const long in_elems = (long)a.B * (a.in.C0 + a.in.C1) * a.Lin;
   if (in_elems >= (1L << 31)) {
     segan_set_error("corr: input of %ld elements exceeds the 2^31 indexing limit", in_elems);
@@ -440,21 +453,21 @@ struct WgradArgs {
   int Ctot;               // B*Ls
   int cols_per_split;
   int H, RLw;
+  int ls_magic;           // ceil(65536 / Ls) when Ls < TK (sample index by multiply-shift)
 };
 
-template <int U>
+template <int U, int TK>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
   constexpr int S = 32 / U;
   constexpr int MB = 128;
-  constexpr int TK = KCH;            // contraction columns per chunk
   constexpr int CVW = 128 / U;       // virtual channels per block (128 output columns)
   constexpr int AST = TK + 1;        // padded A row stride
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int RLw = a.RLw;
-  float* Al = smem;                  // [MB][AST]
-  float* Bl = Al + MB * AST;         // [CVW][RLw]
-  int* posT = reinterpret_cast<int*>(Bl + CVW * RLw);  // [TK]
+  // double-buffered: [2][MB*AST] lo tile, [2][CVW*RLw] hi phases
+  float* Al0 = smem;
+  float* Bl0 = Al0 + 2 * MB * AST;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -490,11 +503,28 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
   // A staging: thread owns 4 consecutive columns (one float4; Ls % 4 == 0 keeps them in
   // one sample) of rows tid/16 + 16*i.  Loads are unconditional (clamped addresses) and
   // masked / transformed when they are written to LDS.
-  const int kc4 = tid & 15, ar0 = tid >> 4;
-  f32x4 areg[MB / 16];
+  constexpr int F4A = TK / 4;          // float4 per A row
+  constexpr int RPA = 256 / F4A;       // rows per pass
+  constexpr int NPA = MB / RPA;
+  const int kc4 = tid % F4A, ar0 = tid / F4A;
+  f32x4 areg[NPA];
   float breg[CVW];
-  int posreg = 0;
   bool a_ok = false;
+  // the rows / channels a thread stages never change: fetch their transforms once
+  ChanXf axf[NPA];
+  bool arow_ok[NPA];
+#pragma unroll
+  for (int i = 0; i < NPA; ++i) {
+    const int m = m0 + ar0 + RPA * i;
+    arow_ok[i] = m < a.M;
+    axf[i] = segan_chan_xf(a.lo, arow_ok[i] ? m : 0);
+  }
+  ChanXf bxf[CVW / S];
+#pragma unroll
+  for (int c = 0; c < CVW / S; ++c) {
+    const int n = cv0 / S + c;
+    bxf[c] = segan_chan_xf(a.hi, n < a.N ? n : 0);
+  }
   unsigned b_ok = 0u;
 
   auto load_chunk = [&](int ch) {
@@ -508,8 +538,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
       const int t = colc - b * a.Ls;
       const int bo0 = b * a.lo.C0 * a.Ls + t, bo1 = b * a.lo.C1 * a.Ls + t;
 #pragma unroll
-      for (int i = 0; i < MB / 16; ++i) {
-        int m = m0 + ar0 + 16 * i;
+      for (int i = 0; i < NPA; ++i) {
+        int m = m0 + ar0 + RPA * i;
         m = m < a.M ? m : 0;
         const bool seg1 = m >= a.lo.C0;
         const float* rowp = seg1 ? a.lo.p1 + (size_t)(m - a.lo.C0) * a.Ls + bo1
@@ -547,53 +577,48 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
                                : a.hi.p0 + (size_t)n * a.Lhi + pbo0;
       breg[c] = rowp[poff[r]];
     }
-    // position table for the contraction columns of this chunk
-    if (tid < TK) {
-      const int col = col0 + tid;
-      posreg = 0;
-      if (col < a.Ctot) posreg = tid + (col / a.Ls - ct.b0) * a.H;
-    }
   };
-  auto store_chunk = [&]() {
+  auto store_chunk = [&](int buf) {
+    float* Al = Al0 + buf * (MB * AST);
+    float* Bl = Bl0 + buf * (CVW * RLw);
 #pragma unroll
-    for (int i = 0; i < MB / 16; ++i) {
-      const int m = m0 + ar0 + 16 * i;
-      float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
-      if (a_ok && m < a.M) {
-        const ChanXf xf = segan_chan_xf(a.lo, m);
-        v0 = segan_apply_xf(xf, areg[i][0]);
-        v1 = segan_apply_xf(xf, areg[i][1]);
-        v2 = segan_apply_xf(xf, areg[i][2]);
-        v3 = segan_apply_xf(xf, areg[i][3]);
-      }
-      float* d = Al + (ar0 + 16 * i) * AST + 4 * kc4;
+    for (int i = 0; i < NPA; ++i) {
+      const bool ok = a_ok && arow_ok[i];
+      const float v0 = ok ? segan_apply_xf(axf[i], areg[i][0]) : 0.f;
+      const float v1 = ok ? segan_apply_xf(axf[i], areg[i][1]) : 0.f;
+      const float v2 = ok ? segan_apply_xf(axf[i], areg[i][2]) : 0.f;
+      const float v3 = ok ? segan_apply_xf(axf[i], areg[i][3]) : 0.f;
+      float* d = Al + (ar0 + RPA * i) * AST + 4 * kc4;
       d[0] = v0; d[1] = v1; d[2] = v2; d[3] = v3;
     }
     if (tid < RLw) {
 #pragma unroll
       for (int c = 0; c < CVW; ++c) {
         const int cv = cv0 + c;
-        const int n = cv / S, r = c % S;
-        float v = 0.0f;
-        if (cv < a.Cv && ((b_ok >> r) & 1u)) {
-          const ChanXf xf = segan_chan_xf(a.hi, n);
-          v = segan_apply_xf(xf, breg[c]);
-        }
-        Bl[c * RLw + tid] = v;
+        const int r = c % S;
+        const bool ok = cv < a.Cv && ((b_ok >> r) & 1u);
+        Bl[c * RLw + tid] = ok ? segan_apply_xf(bxf[c / S], breg[c]) : 0.0f;
       }
     }
-    if (tid < TK) posT[tid] = posreg;
   };
 
   load_chunk(0);
-  store_chunk();
+  store_chunk(0);
   __syncthreads();
   for (int ch = 0; ch < nch; ++ch) {
+    const int buf = ch & 1;
     if (ch + 1 < nch) load_chunk(ch + 1);
+    const float* Al = Al0 + buf * (MB * AST);
+    const float* Bl = Bl0 + buf * (CVW * RLw);
+    // LDS position of contraction column k' (sample s of the chunk sits s*H further):
+    // x = offset of the column from the start of the chunk's first sample
+    const int xh = (split_beg + ch * TK) % a.Ls + h;
     float av0[2], av1[2], bv0[2], bv1[2];
     auto read_step = [&](int s, float (&av)[2], float (&bv)[2]) {
       const int kk = 2 * s;
-      const int pz = posT[kk + h];
+      const int x = xh + kk;
+      const int sl = (a.Ls >= TK) ? (x >= a.Ls ? 1 : 0) : ((x * a.ls_magic) >> 16);
+      const int pz = kk + h + sl * a.H;
 #pragma unroll
       for (int i = 0; i < 2; ++i) av[i] = Al[aoff[i] + kk];
 #pragma unroll
@@ -614,11 +639,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
       if (s + 2 < TK / 2) read_step(s + 2, av0, bv0);
       mma_step(av1, bv1);
     }
+    if (ch + 1 < nch) store_chunk(buf ^ 1);
     __syncthreads();
-    if (ch + 1 < nch) {
-      store_chunk();
-      __syncthreads();
-    }
   }
 
   // ---- epilogue: dw[m][n][S*u + r] += acc ----
@@ -643,12 +665,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 template <int U>
 static int launch_wgrad_t(WgradArgs& a, hipStream_t st) {
   constexpr int CVW = 128 / U;
-  constexpr int TK = KCH;
+  constexpr int TK = 32;
   int NS;
   if (a.Ls >= TK) NS = (a.Ls % TK == 0) ? 1 : 2;
   else NS = (TK % a.Ls == 0) ? TK / a.Ls : (TK + a.Ls - 2) / a.Ls + 1;
   a.H = U - 1;
   a.RLw = TK + NS * a.H;
+  // row stride = 8 (mod 32): the 4 channels x 8 taps a half-wave reads hit 32 distinct banks
+  a.RLw += (8 - a.RLw % 32 + 32) % 32;
   if (a.RLw > 256 || a.Ls % 4 != 0) {
     segan_set_error("wgrad: low-rate length %d unsupported for stride %d (needs a multiple of 4, "
                     "and >= %d)", a.Ls, 32 / U, U / 2);
@@ -658,23 +682,27 @@ static int launch_wgrad_t(WgradArgs& a, hipStream_t st) {
     segan_set_error("wgrad: operand exceeds the 2^31 element indexing limit");
     return SEGAN_EUNSUPPORTED;
   }
+  if (int e = segan_src_defaults(&a.lo, st, "wgrad(lo)")) return e;
+  if (int e = segan_src_defaults(&a.hi, st, "wgrad(hi)")) return e;
   const int ncol = ceil_div(a.Cv, CVW);
   const int nrow = ceil_div(a.M, 128);
-  // split the (b,t) contraction so the grid has ~2 waves of workgroups
+  // split the (b,t) contraction so the grid has a few workgroups per CU
   const int tiles = ncol * nrow;
   const int chunks = ceil_div(a.Ctot, TK);
-  int nsplit = ceil_div(1024, tiles);
-  if (nsplit > chunks) nsplit = chunks;
+  static const int tgt_env = [] { const char* e = getenv("SEGAN_WGRAD_BLOCKS"); return e ? atoi(e) : 0; }();
+  int nsplit = ceil_div(tgt_env > 0 ? tgt_env : 1536, tiles);
+  if (nsplit > chunks / 4) nsplit = chunks / 4;   // at least 4 chunks per workgroup
   if (nsplit < 1) nsplit = 1;
   const int chunks_per = ceil_div(chunks, nsplit);
   nsplit = ceil_div(chunks, chunks_per);
   a.cols_per_split = chunks_per * TK;
-  const size_t lds = (size_t)(128 * (TK + 1) + CVW * a.RLw) * sizeof(float) + TK * sizeof(int);
-  auto kern = wgrad_kernel<U>;
+  const size_t lds = (size_t)(2 * 128 * (TK + 1) + 2 * CVW * a.RLw) * sizeof(float);
+  a.ls_magic = (65536 + a.Ls - 1) / a.Ls;
+  auto kern = wgrad_kernel<U, TK>;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
   hipLaunchKernelGGL(kern, dim3(ncol, nrow, nsplit), dim3(256), lds, st, a);

@@ -93,12 +93,17 @@ def deconv_pad(K, S):
 _weights_epoch = 0
 
 
-def bump_weights_epoch():
-    """Invalidate every WeightPack: call after weights were modified through raw
-    pointers (the fused optimizers, DP broadcast), which torch's version counter
-    cannot see."""
+def bump_weights_epoch(params=None):
+    """Invalidate packed weights after the weights were modified through raw pointers (the
+    fused optimizers, DP broadcast), which torch's version counter cannot see.  With
+    `params` only those tensors' packs are invalidated (an optimizer step must not force
+    the OTHER network to re-pack); without, every WeightPack is."""
     global _weights_epoch
-    _weights_epoch += 1
+    if params is None:
+        _weights_epoch += 1
+        return
+    for p in params:
+        p._segan_epoch = getattr(p, '_segan_epoch', 0) + 1
 
 
 class WeightPack(object):
@@ -111,7 +116,8 @@ class WeightPack(object):
 
     def _get(self, w, S, pad_t, want):
         _chk(w, 'weight', 3)
-        key = (w.data_ptr(), w._version, _weights_epoch, tuple(w.shape), S, pad_t)
+        key = (w.data_ptr(), w._version, _weights_epoch, getattr(w, '_segan_epoch', 0),
+               tuple(w.shape), S, pad_t)
         if self._key.get(want) == key:
             return self._buf[want]
         lib = _lib.load()

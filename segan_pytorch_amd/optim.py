@@ -150,7 +150,7 @@ class RMSprop(_FlatOptimizer):
         ops.rmsprop_step(self.flat_param, self.flat_grad, self._flat_state['square_avg'],
                          float(g['lr']), float(g['alpha']), float(g['eps']))
         self._bump_steps()
-        ops.bump_weights_epoch()
+        ops.bump_weights_epoch(self._params)
         return loss
 
 
@@ -183,5 +183,5 @@ class Adam(_FlatOptimizer):
                       self._flat_state['exp_avg_sq'], float(g['lr']), float(g['betas'][0]),
                       float(g['betas'][1]), float(g['eps']), self._nsteps)
         self._bump_steps()
-        ops.bump_weights_epoch()
+        ops.bump_weights_epoch(self._params)
         return loss
