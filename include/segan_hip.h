@@ -82,9 +82,11 @@ int segan_conv1d_fwd(const segan_src* x, const float* wf, const float* bias, flo
 
 /* Data gradient of the above (autograd of modules.py:98-99): dx[b,n,i] += over the
  * reflect-padded, rolled coordinates.  da: [B, M, L/S]; dx: [B, N, L] is fully
- * overwritten.  `halo` is scratch of B*N*(K-1) floats. */
-int segan_conv1d_dgrad(const float* da, const float* wt, float* dx, float* halo, int B, int N,
-                       int M, int L, int K, int S, int padL, int roll, void* stream);
+ * overwritten.  `halo` is scratch of B*N*(K-1) floats.  `w` (optional) is the UNPACKED
+ * weight [M][N][K]: when given and N <= 2 (the first layer: 1-2 input channels) a direct
+ * VALU kernel is used instead of the MFMA tile kernel and `wt` may be NULL. */
+int segan_conv1d_dgrad(const float* da, const float* wt, const float* w, float* dx, float* halo,
+                       int B, int N, int M, int L, int K, int S, int padL, int roll, void* stream);
 
 /* Weight gradient shared by both layer types (W form):
  *   dw[m,n,k] += sum_{b,t} lo[b,m,t] * pad(roll(hi))[b,n,S*t+k]
@@ -98,9 +100,12 @@ int segan_wgrad(const segan_src* lo, const segan_src* hi, float* dw, int B, int 
  * `pad`) trimmed to S*Ls samples, + bias, optional tanh (last generator layer).
  *   y[b,n,j] = bias[n] + sum_{m} sum_{t,k: S*t+k-pad=j} x[b,m,t] * w[m,n,k]
  * x: [B, M, Ls] as a segan_src (the skip concat and alpha scaling of
- * generator.py:64-76 are its second segment), y: [B, N, S*Ls]. */
-int segan_deconv1d_fwd(const segan_src* x, const float* wt, const float* bias, float* y, int B,
-                       int M, int N, int Ls, int K, int S, int pad, int act, void* stream);
+ * generator.py:64-76 are its second segment), y: [B, N, S*Ls].  `w` (optional): the
+ * UNPACKED weight; with N <= 2 (the last generator layer, Cout = 1) the direct VALU
+ * kernel is used and `wt` may be NULL. */
+int segan_deconv1d_fwd(const segan_src* x, const float* wt, const float* w, const float* bias,
+                       float* y, int B, int M, int N, int Ls, int K, int S, int pad, int act,
+                       void* stream);
 
 /* Data gradient of the deconv: dx[b,m,t] = sum_{n,k} w[m,n,k] * dy[b,n,S*t+k-pad].
  * The M rows are split at M0 into two destinations (dx0: [B,M0,Ls], dx1:

@@ -35,11 +35,11 @@ SIGNATURES = {
     'segan_pack_weights': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     'segan_conv1d_fwd': (c_int, [_SRC, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                  c_int, c_int, _P]),
-    'segan_conv1d_dgrad': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+    'segan_conv1d_dgrad': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                    c_int, _P]),
     'segan_wgrad': (c_int, [_SRC, _SRC, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                             c_int, _P]),
-    'segan_deconv1d_fwd': (c_int, [_SRC, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+    'segan_deconv1d_fwd': (c_int, [_SRC, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                    c_int, _P]),
     'segan_deconv1d_dgrad': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                      c_int, _P]),

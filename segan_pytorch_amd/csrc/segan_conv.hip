@@ -441,6 +441,120 @@ static int launch_corr(CorrArgs& a, int U, hipStream_t st) {
 }
 
 // ====================================================================================
+// T form for 1-2 output channels (the HBM-bound edge layers: the generator's last deconv
+// Cout=1, and the data gradient of the first conv whose input has 1-2 channels).  With so
+// few output channels an MFMA tile would be >90 % padding, so this is a direct VALU kernel:
+// one thread per low-rate position q computes all S phases x N channels, the input window
+// comes from an LDS tile (with the segan_src transform applied while staging) and the taps
+// are wave-uniform scalar loads.
+// ====================================================================================
+template <int S, int N, int PM>
+__global__ __launch_bounds__(256) void tsmall_kernel(const CorrArgs a, const float* __restrict__ w,
+                                                     int K, int M) {
+  constexpr int U = 32 / S;
+  constexpr int MC = 16;                 // input channels per LDS chunk
+  constexpr int TW = 256 + U;            // window: 256 positions + (U-1) taps + 1 phase shift
+  __shared__ float xs[MC][TW + 1];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y;
+  const int q0 = blockIdx.x * 256;
+  const int q = q0 + tid;
+  // window coordinate j <-> input time t = q0 + win_start + j   (win_start = cmin - (U-1))
+  float acc[S][N];
+#pragma unroll
+  for (int r = 0; r < S; ++r)
+#pragma unroll
+    for (int n = 0; n < N; ++n) acc[r][n] = 0.0f;
+
+  for (int mc0 = 0; mc0 < M; mc0 += MC) {
+    for (int e = tid; e < MC * TW; e += 256) {
+      const int mc = e / TW, j = e - mc * TW;
+      const int m = mc0 + mc;
+      const int t = q0 + a.win_start + j;
+      float v = 0.0f;
+      if (m < M && t >= 0 && t < a.Lin) {
+        const ChanXf xf = segan_chan_xf(a.in, m);
+        v = segan_apply_xf(xf, segan_src_row(a.in, b, m, a.Lin)[t]);
+      }
+      xs[mc][j] = v;
+    }
+    __syncthreads();
+    const int mcn = min(MC, M - mc0);
+    for (int mc = 0; mc < mcn; ++mc) {
+      float xv[U + 1];
+#pragma unroll
+      for (int j = 0; j <= U; ++j) xv[j] = xs[mc][tid + j];
+      const float* wm = w + (size_t)(mc0 + mc) * N * K;
+#pragma unroll
+      for (int r = 0; r < S; ++r) {
+        const int rho = (r + PM) % S;     // tap phase of output phase r
+        const int cs = (r + PM) / S;      // 0/1: extra input shift of this phase
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int k = S * u + rho;
+          if (k < K) {
+#pragma unroll
+            for (int n = 0; n < N; ++n)
+              acc[r][n] = fmaf(wm[n * K + k], xv[cs + (U - 1) - u], acc[r][n]);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (q >= a.Tcols) return;
+#pragma unroll
+  for (int r = 0; r < S; ++r)
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      float v = acc[r][n] + (a.bias ? a.bias[n] : 0.0f);
+      if (a.act == SEGAN_ACT_TANH) v = tanhf(v);
+      const int P = S * q + r;
+      int ii = P - a.o_padL;
+      const size_t rowoff = (size_t)b * N + n;
+      if (ii >= 0 && ii < a.Lout) {
+        if (a.o_roll != 0) {
+          ii -= a.o_roll;
+          if (ii < 0) ii += a.Lout;
+          if (ii >= a.Lout) ii -= a.Lout;
+        }
+        a.out0[rowoff * (size_t)a.Lout + ii] = v;
+      } else if (a.halo != nullptr) {
+        const int hl = a.o_padL + a.o_padR;
+        if (ii < 0) a.halo[rowoff * hl + P] = v;
+        else if (ii - a.Lout < a.o_padR) a.halo[rowoff * hl + a.o_padL + (ii - a.Lout)] = v;
+      }
+    }
+}
+
+template <int S, int N>
+static int launch_tsmall_sn(const CorrArgs& a, const float* w, int K, int M, int pad,
+                            hipStream_t st) {
+  dim3 grid(ceil_div(a.Tcols, 256), a.B);
+  switch (pad % S) {
+    case 0: hipLaunchKernelGGL((tsmall_kernel<S, N, 0>), grid, dim3(256), 0, st, a, w, K, M); break;
+    case 1: hipLaunchKernelGGL((tsmall_kernel<S, N, 1 % S>), grid, dim3(256), 0, st, a, w, K, M); break;
+    case 2: hipLaunchKernelGGL((tsmall_kernel<S, N, 2 % S>), grid, dim3(256), 0, st, a, w, K, M); break;
+    default: hipLaunchKernelGGL((tsmall_kernel<S, N, 3 % S>), grid, dim3(256), 0, st, a, w, K, M); break;
+  }
+  return segan_check_launch("tsmall_kernel");
+}
+
+// `a` is filled exactly as for the MFMA T form; w is the UNPACKED weight [M][N][K]
+static int launch_tsmall(CorrArgs& a, const float* w, int K, int M, int N, int S, int pad,
+                         hipStream_t st) {
+  if (int e = segan_src_defaults(&a.in, st, "tsmall")) return e;
+  if (N == 1) {
+    if (S == 4) return launch_tsmall_sn<4, 1>(a, w, K, M, pad, st);
+    if (S == 2) return launch_tsmall_sn<2, 1>(a, w, K, M, pad, st);
+    return launch_tsmall_sn<1, 1>(a, w, K, M, pad, st);
+  }
+  if (S == 4) return launch_tsmall_sn<4, 2>(a, w, K, M, pad, st);
+  if (S == 2) return launch_tsmall_sn<2, 2>(a, w, K, M, pad, st);
+  return launch_tsmall_sn<1, 2>(a, w, K, M, pad, st);
+}
+
+// ====================================================================================
 // wgrad kernel
 // ====================================================================================
 struct WgradArgs {
@@ -453,21 +567,33 @@ struct WgradArgs {
   int Ctot;               // B*Ls
   int cols_per_split;
   int H, RLw;
-  int ls_magic;           // ceil(65536 / Ls) when Ls < TK (sample index by multiply-shift)
+  int ls_magic;           // ceil(65536 / Ls): x / Ls for small x when Ls < TK
+  int per_magic;          // ceil(65536 / (Ls + H)): LDS position -> sample when Ls < TK
 };
 
-template <int U, int TK>
+// x / Ls for 0 <= x < Ls + TK (Ls >= TK: one compare; else exact multiply-shift, x < 64)
+template <int TK>
+__device__ __forceinline__ int wg_sdiv(int x, int Ls, int magic) {
+  return (Ls >= TK) ? (x >= Ls ? 1 : 0) : ((x * magic) >> 16);
+}
+
+// dW[m][n][S*u+r] += sum over the flattened (sample, time) columns.  Block tile: 128 rows
+// (m) x 128 columns ((n,r),u = 128/U virtual channels x U taps), contraction chunks of TK
+// columns, double buffered.  LO_ID / HI_ID: that operand has the identity transform (the
+// gradient operand always has), so its staging is a plain copy.
+template <int U, int TK, bool LO_ID, bool HI_ID>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
   constexpr int S = 32 / U;
   constexpr int MB = 128;
   constexpr int CVW = 128 / U;       // virtual channels per block (128 output columns)
-  constexpr int AST = TK + 1;        // padded A row stride
+  constexpr int NN = CVW / S;        // real hi channels per block
+  constexpr int AST = TK + 4;        // lo row stride: 16-B aligned rows, conflict-free b128 reads
+  constexpr int NJ8 = TK / 8;        // groups of 8 contraction columns
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int RLw = a.RLw;
-  // double-buffered: [2][MB*AST] lo tile, [2][CVW*RLw] hi phases
-  float* Al0 = smem;
-  float* Bl0 = Al0 + 2 * MB * AST;
+  float* Al0 = smem;                  // [2][MB*AST]
+  float* Bl0 = Al0 + 2 * MB * AST;    // [2][CVW*RLw]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -480,16 +606,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
   const int split_end = min(split_beg + a.cols_per_split, a.Ctot);
   if (split_beg >= split_end) return;
   const int nch = (split_end - split_beg + TK - 1) / TK;
+  const int Ls = a.Ls;
 
-  // per-lane operand offsets
-  int aoff[2], bch[2], bu[2];
+  // ---- MFMA operand offsets.  Lane (row/col l31, half h) supplies contraction columns
+  // k' = 8j + 4h + i (i = 0..3) of group j: one ds_read_b128 of the lo tile per row block.
+  int aoff[2], bbase[2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) aoff[i] = (wm * 64 + 32 * i + l31) * AST + h;
+  for (int i = 0; i < 2; ++i) aoff[i] = (wm * 64 + 32 * i + l31) * AST + 4 * h;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int cc = wn * 64 + 32 * j + l31;
-    bch[j] = (cc / U) * RLw;
-    bu[j] = cc % U;
+    bbase[j] = (cc / U) * RLw + cc % U;
   }
 
   f32x16 acc[2][2];
@@ -500,83 +627,92 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-  // A staging: thread owns 4 consecutive columns (one float4; Ls % 4 == 0 keeps them in
-  // one sample) of rows tid/16 + 16*i.  Loads are unconditional (clamped addresses) and
-  // masked / transformed when they are written to LDS.
-  constexpr int F4A = TK / 4;          // float4 per A row
-  constexpr int RPA = 256 / F4A;       // rows per pass
+  // ---- lo staging: thread owns one float4 (4 consecutive columns; Ls % 4 == 0 keeps them
+  // in one sample) of rows ar0 + RPA*i.  Row bases / transforms never change.
+  constexpr int F4A = TK / 4;
+  constexpr int RPA = 256 / F4A;
   constexpr int NPA = MB / RPA;
   const int kc4 = tid % F4A, ar0 = tid / F4A;
+  const float* arow[NPA];
+  bool arow_ok[NPA], arow_s1[NPA];
+  ChanXf axf[NPA];
+#pragma unroll
+  for (int i = 0; i < NPA; ++i) {
+    int m = m0 + ar0 + RPA * i;
+    arow_ok[i] = m < a.M;
+    m = arow_ok[i] ? m : 0;
+    arow_s1[i] = m >= a.lo.C0;
+    arow[i] = arow_s1[i] ? a.lo.p1 + (size_t)(m - a.lo.C0) * Ls : a.lo.p0 + (size_t)m * Ls;
+    if (!LO_ID) axf[i] = segan_chan_xf(a.lo, m);
+  }
+  // ---- hi staging: thread owns LDS position tid (< RLw <= 256) of all CVW channels
+  const float* brow[NN];
+  bool brow_s1[NN];
+  ChanXf bxf[NN];
+#pragma unroll
+  for (int c = 0; c < NN; ++c) {
+    int n = cv0 / S + c;
+    n = n < a.N ? n : 0;
+    brow_s1[c] = n >= a.hi.C0;
+    brow[c] = brow_s1[c] ? a.hi.p1 + (size_t)(n - a.hi.C0) * a.Lhi : a.hi.p0 + (size_t)n * a.Lhi;
+    if (!HI_ID) bxf[c] = segan_chan_xf(a.hi, n);
+  }
+
   f32x4 areg[NPA];
   float breg[CVW];
   bool a_ok = false;
-  // the rows / channels a thread stages never change: fetch their transforms once
-  ChanXf axf[NPA];
-  bool arow_ok[NPA];
-#pragma unroll
-  for (int i = 0; i < NPA; ++i) {
-    const int m = m0 + ar0 + RPA * i;
-    arow_ok[i] = m < a.M;
-    axf[i] = segan_chan_xf(a.lo, arow_ok[i] ? m : 0);
-  }
-  ChanXf bxf[CVW / S];
-#pragma unroll
-  for (int c = 0; c < CVW / S; ++c) {
-    const int n = cv0 / S + c;
-    bxf[c] = segan_chan_xf(a.hi, n < a.N ? n : 0);
-  }
   unsigned b_ok = 0u;
 
   auto load_chunk = [&](int ch) {
     const int col0 = split_beg + ch * TK;
-    // ---- A: lo[m][col] ----
+    const int b0 = col0 / Ls;
+    const int t_first = col0 - b0 * Ls;
+    // ---- lo ----
     {
-      const int col = col0 + 4 * kc4;
-      a_ok = col < split_end;
-      const int colc = a_ok ? col : 0;
-      const int b = colc / a.Ls;
-      const int t = colc - b * a.Ls;
-      const int bo0 = b * a.lo.C0 * a.Ls + t, bo1 = b * a.lo.C1 * a.Ls + t;
+      const int c4 = 4 * kc4;
+      a_ok = col0 + c4 < split_end;
+      const int x = t_first + c4;
+      const int sd = wg_sdiv<TK>(x, Ls, a.ls_magic);
+      int bb = b0 + sd;
+      bb = (a_ok && bb < a.B) ? bb : 0;
+      const int t = x - sd * Ls;
+      const int o0 = bb * a.lo.C0 * Ls + t, o1 = bb * a.lo.C1 * Ls + t;
 #pragma unroll
-      for (int i = 0; i < NPA; ++i) {
-        int m = m0 + ar0 + RPA * i;
-        m = m < a.M ? m : 0;
-        const bool seg1 = m >= a.lo.C0;
-        const float* rowp = seg1 ? a.lo.p1 + (size_t)(m - a.lo.C0) * a.Ls + bo1
-                                 : a.lo.p0 + (size_t)m * a.Ls + bo0;
-        areg[i] = *reinterpret_cast<const f32x4*>(rowp);
+      for (int i = 0; i < NPA; ++i)
+        areg[i] = *reinterpret_cast<const f32x4*>(arow[i] + (arow_s1[i] ? o1 : o0));
+    }
+    // ---- hi ----
+    int s = 0, tau = 0;
+    if (Ls >= TK) {
+      const int len0 = min(Ls - t_first, TK);
+      if (tid < len0 + a.H) { s = 0; tau = t_first + tid; }
+      else { s = 1; tau = tid - (len0 + a.H); }
+    } else {
+      // chunks start on a sample boundary only when Ls divides TK; general decode otherwise
+      const int len0 = min(Ls - t_first, TK);
+      if (tid < len0 + a.H) { s = 0; tau = t_first + tid; }
+      else {
+        const int jj = tid - (len0 + a.H);
+        const int q = (jj * a.per_magic) >> 16;
+        s = 1 + q;
+        tau = jj - q * (Ls + a.H);
       }
     }
-    // ---- B: hi phases (RLw <= 256: one position per thread) ----
-    const ColTile ct = make_coltile(col0, a.Ls, TK);
-    int pbo0 = 0, pbo1 = 0, poff[S];
+    const int bs = b0 + s;
+    const bool bok = tid < RLw && bs < a.B;
+    const int bsc = bok ? bs : 0;
+    const int so0 = bsc * a.hi.C0 * a.Lhi, so1 = bsc * a.hi.C1 * a.Lhi;
+    int poff[S];
     b_ok = 0u;
 #pragma unroll
-    for (int r = 0; r < S; ++r) poff[r] = 0;
-    if (tid < RLw) {
-      int s, tau;
-      lds_pos_decode(ct, tid, a.Ls, a.H, s, tau);
-      const int b = ct.b0 + s;
-      if (b < a.B) {
-        pbo0 = b * a.hi.C0 * a.Lhi;
-        pbo1 = b * a.hi.C1 * a.Lhi;
-#pragma unroll
-        for (int r = 0; r < S; ++r) {
-          const int idx = segan_hi_index(S * tau + r, a.Lhi, a.padL, a.mode, a.roll);
-          if (idx >= 0) { poff[r] = idx; b_ok |= 1u << r; }
-        }
-      }
+    for (int r = 0; r < S; ++r) {
+      const int idx = segan_hi_index(S * tau + r, a.Lhi, a.padL, a.mode, a.roll);
+      poff[r] = (bok && idx >= 0) ? idx : 0;
+      if (bok && idx >= 0) b_ok |= 1u << r;
     }
 #pragma unroll
-    for (int c = 0; c < CVW; ++c) {
-      int cv = cv0 + c;
-      cv = cv < a.Cv ? cv : 0;
-      const int n = cv / S, r = c % S;  // cv0 is a multiple of S
-      const bool seg1 = n >= a.hi.C0;
-      const float* rowp = seg1 ? a.hi.p1 + (size_t)(n - a.hi.C0) * a.Lhi + pbo1
-                               : a.hi.p0 + (size_t)n * a.Lhi + pbo0;
-      breg[c] = rowp[poff[r]];
-    }
+    for (int c = 0; c < CVW; ++c)
+      breg[c] = brow[c / S][(brow_s1[c / S] ? so1 : so0) + poff[c % S]];
   };
   auto store_chunk = [&](int buf) {
     float* Al = Al0 + buf * (MB * AST);
@@ -584,20 +720,22 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll
     for (int i = 0; i < NPA; ++i) {
       const bool ok = a_ok && arow_ok[i];
-      const float v0 = ok ? segan_apply_xf(axf[i], areg[i][0]) : 0.f;
-      const float v1 = ok ? segan_apply_xf(axf[i], areg[i][1]) : 0.f;
-      const float v2 = ok ? segan_apply_xf(axf[i], areg[i][2]) : 0.f;
-      const float v3 = ok ? segan_apply_xf(axf[i], areg[i][3]) : 0.f;
-      float* d = Al + (ar0 + RPA * i) * AST + 4 * kc4;
-      d[0] = v0; d[1] = v1; d[2] = v2; d[3] = v3;
+      f32x4 v = areg[i];
+      if (!LO_ID) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = segan_apply_xf(axf[i], v[e]);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.0f;
+      *reinterpret_cast<f32x4*>(Al + (ar0 + RPA * i) * AST + 4 * kc4) = v;
     }
     if (tid < RLw) {
 #pragma unroll
       for (int c = 0; c < CVW; ++c) {
-        const int cv = cv0 + c;
-        const int r = c % S;
-        const bool ok = cv < a.Cv && ((b_ok >> r) & 1u);
-        Bl[c * RLw + tid] = ok ? segan_apply_xf(bxf[c / S], breg[c]) : 0.0f;
+        const bool ok = (cv0 + c) < a.Cv && ((b_ok >> (c % S)) & 1u);
+        float v = breg[c];
+        if (!HI_ID) v = segan_apply_xf(bxf[c / S], v);
+        Bl[c * RLw + tid] = ok ? v : 0.0f;
       }
     }
   };
@@ -610,34 +748,50 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     if (ch + 1 < nch) load_chunk(ch + 1);
     const float* Al = Al0 + buf * (MB * AST);
     const float* Bl = Bl0 + buf * (CVW * RLw);
-    // LDS position of contraction column k' (sample s of the chunk sits s*H further):
-    // x = offset of the column from the start of the chunk's first sample
-    const int xh = (split_beg + ch * TK) % a.Ls + h;
-    float av0[2], av1[2], bv0[2], bv1[2];
-    auto read_step = [&](int s, float (&av)[2], float (&bv)[2]) {
-      const int kk = 2 * s;
-      const int x = xh + kk;
-      const int sl = (a.Ls >= TK) ? (x >= a.Ls ? 1 : 0) : ((x * a.ls_magic) >> 16);
-      const int pz = kk + h + sl * a.H;
+    // LDS position of contraction column k' = 8j + 4h (+i): sample s of the chunk sits s*H
+    // further right; 4 | Ls keeps the 4 columns of a group in one sample.
+    const int t_first = (split_beg + ch * TK) % Ls;
+    int bpos[NJ8][2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) av[i] = Al[aoff[i] + kk];
+    for (int j = 0; j < NJ8; ++j) {
+      const int k0 = 8 * j + 4 * h;
+      const int p = k0 + wg_sdiv<TK>(t_first + k0, Ls, a.ls_magic) * a.H;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) bv[j] = Bl[bch[j] + pz + bu[j]];
+      for (int jj = 0; jj < 2; ++jj) bpos[j][jj] = bbase[jj] + p;
+    }
+    f32x4 af0[2], af1[2];
+    float bv0[2], bv1[2];
+    auto read_a = [&](int j, f32x4 (&af)[2]) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const f32x4*>(Al + aoff[i] + 8 * j);
     };
-    auto mma_step = [&](const float (&av)[2], const float (&bv)[2]) {
+    auto read_b = [&](int s, float (&bv)[2]) {
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) bv[jj] = Bl[bpos[s / 4][jj] + (s & 3)];
+    };
+    auto mma = [&](const f32x4 (&af)[2], int e, const float (&bv)[2]) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        for (int jj = 0; jj < 2; ++jj)
+          acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bv[jj], acc[i][jj], 0, 0, 0);
     };
-    read_step(0, av0, bv0);
+    read_a(0, af0);
+    read_b(0, bv0);
 #pragma unroll
-    for (int s = 0; s < TK / 2; s += 2) {
-      read_step(s + 1, av1, bv1);
-      mma_step(av0, bv0);
-      if (s + 2 < TK / 2) read_step(s + 2, av0, bv0);
-      mma_step(av1, bv1);
+    for (int j = 0; j < NJ8; j += 2) {
+      // group j (af0), then group j+1 (af1); B one step ahead in alternating sets
+      read_a(j + 1, af1);
+      read_b(4 * j + 1, bv1); mma(af0, 0, bv0);
+      read_b(4 * j + 2, bv0); mma(af0, 1, bv1);
+      read_b(4 * j + 3, bv1); mma(af0, 2, bv0);
+      read_b(4 * j + 4, bv0); mma(af0, 3, bv1);
+      if (j + 2 < NJ8) read_a(j + 2, af0);
+      read_b(4 * j + 5, bv1); mma(af1, 0, bv0);
+      read_b(4 * j + 6, bv0); mma(af1, 1, bv1);
+      read_b(4 * j + 7, bv1); mma(af1, 2, bv0);
+      if (4 * j + 8 < TK / 2) read_b(4 * j + 8, bv0);
+      mma(af1, 3, bv1);
     }
     if (ch + 1 < nch) store_chunk(buf ^ 1);
     __syncthreads();
@@ -662,8 +816,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
   }
 }
 
-template <int U>
-static int launch_wgrad_t(WgradArgs& a, hipStream_t st) {
+template <int U, bool LO_ID, bool HI_ID>
+static int launch_wgrad_x(WgradArgs& a, hipStream_t st) {
   constexpr int CVW = 128 / U;
   constexpr int TK = 32;
   int NS;
@@ -684,6 +838,8 @@ static int launch_wgrad_t(WgradArgs& a, hipStream_t st) {
   }
   if (int e = segan_src_defaults(&a.lo, st, "wgrad(lo)")) return e;
   if (int e = segan_src_defaults(&a.hi, st, "wgrad(hi)")) return e;
+  a.ls_magic = (65536 + a.Ls - 1) / a.Ls;
+  a.per_magic = (65536 + a.Ls + a.H - 1) / (a.Ls + a.H);
   const int ncol = ceil_div(a.Cv, CVW);
   const int nrow = ceil_div(a.M, 128);
   // split the (b,t) contraction so the grid has a few workgroups per CU
@@ -696,9 +852,8 @@ static int launch_wgrad_t(WgradArgs& a, hipStream_t st) {
   const int chunks_per = ceil_div(chunks, nsplit);
   nsplit = ceil_div(chunks, chunks_per);
   a.cols_per_split = chunks_per * TK;
-  const size_t lds = (size_t)(2 * 128 * (TK + 1) + 2 * CVW * a.RLw) * sizeof(float);
-  a.ls_magic = (65536 + a.Ls - 1) / a.Ls;
-  auto kern = wgrad_kernel<U, TK>;
+  const size_t lds = (size_t)(2 * 128 * (TK + 4) + 2 * CVW * a.RLw) * sizeof(float);
+  auto kern = wgrad_kernel<U, TK, LO_ID, HI_ID>;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -707,6 +862,16 @@ static int launch_wgrad_t(WgradArgs& a, hipStream_t st) {
   }
   hipLaunchKernelGGL(kern, dim3(ncol, nrow, nsplit), dim3(256), lds, st, a);
   return segan_check_launch("wgrad_kernel");
+}
+
+template <int U>
+static int launch_wgrad_t(WgradArgs& a, hipStream_t st) {
+  const bool lo_id = !a.lo.scale && !a.lo.shift && !a.lo.slope;
+  const bool hi_id = !a.hi.scale && !a.hi.shift && !a.hi.slope;
+  if (lo_id && hi_id) return launch_wgrad_x<U, true, true>(a, st);
+  if (lo_id) return launch_wgrad_x<U, true, false>(a, st);
+  if (hi_id) return launch_wgrad_x<U, false, true>(a, st);
+  return launch_wgrad_x<U, false, false>(a, st);
 }
 
 // ====================================================================================
@@ -852,13 +1017,13 @@ extern "C" int segan_deconv1d_dgrad(const float* dy, const float* wf, float* dx0
   return launch_corr<true, false>(a, U, (hipStream_t)stream);
 }
 
-extern "C" int segan_deconv1d_fwd(const segan_src* x, const float* wt, const float* bias, float* y,
-                                  int B, int M, int N, int Ls, int K, int S, int pad, int act,
-                                  void* stream) {
+extern "C" int segan_deconv1d_fwd(const segan_src* x, const float* wt, const float* w,
+                                  const float* bias, float* y, int B, int M, int N, int Ls, int K,
+                                  int S, int pad, int act, void* stream) {
   SEGAN_REQUIRE(stride_ok(S), "deconv1d_fwd: stride %d not in {1,2,4}", S);
   SEGAN_REQUIRE(K >= 1 && K <= 32, "deconv1d_fwd: kernel width %d not in [1,32]", K);
   SEGAN_REQUIRE(B > 0 && N > 0 && M > 0 && Ls > 0, "deconv1d_fwd: bad sizes");
-  SEGAN_REQUIRE(wt && y, "deconv1d_fwd: NULL pointer");
+  SEGAN_REQUIRE(y && (wt || (w && N <= 2)), "deconv1d_fwd: NULL pointer");
   SEGAN_REQUIRE(pad >= 0 && K - 2 * pad - S == (K & 1),
                 "deconv1d_fwd: K=%d S=%d pad=%d does not give an output of S*Ls samples", K, S, pad);
   SEGAN_REQUIRE(act == SEGAN_ACT_NONE || act == SEGAN_ACT_TANH, "deconv1d_fwd: bad activation");
@@ -883,16 +1048,17 @@ extern "C" int segan_deconv1d_fwd(const segan_src* x, const float* wt, const flo
   a.H = U - 1 + (cmax - cmin);
   a.OC0 = N; a.OC1 = 0; a.Lout = S * Ls; a.act = act;
   a.o_padL = 0; a.o_roll = 0; a.o_padR = 0;
+  if (w && N <= 2) return launch_tsmall(a, w, K, M, N, S, pad, (hipStream_t)stream);
   return launch_corr<false, true>(a, U, (hipStream_t)stream);
 }
 
-extern "C" int segan_conv1d_dgrad(const float* da, const float* wt, float* dx, float* halo, int B,
-                                  int N, int M, int L, int K, int S, int padL, int roll,
-                                  void* stream) {
+extern "C" int segan_conv1d_dgrad(const float* da, const float* wt, const float* w, float* dx,
+                                  float* halo, int B, int N, int M, int L, int K, int S, int padL,
+                                  int roll, void* stream) {
   SEGAN_REQUIRE(stride_ok(S), "conv1d_dgrad: stride %d not in {1,2,4}", S);
   SEGAN_REQUIRE(K >= 1 && K <= 32, "conv1d_dgrad: kernel width %d not in [1,32]", K);
   SEGAN_REQUIRE(B > 0 && N > 0 && M > 0 && L > 0 && L % S == 0, "conv1d_dgrad: bad sizes");
-  SEGAN_REQUIRE(da && wt && dx && halo, "conv1d_dgrad: NULL pointer");
+  SEGAN_REQUIRE(da && dx && halo && (wt || (w && N <= 2)), "conv1d_dgrad: NULL pointer");
   SEGAN_REQUIRE(roll > -L && roll < L, "conv1d_dgrad: |roll| must be < L");
   const int padR = K - 1 - padL;
   SEGAN_REQUIRE(padL >= 0 && padR >= 0 && padL < L && padR < L, "conv1d_dgrad: bad padding");
@@ -915,7 +1081,8 @@ extern "C" int segan_conv1d_dgrad(const float* da, const float* wt, float* dx, f
   a.H = U - 1;
   a.OC0 = N; a.OC1 = 0; a.Lout = L; a.act = SEGAN_ACT_NONE;
   a.o_padL = padL; a.o_roll = roll; a.o_padR = padR;
-  int e = launch_corr<false, true>(a, U, st);
+  int e = (w && N <= 2) ? launch_tsmall(a, w, K, M, N, S, 0, st)
+                        : launch_corr<false, true>(a, U, st);
   if (e) return e;
   if (padL + padR > 0) {
     const int rows = B * N;

@@ -176,7 +176,11 @@ def conv1d_dgrad(da, w, L, S, roll=0, padL=None, pack=None):
         padL = conv_pad(K, S)[0]
     dx = torch.empty((B, N, L), device=da.device, dtype=torch.float32)
     halo = torch.empty((B * N * max(K - 1, 1),), device=da.device, dtype=torch.float32)
-    check(_lib.load().segan_conv1d_dgrad(_ptr(da), _ptr((pack or WeightPack()).t(w, S, 0)),
+    small = N <= 2          # first layer: direct VALU kernel on the unpacked weight
+    _chk(w, 'weight', 3)
+    check(_lib.load().segan_conv1d_dgrad(_ptr(da),
+                                         None if small else _ptr((pack or WeightPack()).t(w, S, 0)),
+                                         _ptr(w.detach()) if small else None,
                                          _ptr(dx), _ptr(halo), B,
                                          N, M, L, K, S, padL, roll, _stream()), 'conv1d_dgrad')
     return dx
@@ -205,8 +209,11 @@ def deconv1d_fwd(src, w, bias, S, act=ACT_NONE, pack=None):
     B, Ls = src.B, src.L
     y = torch.empty((B, N, S * Ls), device=w.device, dtype=torch.float32)
     cs = src.c_struct()
-    check(_lib.load().segan_deconv1d_fwd(ctypes.byref(cs), _ptr((pack or WeightPack()).t(w, S, pad)),
-                                         _ptr(bias),
+    small = N <= 2          # last generator layer (Cout = 1): direct VALU kernel
+    _chk(w, 'weight', 3)
+    check(_lib.load().segan_deconv1d_fwd(ctypes.byref(cs),
+                                         None if small else _ptr((pack or WeightPack()).t(w, S, pad)),
+                                         _ptr(w.detach()) if small else None, _ptr(bias),
                                          _ptr(y), B, M, N, Ls, K, S, pad, act, _stream()),
           'deconv1d_fwd')
     return y
