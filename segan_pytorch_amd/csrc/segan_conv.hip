@@ -77,6 +77,7 @@ struct CorrArgs {
   int NP, Nout;           // T form row decode: row = r*NP + n
   int OC0, OC1, Lout, act;
   int o_padL, o_roll, o_padR;  // HI store (conv dgrad: reflect halo)
+  int prio_mode;               // 0: none, 1: hashed static wave priority per workgroup
 };
 
 // Staging discipline (both kernels): load_chunk() only ISSUES global loads — every
@@ -102,6 +103,15 @@ __global__ __launch_bounds__(256, 2) void corr_kernel(const CorrArgs a) {
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, h = lane >> 5;
 
+  // Co-resident workgroups do identical work and would otherwise reach their staging /
+  // barrier phases together, idling the MFMA pipe; distinct static priorities let one
+  // run ahead and spread the phases.
+  if (a.prio_mode == 1) {
+    const unsigned hsh = (blockIdx.x * 2654435761u) >> 30;
+    if (hsh == 1) __builtin_amdgcn_s_setprio(1);
+    else if (hsh == 2) __builtin_amdgcn_s_setprio(2);
+    else if (hsh == 3) __builtin_amdgcn_s_setprio(3);
+  }
   const int rowtile = blockIdx.x / a.ncoltiles;
   const int coltile = blockIdx.x - rowtile * a.ncoltiles;
   const int m0 = rowtile * MB;
@@ -269,13 +279,19 @@ __global__ __launch_bounds__(256, 2) void corr_kernel(const CorrArgs a) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[OUT_HI ? i : 0][j], acc[i][j],
                                                            0, 0, 0);
     };
+    // sched_barrier pins "reads of step s+1, then MFMAs of step s" so the LDS latency of the
+    // next operands is covered by the 4 x 64-cycle MFMAs instead of being exposed
     read_step(0, av0, bv0);
 #pragma unroll
     for (int s = 0; s < KC / 2; s += 2) {
       read_step(s + 1, av1, bv1);
+      __builtin_amdgcn_sched_barrier(0);
       mma_step(av0, bv0);
+      __builtin_amdgcn_sched_barrier(0);
       if (s + 2 < KC / 2) read_step(s + 2, av0, bv0);
+      __builtin_amdgcn_sched_barrier(0);
       mma_step(av1, bv1);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (ch + 1 < nch) store_chunk(ch + 1, buf ^ 1);
     __syncthreads();
@@ -425,6 +441,8 @@ static int launch_corr(CorrArgs& a, int U, hipStream_t st) {
                     a.RLs);
     return SEGAN_EUNSUPPORTED;
   }
+  static const int prio_env = [] { const char* e = getenv("SEGAN_PRIO"); return e ? atoi(e) : 0; }();
+  a.prio_mode = prio_env;
   if (int e = segan_src_defaults(&a.in, st, "corr")) return e;
   const long in_elems = (long)a.B * (a.in.C0 + a.in.C1) * a.Lin;
   if (in_elems >= (1L << 31)) {
@@ -569,6 +587,7 @@ struct WgradArgs {
   int H, RLw;
   int ls_magic;           // ceil(65536 / Ls): x / Ls for small x when Ls < TK
   int per_magic;          // ceil(65536 / (Ls + H)): LDS position -> sample when Ls < TK
+  int prio_mode;
 };
 
 // x / Ls for 0 <= x < Ls + TK (Ls >= TK: one compare; else exact multiply-shift, x < 64)
@@ -600,6 +619,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, h = lane >> 5;
 
+  if (a.prio_mode == 1) {
+    const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned hsh = (lin * 2654435761u) >> 30;
+    if (hsh == 1) __builtin_amdgcn_s_setprio(1);
+    else if (hsh == 2) __builtin_amdgcn_s_setprio(2);
+    else if (hsh == 3) __builtin_amdgcn_s_setprio(3);
+  }
   const int cv0 = blockIdx.x * CVW;
   const int m0 = blockIdx.y * MB;
   const int split_beg = blockIdx.z * a.cols_per_split;
@@ -778,21 +804,24 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     };
     read_a(0, af0);
     read_b(0, bv0);
+#define SB __builtin_amdgcn_sched_barrier(0)
 #pragma unroll
     for (int j = 0; j < NJ8; j += 2) {
-      // group j (af0), then group j+1 (af1); B one step ahead in alternating sets
+      // group j (af0), then group j+1 (af1); B one step ahead in alternating sets; the
+      // sched_barriers pin "next reads, then this step's MFMAs"
       read_a(j + 1, af1);
-      read_b(4 * j + 1, bv1); mma(af0, 0, bv0);
-      read_b(4 * j + 2, bv0); mma(af0, 1, bv1);
-      read_b(4 * j + 3, bv1); mma(af0, 2, bv0);
-      read_b(4 * j + 4, bv0); mma(af0, 3, bv1);
+      read_b(4 * j + 1, bv1); SB; mma(af0, 0, bv0); SB;
+      read_b(4 * j + 2, bv0); SB; mma(af0, 1, bv1); SB;
+      read_b(4 * j + 3, bv1); SB; mma(af0, 2, bv0); SB;
+      read_b(4 * j + 4, bv0); SB; mma(af0, 3, bv1); SB;
       if (j + 2 < NJ8) read_a(j + 2, af0);
-      read_b(4 * j + 5, bv1); mma(af1, 0, bv0);
-      read_b(4 * j + 6, bv0); mma(af1, 1, bv1);
-      read_b(4 * j + 7, bv1); mma(af1, 2, bv0);
+      read_b(4 * j + 5, bv1); SB; mma(af1, 0, bv0); SB;
+      read_b(4 * j + 6, bv0); SB; mma(af1, 1, bv1); SB;
+      read_b(4 * j + 7, bv1); SB; mma(af1, 2, bv0); SB;
       if (4 * j + 8 < TK / 2) read_b(4 * j + 8, bv0);
-      mma(af1, 3, bv1);
+      SB; mma(af1, 3, bv1); SB;
     }
+#undef SB
     if (ch + 1 < nch) store_chunk(buf ^ 1);
     __syncthreads();
   }
@@ -838,6 +867,8 @@ static int launch_wgrad_x(WgradArgs& a, hipStream_t st) {
   }
   if (int e = segan_src_defaults(&a.lo, st, "wgrad(lo)")) return e;
   if (int e = segan_src_defaults(&a.hi, st, "wgrad(hi)")) return e;
+  static const int prio_env = [] { const char* e = getenv("SEGAN_PRIO"); return e ? atoi(e) : 0; }();
+  a.prio_mode = prio_env;
   a.ls_magic = (65536 + a.Ls - 1) / a.Ls;
   a.per_magic = (65536 + a.Ls + a.H - 1) / (a.Ls + a.H);
   const int ncol = ceil_div(a.Cv, CVW);
