@@ -13,6 +13,8 @@ tiny_train2.pt   the same net driven through the reference's literal ``SEGAN.tra
                  from the recorded seeds): final weights.
 tiny_s2.pt       a stride-2 variant (vanilla-SEGAN style, fmaps 4/8/8/16, L=256) forward
                  and gradients.
+tiny_wsegan2.pt  the tiny net as WSEGAN with --misalign_pair through the reference's literal
+                 ``WSEGAN.train`` for two iterations (stft / .cuda() patched in the harness).
 segan_plus_b2.pt the default SEGAN+ net (ckpt_segan+/train.opts, seed 111) at B=2:
                  per-tensor init checksums, G output, D logits, losses, and
                  checksums/samples of every gradient.
@@ -179,6 +181,38 @@ def main():
     fx3.update(manual_step(ref, segan, clean, noisy, z, 9))
     torch.save(fx3, os.path.join(OUT, 'tiny_s2.pt'))
     print('tiny_s2.pt done')
+
+    # ---------------- tiny_wsegan2: the literal WSEGAN.train (misalign pair) ----------------
+    # The reference cannot run as written on torch 2.x / CPU: the
+    # legacy torch.stft call needs return_complex, and labels are hard-.cuda()'d.  Both are
+    # patched IN THE HARNESS ONLY (the reference sources are untouched): stft returns the
+    # legacy real view [..., 2] so torch.norm(x, 2, dim=3) is |STFT| as before.
+    ow = tiny_opts()
+    ow.update(dict(wsegan=True, misalign_pair=True, cuda=False, save_freq=1000))
+    _stft = torch.stft
+    torch.stft = lambda *a, **k: torch.view_as_real(_stft(*a, return_complex=True, **k))
+    _cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        seed_all(111)
+        wseg = ref.WSEGAN(SimpleNamespace(**ow))
+        c1, n1 = synth(3, 1024, 4)
+        names = ['utt_additive_0', 'utt_1', 'utt_additive_2']
+        loader = [[names, c1, n1, torch.zeros(3)]]
+        fxw = {'opts': ow, 'G0': clone_sd(wseg.G), 'D0': clone_sd(wseg.D), 'clean': c1,
+               'noisy': n1, 'names': names, 'seed': 31, 'iters': 2}
+        ow2 = dict(ow)
+        ow2['epoch'] = 2          # 2 iterations over the 1-batch loader
+        seed_all(31)
+        wseg.train(SimpleNamespace(**ow2), loader, None, ow['l1_weight'], ow['l1_dec_step'],
+                   ow['l1_dec_epoch'], 1000, va_dloader=None, device='cpu')
+        fxw['G_final'] = clone_sd(wseg.G)
+        fxw['D_final'] = clone_sd(wseg.D)
+        torch.save(fxw, os.path.join(OUT, 'tiny_wsegan2.pt'))
+        print('tiny_wsegan2.pt done')
+    finally:
+        torch.stft = _stft
+        torch.Tensor.cuda = _cuda
 
     # ---------------- segan_plus_b2: the default net ----------------
     ob = base_opts()

@@ -199,3 +199,51 @@ def gan_step(g_sd, d_sd, clean, noisy, z, rolls3, strides, l1_weight=100.0, lr=5
     out['D'] = {k: v.detach() for k, v in D.items()}
     out['g_sq'], out['d_sq'] = g_sq, d_sq
     return out
+
+
+def stft_pow_db(x, n_fft=2048):
+    """10*log10(|STFT|^2 + 10e-20) of model.py:640-653: rectangular window (window=None),
+    win_length 320 centred in n_fft, hop 160, center/reflect padding, normalized."""
+    st = torch.stft(x.squeeze(1), n_fft=min(x.size(-1), n_fft), hop_length=160, win_length=320,
+                    normalized=True, return_complex=True)
+    return 10 * torch.log10(st.abs() ** 2 + 10e-20)
+
+
+def wsegan_step(g_sd, d_sd, clean, noisy, z, rolls, perm, names, strides, l1_weight=100.0,
+                pow_weight=0.001, lr=5e-5, n_fft=2048, g_sq=None, d_sq=None):
+    """One WSEGAN step with --misalign_pair, model.py:577-669 (LSGAN cost).  rolls: the
+    four roll lists in call order (D real, D fake, D misaligned, D fake-for-G); perm: the
+    batch permutation random.shuffle produced (model.py:598-600)."""
+    G = _leafs(g_sd)
+    D = _leafs(d_sd)
+    B = clean.size(0)
+    ones, zeros = torch.ones(B, 1, dtype=clean.dtype), torch.zeros(B, 1, dtype=clean.dtype)
+    d_real = discriminator_forward(D, torch.cat((clean, noisy), 1), rolls[0], strides)
+    Genh = generator_forward(G, noisy, z, strides)
+    d_fake = discriminator_forward(D, torch.cat((Genh.detach(), noisy), 1), rolls[1], strides)
+    d_loss = F.mse_loss(d_fake, zeros) + F.mse_loss(d_real, ones)
+    d_shuf = discriminator_forward(D, torch.cat((clean, clean[perm]), 1), rolls[2], strides)
+    d_loss = (d_loss + F.mse_loss(d_shuf, zeros)) * (1 / 3)
+    dkeys = [k for k in D if _is_param(k)]
+    dgr = torch.autograd.grad(d_loss, [D[k] for k in dkeys])
+    d_sq = d_sq or {k: torch.zeros_like(D[k]) for k in dkeys}
+    with torch.no_grad():
+        for k, g in zip(dkeys, dgr):
+            rmsprop_update(D[k], g, d_sq[k], lr)
+    d_fake_ = discriminator_forward(D, torch.cat((Genh, noisy), 1), rolls[3], strides)
+    g_adv = F.mse_loss(d_fake_, ones)
+    pow_loss = pow_weight * F.l1_loss(stft_pow_db(Genh, n_fft), stft_pow_db(clean, n_fft))
+    mask = torch.zeros(B, 1, Genh.size(2), dtype=clean.dtype)
+    for i, n in enumerate(names):
+        if 'additive' in n:
+            mask[i, 0, :] = 1.0
+    den_loss = l1_weight * F.l1_loss(Genh * mask, clean * mask)
+    gkeys = [k for k in G if G[k].requires_grad]
+    ggr = torch.autograd.grad(g_adv + pow_loss + den_loss, [G[k] for k in gkeys])
+    g_sq = g_sq or {k: torch.zeros_like(G[k]) for k in gkeys}
+    with torch.no_grad():
+        for k, g in zip(gkeys, ggr):
+            rmsprop_update(G[k], g, g_sq[k], lr)
+    return {'G': {k: v.detach() for k, v in G.items()}, 'D': {k: v.detach() for k, v in D.items()},
+            'g_sq': g_sq, 'd_sq': d_sq, 'd_loss': d_loss.detach(), 'g_adv': g_adv.detach(),
+            'pow_loss': pow_loss.detach(), 'den_loss': den_loss.detach(), 'Genh': Genh.detach()}

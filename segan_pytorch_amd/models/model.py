@@ -99,7 +99,7 @@ class SEGAN(Model):
                                skip_kwidth=opts.skip_kwidth)
         else:
             self.G = generator
-        self.G.apply(self._init_fn())
+        self.G.apply(weights_init)
         if discriminator is None:
             dkwidth = opts.gkwidth if opts.dkwidth is None else opts.dkwidth
             self.D = Discriminator(2, opts.denc_fmaps, dkwidth, poolings=opts.denc_poolings,
@@ -108,10 +108,7 @@ class SEGAN(Model):
                                    sinc_conv=opts.sinc_conv)
         else:
             self.D = discriminator
-        self.D.apply(self._init_fn())
-
-    def _init_fn(self):
-        return weights_init
+        self.D.apply(weights_init)
 
     # ---- inference --------------------------------------------------------------------
     def generate(self, inwav, z=None, device='cpu'):
@@ -246,19 +243,141 @@ class SEGAN(Model):
 
 
 class WSEGAN(SEGAN):
-    """Placeholder for the WSEGAN variant (model.py:509-766)."""
+    """Whispered-speech SEGAN variant (model.py:509-766): one summed discriminator loss
+    per step with an optional misaligned / interference fake pair, and a generator loss
+    of LSGAN + STFT log-power L1 + masked L1.  All conv/deconv/BN/dense work runs on the
+    HIP path; the STFT of the power loss uses ``torch.stft`` (rocFFT) — it is not yet a
+    native kernel ("out of scope / next")."""
 
     def __init__(self, opts, name='WSEGAN', generator=None, discriminator=None):
+        self.lbd = 1
+        self.critic_iters = 1
         self.misalign_pair = opts.misalign_pair
         self.interf_pair = opts.interf_pair
         self.pow_weight = opts.pow_weight
         self.vanilla_gan = opts.vanilla_gan
         self.n_fft = opts.n_fft
-        super(WSEGAN, self).__init__(opts, name=name, generator=generator,
-                                     discriminator=discriminator)
+        if self.vanilla_gan:
+            raise NotImplementedError('--vanilla_gan (BCE-with-logits cost, model.py:582-583) is '
+                                      'not implemented; the LSGAN cost is')
+        # like the reference: SEGAN.__init__ builds and initialises with weights_init
+        # (consuming the same RNG draws), then both nets are re-initialised Xavier-uniform
+        super(WSEGAN, self).__init__(opts, name, None, None)
+        self.G.apply(wsegan_weights_init)
+        self.D.apply(wsegan_weights_init)
 
-    def _init_fn(self):
-        return wsegan_weights_init
+    def sample_dloader(self, dloader, device='cpu'):
+        """A fresh iterator every step, first batch only (model.py:526-535)."""
+        uttname, clean, noisy, slice_idx = next(iter(dloader))
+        return (uttname, clean.unsqueeze(1).to(device), noisy.unsqueeze(1).to(device),
+                slice_idx.to(device))
 
-    def train(self, *args, **kwargs):
-        raise NotImplementedError('WSEGAN.train (model.py:537-753) is not implemented yet')
+    def _pow_db(self, x):
+        """10*log10(|STFT|^2 + 10e-20), rect window 320 / hop 160 / normalized
+        (model.py:640-653; torch.norm(stft, 2, dim=3) of the legacy real view = abs)."""
+        st = torch.stft(x.squeeze(1), n_fft=min(x.size(-1), self.n_fft), hop_length=160,
+                        win_length=320, normalized=True, return_complex=True)
+        return 10 * torch.log10(st.abs() ** 2 + 10e-20)
+
+    def wgan_step(self, uttname, clean, noisy, Gopt, Dopt, l1_weight, z=None):
+        """One WSEGAN step (model.py:577-669).  Returns (d_loss, G_cost, pow_loss,
+        den_loss) as device scalars."""
+        from random import shuffle
+        cost = losses.MSELoss()
+        bsz = clean.size(0)
+        Dopt.zero_grad()
+        d_real, _ = self.infer_D(clean, noisy)
+        d_real_loss = cost(d_real.view(-1), 1.0)
+        Genh = self.infer_G(noisy, clean, z=z)
+        d_fake, _ = self.infer_D(Genh.detach(), noisy)
+        d_fake_loss = cost(d_fake.view(-1), 0.0)
+        d_weight = 0.5
+        d_loss = d_fake_loss + d_real_loss
+        if self.misalign_pair:
+            perm = list(range(bsz))
+            shuffle(perm)      # same RNG draws as shuffling the chunk list (model.py:598-600)
+            clean_shuf = clean[torch.as_tensor(perm, device=clean.device)]
+            d_fake_shuf, _ = self.infer_D(clean, clean_shuf)
+            d_loss = d_loss + cost(d_fake_shuf.view(-1), 0.0)
+            d_weight = 1 / 3
+        if self.interf_pair:
+            from scipy import signal
+            freqs, amps = [250, 1000, 4000], [0.01, 0.05, 0.1, 1]
+            t = np.linspace(0, 2, 32000)
+            squares = []
+            for _ in range(bsz):
+                f_ = random.choice(freqs)
+                a_ = random.choice(amps)
+                sq = a_ * signal.square(2 * np.pi * f_ * t)
+                squares.append(torch.FloatTensor(sq[:clean.size(-1)].reshape((1, -1))))
+            squares = torch.cat(squares, dim=0).unsqueeze(1).to(clean.device)
+            d_fake_inter, _ = self.infer_D(clean + squares, noisy)
+            d_loss = d_loss + cost(d_fake_inter.view(-1), 0.0)
+            d_weight = 1 / 4
+        d_loss = d_weight * d_loss
+        d_loss.backward()
+        sdist.allreduce_grads(Dopt)
+        Dopt.step()
+
+        Gopt.zero_grad()
+        with _frozen(self.D):
+            d_fake_, _ = self.infer_D(Genh, noisy)
+            g_adv_loss = cost(d_fake_.view(-1), 1.0)
+            pow_loss = self.pow_weight * losses.l1_loss(self._pow_db(Genh), self._pow_db(clean))
+            G_cost = g_adv_loss + pow_loss
+            if l1_weight > 0:
+                mask = torch.zeros(bsz, 1, Genh.size(2), device=Genh.device)
+                for utt_i, uttn in enumerate(uttname):
+                    if 'additive' in uttn:
+                        mask[utt_i, 0, :] = 1.
+                den_loss = l1_weight * losses.l1_loss(Genh * mask, clean * mask)
+                G_cost = G_cost + den_loss
+            else:
+                den_loss = torch.zeros((), device=Genh.device)
+            G_cost.backward()
+        sdist.allreduce_grads(Gopt)
+        Gopt.step()
+        return d_loss, G_cost, pow_loss, den_loss
+
+    def train(self, opts, dloader, criterion, l1_init, l1_dec_step, l1_dec_epoch, log_freq,
+              va_dloader=None, device='cpu'):
+        self.writer = SummaryWriter(os.path.join(opts.save_path, 'train'))
+        Gopt, Dopt = self.build_optimizers(opts)
+        self.G.optim, self.D.optim = Gopt, Dopt
+        sdist.broadcast_params(self.G)
+        sdist.broadcast_params(self.D)
+        is_main = sdist.rank() == 0
+        eoe_g_saver = Saver(self.G, opts.save_path, max_ckpts=3, optimizer=Gopt, prefix='EOE_G-')
+        eoe_d_saver = Saver(self.D, opts.save_path, max_ckpts=3, optimizer=Dopt, prefix='EOE_D-')
+        l1_weight = l1_init     # never decays here (model.py:655-667)
+        timings = []
+        self.G.train()
+        self.D.train()
+        for iteration in range(1, opts.epoch * len(dloader) + 1):
+            beg_t = timeit.default_timer()
+            uttname, clean, noisy, _ = self.sample_dloader(dloader, device)
+            d_loss, G_cost, pow_loss, den_loss = self.wgan_step(uttname, clean, noisy, Gopt, Dopt,
+                                                                l1_weight)
+            timings.append(timeit.default_timer() - beg_t)
+            if is_main and iteration % log_freq == 0:
+                print('Iter {}/{} ({} bpe) d_loss:{:.4f}, g_loss: {:.4f}, pow_loss: {:.4f}, '
+                      'den_loss: {:.4f} btime: {:.4f} s, mbtime: {:.4f} s'.format(
+                          iteration, len(dloader) * opts.epoch, len(dloader), d_loss.item(),
+                          G_cost.item(), pow_loss.item(), den_loss.item(), timings[-1],
+                          np.mean(timings)))
+                self.writer.add_scalar('D_loss', d_loss.item(), iteration)
+                self.writer.add_scalar('G_loss', G_cost.item(), iteration)
+            if is_main and iteration % len(dloader) == 0:
+                self.G.save(self.save_path, iteration, saver=eoe_g_saver)
+                self.D.save(self.save_path, iteration, saver=eoe_d_saver)
+
+    def generate(self, inwav, z=None, device=None):
+        """Whole-utterance inference in one fully-convolutional pass (model.py:755-766)."""
+        self.G.eval()
+        ori_len = inwav.size(2)
+        pad = (-ori_len) % 1024
+        p_wav = torch.nn.functional.pad(inwav, (0, pad)) if pad else inwav
+        with torch.no_grad():
+            c_res, hall = self.infer_G(p_wav.contiguous(), z=z, ret_hid=True)
+        c_res = c_res[0, 0, :ori_len].cpu().data.numpy()
+        return de_emphasize(c_res, self.preemph), hall

@@ -36,6 +36,21 @@ def tiny_s2():
 
 
 @pytest.fixture(scope='session')
+def tiny_wsegan2():
+    return load_golden('tiny_wsegan2.pt')
+
+
+def draw_rolls(n_layers, phase_shift):
+    """The python-`random` draws of one Discriminator.forward (discriminator.py:159-163)."""
+    import random
+    out = []
+    for _ in range(n_layers):
+        s = random.randint(1, phase_shift)
+        out.append(s if random.random() > 0.5 else -s)
+    return out
+
+
+@pytest.fixture(scope='session')
 def segan_plus_b2():
     return load_golden('segan_plus_b2.pt')
 

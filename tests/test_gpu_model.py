@@ -291,3 +291,31 @@ def test_blocks_standalone_match_oracle():
     assert max_rel(yq, yr) < ACT_TOL
     assert max_rel(xqg.grad, xqd.grad) < GRAD_TOL
     assert max_rel(db.deconv.weight.grad, sd['deconv.weight'].grad) < GRAD_TOL
+
+
+def test_wsegan_literal_train_matches_reference(tmp_path):
+    """WSEGAN.train with --misalign_pair on the GPU against the reference's literal
+    WSEGAN.train (two iterations; same host RNG streams)."""
+    from conftest import load_golden
+    from segan_pytorch_amd.models import WSEGAN
+    fx = load_golden('tiny_wsegan2.pt')
+    o = dict(fx['opts'])
+    o['save_path'] = str(tmp_path)
+    o['epoch'] = fx['iters']
+    m = WSEGAN(SimpleNamespace(**o))
+    m.G.load_state_dict(fx['G0'])
+    m.D.load_state_dict(fx['D0'])
+    m = m.to(DEV)
+    loader = [[fx['names'], fx['clean'], fx['noisy'], torch.zeros(3)]]
+    random.seed(fx['seed'])
+    np.random.seed(fx['seed'])
+    torch.manual_seed(fx['seed'])
+    m.train(SimpleNamespace(**o), loader, None, o['l1_weight'], o['l1_dec_step'],
+            o['l1_dec_epoch'], 1000, va_dloader=None, device=DEV)
+    for name, net, fin in (('G', m.G, fx['G_final']), ('D', m.D, fx['D_final'])):
+        sd = net.state_dict()
+        for k, v in fin.items():
+            if not torch.is_floating_point(v) or (name == 'D' and k.endswith(NOISE_KEYS)):
+                continue
+            err = (sd[k].cpu() - v).abs().max().item()
+            assert err < 2 * STEP_TOL, (name, k, err)

@@ -153,3 +153,28 @@ def test_blocks_standalone(tiny_step):
                     4).square().sum().backward()
     assert max_rel(xqg.grad, xqd.grad) < 1e-4
     assert max_rel(db.deconv.weight.grad, sd['deconv.weight'].grad) < 1e-4
+
+
+def test_wsegan_literal_train(tiny_wsegan2, tmp_path):
+    """WSEGAN.train (misalign pair, STFT power loss, masked L1) against the reference's
+    literal WSEGAN.train."""
+    from segan_pytorch_amd.models import WSEGAN
+    fx = tiny_wsegan2
+    o = dict(fx['opts'])
+    o['save_path'] = str(tmp_path)
+    o['epoch'] = fx['iters']
+    m = WSEGAN(SimpleNamespace(**o))
+    m.G.load_state_dict(fx['G0'])
+    m.D.load_state_dict(fx['D0'])
+    loader = [[fx['names'], fx['clean'], fx['noisy'], torch.zeros(3)]]
+    random.seed(fx['seed'])
+    np.random.seed(fx['seed'])
+    torch.manual_seed(fx['seed'])
+    m.train(SimpleNamespace(**o), loader, None, o['l1_weight'], o['l1_dec_step'],
+            o['l1_dec_epoch'], 1000, va_dloader=None, device='cpu')
+    for name, net, fin in (('G', m.G, fx['G_final']), ('D', m.D, fx['D_final'])):
+        sd = net.state_dict()
+        for k, v in fin.items():
+            if not torch.is_floating_point(v) or (name == 'D' and k.endswith(NOISE_KEYS)):
+                continue
+            assert (sd[k] - v).abs().max().item() < 2 * STEP_TOL, (name, k)

@@ -137,3 +137,34 @@ def test_default_net_init_and_step(segan_plus_b2):
         _chk(res['d_grads'][k], c, 1e-4)
     for k, c in fx['g_grads'].items():
         _chk(res['g_grads'][k], c, 1e-4)
+
+
+def test_wsegan_literal_train_replay(tiny_wsegan2):
+    """The oracle's WSEGAN step replayed against the reference's literal WSEGAN.train
+    (--misalign_pair, two iterations)."""
+    from conftest import draw_rolls
+    fx = tiny_wsegan2
+    o = fx['opts']
+    st = o['genc_poolings']
+    random.seed(fx['seed'])
+    torch.manual_seed(fx['seed'])
+    clean, noisy = fx['clean'].unsqueeze(1), fx['noisy'].unsqueeze(1)
+    G, D, g_sq, d_sq = fx['G0'], fx['D0'], None, None
+    for _ in range(fx['iters']):
+        r0 = draw_rolls(len(st), o['phase_shift'])
+        z = torch.randn(clean.size(0), o['z_dim'], 16)
+        r1 = draw_rolls(len(st), o['phase_shift'])
+        perm = list(range(clean.size(0)))
+        random.shuffle(perm)
+        r2 = draw_rolls(len(st), o['phase_shift'])
+        r3 = draw_rolls(len(st), o['phase_shift'])
+        res = O.wsegan_step(G, D, clean, noisy, z, [r0, r1, r2, r3], perm, fx['names'], st,
+                            l1_weight=o['l1_weight'], pow_weight=o['pow_weight'], lr=o['g_lr'],
+                            n_fft=o['n_fft'], g_sq=g_sq, d_sq=d_sq)
+        G, D, g_sq, d_sq = res['G'], res['D'], res['g_sq'], res['d_sq']
+    for k, v in fx['G_final'].items():
+        assert (G[k] - v).abs().max().item() < 5e-5, k   # 10 % of an RMSprop step
+    for k, v in fx['D_final'].items():
+        if not torch.is_floating_point(v) or k.endswith(('conv.bias', 'norm.running_mean')):
+            continue
+        assert (D[k] - v).abs().max().item() < 5e-5, k

@@ -1,0 +1,167 @@
+#!/usr/bin/env python
+"""Train SEGAN+ / WSEGAN on MI355X — the reference's train.py entry point (same flags,
+same defaults, same `train.opts` dump) driving the HIP engine in `segan_pytorch_amd`.
+
+    python train.py --save_path ckpt_segan+ --clean_trainset ... --noisy_trainset ... \
+        --batch_size 300 --no_train_gen
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 train.py ...
+
+Additions over the reference: `--synthetic N` trains on N fixed-seed synthetic chunk
+pairs (no dataset needed), and under torch.distributed.run every rank trains on its
+shard of each epoch with RCCL gradient averaging.
+"""
+import argparse
+import json
+import os
+import random
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader
+
+from segan_pytorch_amd import distributed as sdist
+from segan_pytorch_amd import losses
+from segan_pytorch_amd.datasets import SEDataset, SyntheticSEDataset, collate_fn
+from segan_pytorch_amd.models import SEGAN, WSEGAN
+
+_FMAPS = [64, 128, 256, 512, 1024]
+_POOLS = [4, 4, 4, 4, 4]
+
+# (flag, kwargs) — names and defaults are the reference's (train.py:101-247)
+FLAGS = [
+    ('--save_path', dict(type=str, default='seganv1_ckpt')),
+    ('--d_pretrained_ckpt', dict(type=str, default=None)),
+    ('--g_pretrained_ckpt', dict(type=str, default=None)),
+    ('--cache_dir', dict(type=str, default='data_cache')),
+    ('--clean_trainset', dict(type=str, default='data/clean_trainset')),
+    ('--noisy_trainset', dict(type=str, default='data/noisy_trainset')),
+    ('--clean_valset', dict(type=str, default=None)),
+    ('--noisy_valset', dict(type=str, default=None)),
+    ('--h5_data_root', dict(type=str, default=None)),
+    ('--h5', dict(action='store_true', default=False)),
+    ('--data_stride', dict(type=float, default=0.5)),
+    ('--seed', dict(type=int, default=111)),
+    ('--epoch', dict(type=int, default=100)),
+    ('--patience', dict(type=int, default=100)),
+    ('--batch_size', dict(type=int, default=100)),
+    ('--save_freq', dict(type=int, default=50)),
+    ('--slice_size', dict(type=int, default=16384)),
+    ('--opt', dict(type=str, default='rmsprop')),
+    ('--l1_dec_epoch', dict(type=int, default=100)),
+    ('--l1_weight', dict(type=float, default=100)),
+    ('--l1_dec_step', dict(type=float, default=1e-5)),
+    ('--g_lr', dict(type=float, default=0.00005)),
+    ('--d_lr', dict(type=float, default=0.00005)),
+    ('--preemph', dict(type=float, default=0.95)),
+    ('--max_samples', dict(type=int, default=None)),
+    ('--eval_workers', dict(type=int, default=2)),
+    ('--slice_workers', dict(type=int, default=1)),
+    ('--num_workers', dict(type=int, default=1)),
+    ('--no-cuda', dict(action='store_true', default=False)),
+    ('--random_scale', dict(type=float, nargs='+', default=[1])),
+    ('--no_train_gen', dict(action='store_true', default=False)),
+    ('--preemph_norm', dict(action='store_true', default=False)),
+    ('--wsegan', dict(action='store_true', default=False)),
+    ('--aewsegan', dict(action='store_true', default=False)),
+    ('--vanilla_gan', dict(action='store_true', default=False)),
+    ('--no_bias', dict(action='store_true', default=False)),
+    ('--n_fft', dict(type=int, default=2048)),
+    ('--reg_loss', dict(type=str, default='l1_loss')),
+    ('--skip_merge', dict(type=str, default='concat')),
+    ('--skip_type', dict(type=str, default='alpha')),
+    ('--skip_init', dict(type=str, default='one')),
+    ('--skip_kwidth', dict(type=int, default=11)),
+    ('--gkwidth', dict(type=int, default=31)),
+    ('--genc_fmaps', dict(type=int, nargs='+', default=list(_FMAPS))),
+    ('--genc_poolings', dict(type=int, nargs='+', default=list(_POOLS))),
+    ('--z_dim', dict(type=int, default=1024)),
+    ('--gdec_fmaps', dict(type=int, nargs='+', default=None)),
+    ('--gdec_poolings', dict(type=int, nargs='+', default=None)),
+    ('--gdec_kwidth', dict(type=int, default=None)),
+    ('--gnorm_type', dict(type=str, default=None)),
+    ('--no_z', dict(action='store_true', default=False)),
+    ('--no_skip', dict(action='store_true', default=False)),
+    ('--pow_weight', dict(type=float, default=0.001)),
+    ('--misalign_pair', dict(action='store_true', default=False)),
+    ('--interf_pair', dict(action='store_true', default=False)),
+    ('--denc_fmaps', dict(type=int, nargs='+', default=list(_FMAPS))),
+    ('--dpool_type', dict(type=str, default='none')),
+    ('--dpool_slen', dict(type=int, default=16)),
+    ('--dkwidth', dict(type=int, default=None)),
+    ('--denc_poolings', dict(type=int, nargs='+', default=list(_POOLS))),
+    ('--dnorm_type', dict(type=str, default='bnorm')),
+    ('--phase_shift', dict(type=int, default=5)),
+    ('--sinc_conv', dict(action='store_true', default=False)),
+    # ---- additions ----
+    ('--synthetic', dict(type=int, default=0,
+                         help='train on this many fixed-seed synthetic chunk pairs')),
+]
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description=__doc__,
+                                formatter_class=argparse.RawDescriptionHelpFormatter)
+    for flag, kw in FLAGS:
+        p.add_argument(flag, **kw)
+    return p
+
+
+def main(opts):
+    rank, world, local = sdist.init_from_env()
+    use_cuda = torch.cuda.is_available() and not opts.no_cuda
+    if not use_cuda:
+        raise SystemExit('segan_pytorch_amd trains only on an MI355X (HIP) device: no GPU is '
+                         'visible (and there is no CPU fallback)')
+    device = torch.device('cuda', local if world > 1 else 0)
+    torch.cuda.set_device(device)
+    opts.cuda = True
+    random.seed(opts.seed)
+    np.random.seed(opts.seed)
+    torch.manual_seed(opts.seed)
+    torch.cuda.manual_seed_all(opts.seed)
+    if opts.aewsegan:
+        raise NotImplementedError('AEWSEGAN is broken in the reference (model.py:823) and is '
+                                  'not implemented')
+    segan = (WSEGAN if opts.wsegan else SEGAN)(opts)
+    segan.to(device)
+    print('Total model parameters: ', segan.get_n_params())
+    if opts.g_pretrained_ckpt is not None:
+        segan.G.load_pretrained(opts.g_pretrained_ckpt, True)
+    if opts.d_pretrained_ckpt is not None:
+        segan.D.load_pretrained(opts.d_pretrained_ckpt, True)
+    if opts.h5:
+        raise NotImplementedError('--h5 datasets are not implemented')
+    if opts.synthetic > 0:
+        dset = SyntheticSEDataset(opts.synthetic, opts.slice_size, seed=opts.seed)
+    else:
+        dset = SEDataset(opts.clean_trainset, opts.noisy_trainset, opts.preemph,
+                         cache_dir=opts.cache_dir, split='train', stride=opts.data_stride,
+                         slice_size=opts.slice_size, max_samples=opts.max_samples, verbose=True,
+                         preemph_norm=opts.preemph_norm, random_scale=opts.random_scale)
+    sampler = None
+    if world > 1:
+        from torch.utils.data.distributed import DistributedSampler
+        sampler = DistributedSampler(dset, num_replicas=world, rank=rank, shuffle=True,
+                                     seed=opts.seed, drop_last=True)
+    dloader = DataLoader(dset, batch_size=opts.batch_size, shuffle=(sampler is None),
+                         sampler=sampler, num_workers=opts.num_workers, pin_memory=True,
+                         collate_fn=collate_fn, drop_last=(world > 1))
+    if opts.clean_valset is not None:
+        raise NotImplementedError('validation (CompositeEval / PESQ binary) is outside the '
+                                  'accelerated path')
+    # per-rank host RNG streams for z and the phase shifts
+    random.seed(opts.seed + rank)
+    torch.manual_seed(opts.seed + rank)
+    segan.train(opts, dloader, losses.MSELoss(), opts.l1_weight, opts.l1_dec_step,
+                opts.l1_dec_epoch, opts.save_freq, va_dloader=None, device=device)
+
+
+if __name__ == '__main__':
+    opts = build_parser().parse_args()
+    opts.bias = not opts.no_bias
+    os.makedirs(opts.save_path, exist_ok=True)
+    if int(os.environ.get('RANK', '0')) == 0:
+        with open(os.path.join(opts.save_path, 'train.opts'), 'w') as cfg_f:
+            cfg_f.write(json.dumps(vars(opts), indent=2))
+        print('Parsed arguments: ', json.dumps(vars(opts), indent=2))
+    main(opts)
