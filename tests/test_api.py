@@ -1,0 +1,155 @@
+"""Drop-in boundary checks that need no GPU: the C-ABI library loads and exports every
+symbol include/segan_hip.h declares, the Python surface mirrors the reference's
+(constructor signatures, state_dict keys, CLI flags, checkpoint format), and the product
+path refuses to run without a HIP device (no fallback)."""
+import inspect
+import json
+import os
+import re
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from segan_pytorch_amd import _lib
+    hdr = open(os.path.join(ROOT, 'include', 'segan_hip.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    declared = set(re.findall(r'\b(segan_[a-z0-9_]+)\s*\(', hdr))
+    declared -= {'segan_src'}
+    assert len(declared) >= 25
+    lib = _lib.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), 'libsegan_hip.so does not export ' + name
+        assert name in _lib.SIGNATURES, 'no ctypes signature for ' + name
+    assert set(_lib.SIGNATURES) == declared
+    assert lib.segan_abi_version() == _lib.ABI_VERSION
+    # argument validation happens before any launch and reports through segan_last_error
+    assert lib.segan_packed_f_bytes(64, 64, 3) == 0
+    rc = lib.segan_fill(None, 0.0, 10, None)
+    assert rc != 0 and b'fill' in lib.segan_last_error()
+
+
+def test_constructor_signatures_match_the_reference():
+    from segan_pytorch_amd.models import Discriminator, GConv1DBlock, GDeconv1DBlock, Generator
+    g = list(inspect.signature(Generator.__init__).parameters)
+    assert g == ['self', 'ninputs', 'fmaps', 'kwidth', 'poolings', 'dec_fmaps', 'dec_kwidth',
+                 'dec_poolings', 'z_dim', 'no_z', 'skip', 'bias', 'skip_init', 'skip_dropout',
+                 'skip_type', 'norm_type', 'skip_merge', 'skip_kwidth', 'name']
+    d = list(inspect.signature(Discriminator.__init__).parameters)
+    assert d == ['self', 'ninputs', 'fmaps', 'kwidth', 'poolings', 'pool_type', 'pool_slen',
+                 'norm_type', 'bias', 'phase_shift', 'sinc_conv']
+    assert list(inspect.signature(GConv1DBlock.__init__).parameters) == \
+        ['self', 'ninp', 'fmaps', 'kwidth', 'stride', 'bias', 'norm_type']
+    assert list(inspect.signature(GDeconv1DBlock.__init__).parameters) == \
+        ['self', 'ninp', 'fmaps', 'kwidth', 'stride', 'bias', 'norm_type', 'act']
+    assert list(inspect.signature(Generator.forward).parameters) == ['self', 'x', 'z', 'ret_hid']
+
+
+def test_state_dict_keys_and_shapes_match_reference(tiny_step, segan_plus_b2):
+    from segan_pytorch_amd.models import SEGAN
+    for fx, has_w in ((tiny_step, True), (segan_plus_b2, False)):
+        m = SEGAN(SimpleNamespace(**fx['opts']))
+        if has_w:
+            assert list(m.G.state_dict().keys()) == list(fx['G0'].keys())
+            assert list(m.D.state_dict().keys()) == list(fx['D0'].keys())
+            for k, v in fx['G0'].items():
+                assert m.G.state_dict()[k].shape == v.shape, k
+            for k, v in fx['D0'].items():
+                assert m.D.state_dict()[k].shape == v.shape, k
+        else:
+            assert list(m.G.state_dict().keys()) == list(fx['init_G'].keys())
+            assert list(m.D.state_dict().keys()) == list(fx['init_D'].keys())
+            assert m.G.get_n_params() == 64770561 and m.D.get_n_params() == 25825793
+
+
+def test_cli_flags_cover_the_reference_train_opts(segan_plus_b2):
+    import train
+    ns = vars(train.build_parser().parse_args([]))
+    ref_keys = set(segan_plus_b2['opts'].keys()) - {'l1_loss', 'bias', 'reg_loss', 'save_path'}
+    missing = ref_keys - set(ns.keys())
+    assert not missing, missing
+    assert ns['batch_size'] == 100 and ns['gkwidth'] == 31 and ns['genc_poolings'] == [4] * 5
+    assert ns['skip_merge'] == 'concat' and ns['dnorm_type'] == 'bnorm' and ns['phase_shift'] == 5
+    import clean
+    c = vars(clean.build_parser().parse_args([]))
+    assert set(c) == {'g_pretrained_ckpt', 'test_files', 'h5', 'seed', 'synthesis_path', 'cuda',
+                      'soundfile', 'cfg_file'}
+
+
+def test_no_cpu_fallback(tiny_step):
+    from segan_pytorch_amd import ops
+    from segan_pytorch_amd.models import SEGAN
+    m = SEGAN(SimpleNamespace(**tiny_step['opts']))
+    with pytest.raises(RuntimeError, match='MI355X'):
+        m.G(tiny_step['noisy'], z=tiny_step['z'])
+    with pytest.raises(RuntimeError, match='MI355X'):
+        m.D(torch.cat((tiny_step['clean'], tiny_step['noisy']), 1))
+    Gopt, Dopt = m.build_optimizers(SimpleNamespace(**tiny_step['opts']))
+    with pytest.raises(RuntimeError, match='MI355X'):
+        Gopt.step()
+    with pytest.raises(RuntimeError):
+        ops.Src(torch.zeros(1, 1, 64))
+
+
+def test_argument_validation_mirrors_reference_errors():
+    from segan_pytorch_amd.models import Discriminator, GConv1DBlock, Generator
+    with pytest.raises(ValueError):          # discriminator.py:83-86
+        Discriminator(2, [8, 16], 31, [4, 4], pool_slen=None)
+    with pytest.raises(TypeError):           # modules.py:17-18
+        GConv1DBlock(1, 4, 31, stride=4, norm_type='bogus')
+    with pytest.raises(AssertionError):      # generator.py:105
+        Generator(1, (8, 16), 31, [4, 4])
+    g = Generator(1, [8, 16], 31, [4, 4], z_dim=8, skip_merge='concat')
+    with pytest.raises(ValueError):
+        g(torch.zeros(1, 1, 30))             # not divisible by the pooling
+    with pytest.raises(ValueError):          # generator.py:200-202
+        g(torch.zeros(1, 1, 32), z=torch.zeros(1, 8))
+    for bad in (dict(norm_type='snorm'), dict(sinc_conv=True), dict(pool_type='gmax')):
+        with pytest.raises(NotImplementedError):
+            Discriminator(2, [8, 16], 31, [4, 4], pool_slen=2, **bad)
+
+
+def test_flat_arena_optimizer_state_dict_format():
+    from segan_pytorch_amd import optim as soptim
+    ps = [torch.nn.Parameter(torch.randn(3, 2, 5)), torch.nn.Parameter(torch.randn(7))]
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    ours, ref = soptim.RMSprop(qs, lr=5e-5), torch.optim.RMSprop(ps, lr=5e-5)
+    # parameters became views of one arena, values preserved, grads pre-allocated
+    assert all(torch.equal(p.detach(), q.detach()) for p, q in zip(ps, qs))
+    assert qs[1].data_ptr() == ours.flat_param.data_ptr() + 4 * ours._offsets[1]
+    assert all(q.grad is not None and float(q.grad.abs().sum()) == 0 for q in qs)
+    for p in ps:
+        p.grad = torch.zeros_like(p)
+    ref.step()
+    sd, rsd = ours.state_dict(), ref.state_dict()
+    assert set(sd['state'][0].keys()) == set(rsd['state'][0].keys()) == {'step', 'square_avg'}
+    for k in ('lr', 'alpha', 'eps', 'momentum', 'centered', 'weight_decay'):
+        assert sd['param_groups'][0][k] == rsd['param_groups'][0][k]
+    ours.load_state_dict(rsd)           # a torch RMSprop checkpoint loads
+    assert ours.state[qs[0]]['square_avg'].data_ptr() == \
+        ours._flat_state['square_avg'].data_ptr()
+    ours.zero_grad()
+    # a gradient re-allocated behind our back is folded into the arena again
+    qs[0].grad = torch.ones_like(qs[0])
+    ours._resync()
+    assert qs[0].grad.data_ptr() == ours.flat_grad.data_ptr()
+    assert float(ours.flat_grad[:30].sum()) == 30.0
+
+
+def test_saver_rotation_matches_reference_format(tmp_path):
+    from segan_pytorch_amd.models import Generator, Saver
+    g = Generator(1, [4, 8], 31, [4, 4], z_dim=8, skip_merge='concat')
+    sv = Saver(g, str(tmp_path), max_ckpts=2, prefix='EOE_G-')
+    for step in (1, 2, 3, 4, 5):
+        sv.save('Generator', step)
+    idx = json.load(open(os.path.join(str(tmp_path), 'EOE_G-checkpoints')))
+    assert idx['current'] == 'EOE_G-Generator-5.ckpt'
+    files = sorted(f for f in os.listdir(str(tmp_path)) if f.startswith('weights_'))
+    # the reference drops the oldest once MORE than max_ckpts are listed (core.py:40-51)
+    assert files == ['weights_EOE_G-Generator-{}.ckpt'.format(s) for s in (3, 4, 5)]
+    ck = torch.load(os.path.join(str(tmp_path), files[-1]), weights_only=False)
+    assert set(ck.keys()) == {'step', 'state_dict'} and ck['step'] == 5
