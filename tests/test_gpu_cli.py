@@ -1,0 +1,42 @@
+"""End-to-end entry points on the GPU: train.py (synthetic data) writes reference-format
+checkpoints + train.opts, clean.py enhances a wav with them."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+from scipy.io import wavfile
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_train_then_clean(tmp_path):
+    ck = str(tmp_path / 'ckpt')
+    cmd = [sys.executable, os.path.join(ROOT, 'train.py'), '--save_path', ck, '--synthetic', '8',
+           '--batch_size', '4', '--epoch', '1', '--save_freq', '1', '--no_train_gen',
+           '--genc_fmaps', '8', '16', '32', '--denc_fmaps', '8', '16', '32', '--genc_poolings',
+           '4', '4', '4', '--denc_poolings', '4', '4', '4', '--z_dim', '32', '--slice_size', '1024',
+           '--num_workers', '0']
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert 'btime' in out.stdout
+    opts = json.load(open(os.path.join(ck, 'train.opts')))
+    assert opts['bias'] is True and opts['batch_size'] == 4
+    names = os.listdir(ck)
+    g_ckpts = [n for n in names if n.startswith('weights_EOE_G-Generator-')]
+    assert g_ckpts and 'EOE_G-checkpoints' in names and 'EOE_D-checkpoints' in names
+    # a 1.3-chunk utterance of int16 noise -> clean.py
+    wav_dir, out_dir = tmp_path / 'noisy', tmp_path / 'enh'
+    wav_dir.mkdir()
+    rng = np.random.default_rng(0)
+    wavfile.write(str(wav_dir / 'a.wav'), 16000, (rng.standard_normal(21000) * 3000).astype(np.int16))
+    cmd = [sys.executable, os.path.join(ROOT, 'clean.py'), '--g_pretrained_ckpt',
+           os.path.join(ck, g_ckpts[0]), '--cfg_file', os.path.join(ck, 'train.opts'),
+           '--test_files', str(wav_dir), '--synthesis_path', str(out_dir), '--cuda']
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rate, enh = wavfile.read(str(out_dir / 'a.wav'))
+    assert rate == 16000 and enh.shape[0] == 21000 and np.isfinite(enh).all()
