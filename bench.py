@@ -123,9 +123,11 @@ class KernelTimer(object):
         return out
 
 
-def cpu_baseline(steps=2, B=16):
-    """Time the CPU oracle's GAN step (a port of the reference path, oneDNN off as the
-    numerically trustworthy setting) on this host."""
+def cpu_baseline(B=48):
+    """Time the CPU oracle's GAN step (oracle/segan_oracle.py: the reference's path restated
+    on torch CPU ops) on this host's cores: one warm-up step + one timed step at batch B with
+    oneDNN off (the numerically trustworthy setting) and the same again with
+    oneDNN on (what a stock reference run would use); the FASTER of the two is reported."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import segan_oracle as O
     from segan_pytorch_amd.datasets import synthetic_pairs
@@ -133,26 +135,54 @@ def cpu_baseline(steps=2, B=16):
     opts = default_opts()
     random.seed(111); np.random.seed(111); torch.manual_seed(111)
     m = SEGAN(SimpleNamespace(**opts))
-    gsd = {k: v.detach() for k, v in m.G.state_dict().items()}
-    dsd = {k: v.detach() for k, v in m.D.state_dict().items()}
+    gsd0 = {k: v.detach() for k, v in m.G.state_dict().items()}
+    dsd0 = {k: v.detach() for k, v in m.D.state_dict().items()}
     clean, noisy = synthetic_pairs(B, 16384, 0)
     clean, noisy = clean.unsqueeze(1), noisy.unsqueeze(1)
     z = torch.randn(B, 1024, 16)
     rolls = [[1, -2, 3, -4, 5]] * 3
     st = opts['genc_poolings']
-    times = []
-    g_sq = d_sq = None
-    for i in range(steps + 1):
-        t0 = time.perf_counter()
-        res = O.gan_step(gsd, dsd, clean, noisy, z, rolls, st, 100.0, 5e-5, g_sq=g_sq, d_sq=d_sq)
-        dt = time.perf_counter() - t0
-        gsd, dsd, g_sq, d_sq = res['G'], res['D'], res['g_sq'], res['d_sq']
-        if i > 0:
-            times.append(dt)
-    per = sum(times) / len(times)
+    results = {}
+    for mode in (False, True):
+        torch.backends.mkldnn.enabled = mode
+        gsd, dsd, g_sq, d_sq = gsd0, dsd0, None, None
+        per = None
+        for i in range(2):
+            t0 = time.perf_counter()
+            res = O.gan_step(gsd, dsd, clean, noisy, z, rolls, st, 100.0, 5e-5, g_sq=g_sq,
+                             d_sq=d_sq)
+            per = time.perf_counter() - t0
+            gsd, dsd, g_sq, d_sq = res['G'], res['D'], res['g_sq'], res['d_sq']
+        results['onednn_on' if mode else 'onednn_off'] = per
+    torch.backends.mkldnn.enabled = False
+    best = min(results, key=results.get)
+    per = results[best]
     return dict(value=B / per, unit='chunks/s', cores=torch.get_num_threads(), kind='port',
-                sample='oracle GAN step (SEGAN+ default net), batch {}, mean of {} steps after 1 '
-                       'warm-up, {:.2f} s/step, oneDNN off'.format(B, steps, per))
+                sample='oracle GAN step (SEGAN+ default net, fp32) at batch {}: 1 warm-up + 1 timed '
+                       'step per setting; {:.2f} s/step oneDNN off, {:.2f} s/step oneDNN on; '
+                       'reported = {}'.format(B, results['onednn_off'], results['onednn_on'], best))
+
+
+def pmc_traffic(kernel_prefix):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_pmc_hbm_traffic.json: FETCH_SIZE and WRITE_SIZE in separate passes over this
+    same command; FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md)."""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_traffic.json')
+    if not os.path.exists(path):
+        return None
+    try:
+        ks = json.load(open(path))['kernels']
+        n = f = w = 0.0
+        for name, v in ks.items():
+            if kernel_prefix in name:
+                n += v['launches']
+                f += v['launches'] * v['fetch_kb_avg']
+                w += v['launches'] * v['write_kb_avg']
+        if n == 0:
+            return None
+        return (2.0 * f + w) * 1024.0 / n
+    except Exception:
+        return None
 
 
 def main():
@@ -246,7 +276,9 @@ def main():
                 line['roofline'] = {
                     'bound': 'mfma', 'kernel': 'corr_kernel (conv/deconv forward + data gradient)',
                     'achieved': c['tflops'], 'peak': PEAK_F32_MFMA_TF, 'unit': 'TFLOP/s',
-                    'frac': c['tflops'] / PEAK_F32_MFMA_TF, 'traffic': None,
+                    'frac': c['tflops'] / PEAK_F32_MFMA_TF, 'traffic': pmc_traffic('corr_kernel'),
+                    'traffic_unit': 'HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, '
+                                    'profiles/r01_pmc_hbm_traffic.json)',
                     'avg_launch_us': c['avg_us'], 'launches': c['launches'],
                     'gflop_per_launch': c['flops_per_launch'] / 1e9,
                     'share_of_step_time': c['total_ms'] / (1e3 * dt)}

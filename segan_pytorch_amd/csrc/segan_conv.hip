@@ -84,13 +84,22 @@ struct CorrArgs {
 // address is clamped to a valid element, so there is no branch and no wait between
 // them and they stay in flight under the MFMA loop; masking, the segan_src transform
 // and the LDS writes happen in store_chunk(), after the compute of the previous chunk.
-template <int MB, int NB, int U, bool IN_HI, bool OUT_HI, int MAXPOS, int KC>
+//
+// Tile geometry: MB rows x NB columns per 256-thread workgroup, waves WM x (4/WM).
+//   F form: rows = output channels m; waves 2x2.
+//   T form: rows = (phase r, channel n) with ALL S phases of MB/S channels in one tile and
+//           waves 1x4 (NB=128) so that one lane ends up holding the S consecutive output
+//           samples S*q..S*q+S-1 of a channel: full-line stores instead of stride-S ones.
+template <int MB, int NB, int WM, int U, bool IN_HI, bool OUT_HI, bool SHIFT, int MAXPOS, int KC>
 __global__ __launch_bounds__(256, 2) void corr_kernel(const CorrArgs a) {
   constexpr int S = 32 / U;
   constexpr int SI = IN_HI ? S : 1;   // indices per staged position
   constexpr int CV = KC / U;          // virtual channels per chunk
-  constexpr int NI = MB / 64;
-  constexpr int NJ = NB / 64;
+  constexpr int WN = 4 / WM;
+  constexpr int NI = MB / (32 * WM);
+  constexpr int NJ = NB / (32 * WN);
+  constexpr int NPT = MB / S;         // T form: channels per tile
+  static_assert(!OUT_HI || NPT % 32 == 0, "T-form tiles hold whole 32-row phase blocks");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int RLs = a.RLs;
@@ -100,21 +109,13 @@ __global__ __launch_bounds__(256, 2) void corr_kernel(const CorrArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, h = lane >> 5;
 
-  // Co-resident workgroups do identical work and would otherwise reach their staging /
-  // barrier phases together, idling the MFMA pipe; distinct static priorities let one
-  // run ahead and spread the phases.
-  if (a.prio_mode == 1) {
-    const unsigned hsh = (blockIdx.x * 2654435761u) >> 30;
-    if (hsh == 1) __builtin_amdgcn_s_setprio(1);
-    else if (hsh == 2) __builtin_amdgcn_s_setprio(2);
-    else if (hsh == 3) __builtin_amdgcn_s_setprio(3);
-  }
   const int rowtile = blockIdx.x / a.ncoltiles;
   const int coltile = blockIdx.x - rowtile * a.ncoltiles;
-  const int m0 = rowtile * MB;
+  const int m0 = rowtile * MB;          // F form: first row; T form: n0 = rowtile * NPT
+  const int n0 = rowtile * NPT;
   if (!OUT_HI) {
     // dual destination: skip tiles whose rows all go to a NULL destination
     if (a.out0 == nullptr && m0 + MB <= a.OC0) return;
@@ -123,8 +124,6 @@ __global__ __launch_bounds__(256, 2) void corr_kernel(const CorrArgs a) {
   const ColTile ct = make_coltile(coltile * NB, a.Tcols, NB);
 
   // ---- per-thread staging positions of the activation tile (fixed for all chunks) ----
-  // pos_off: element offset inside a channel row (clamped to 0 when masked)
-  // pos_bo0/1: element offset of the sample inside segment 0 / 1
   int pos_off[MAXPOS][SI];
   unsigned pos_ok[MAXPOS];
   int pos_bo0[MAXPOS], pos_bo1[MAXPOS];
@@ -162,18 +161,14 @@ __global__ __launch_bounds__(256, 2) void corr_kernel(const CorrArgs a) {
   int aoff[NI], boff[NJ], rsh[NI];
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
-    const int rloc = wm * (MB / 2) + 32 * i;
+    const int rloc = 32 * (wm * NI + i);
     aoff[i] = h * MB + rloc + l31;
-    rsh[i] = 0;
-    if (OUT_HI) {
-      const int r = (m0 + rloc) / a.NP;
-      rsh[i] = a.rowshift[r < S ? r : S - 1];
-    }
+    rsh[i] = SHIFT ? a.rowshift[rloc / NPT] : 0;
   }
   int col_b[NJ], col_t[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
-    const int cl = wn * (NB / 2) + 32 * j + l31;
+    const int cl = wn * (NB / WN) + 32 * j + l31;
     const int col = ct.col0 + cl;
     if (col < a.Ctot) {
       const int b = col / a.Tcols;
@@ -202,7 +197,9 @@ __global__ __launch_bounds__(256, 2) void corr_kernel(const CorrArgs a) {
   f32x4 wreg[NPASS];
   float ireg[CV][MAXPOS];
   const int wrow = tid / F4R, wc4 = tid % F4R;
-  const float* wbase = a.wp + (size_t)wrow * a.RP + m0 + 4 * wc4;
+  // global column of LDS column 4*wc4: F form m0 + c; T form phase-major (r*NP + n0 + nl)
+  const int wgcol = OUT_HI ? ((4 * wc4) / NPT) * a.NP + n0 + (4 * wc4) % NPT : m0 + 4 * wc4;
+  const float* wbase = a.wp + (size_t)wrow * a.RP + wgcol;
 
   auto load_chunk = [&](int ch) {
     const float* wsrc = wbase + (size_t)(ch * KC) * a.RP;
@@ -257,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void corr_kernel(const CorrArgs a) {
     const float* Il = Il0 + buf * (CV * RLs);
     // operands of step s+1 are read from LDS before the MFMAs of step s are issued
     // (two named register sets; everything is unrolled so all indices are static)
-    constexpr int NBI = OUT_HI ? NI : 1;
+    constexpr int NBI = SHIFT ? NI : 1;
     float av0[NI], av1[NI], bv0[NBI][NJ], bv1[NBI][NJ];
     auto read_step = [&](int s, float (&av)[NI], float (&bv)[NBI][NJ]) {
       const int kk = 2 * s;
@@ -269,18 +266,18 @@ __global__ __launch_bounds__(256, 2) void corr_kernel(const CorrArgs a) {
 #pragma unroll
       for (int i = 0; i < NBI; ++i)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) bv[i][j] = ir[boff[j] + (OUT_HI ? rsh[i] : 0)];
+        for (int j = 0; j < NJ; ++j) bv[i][j] = ir[boff[j] + (SHIFT ? rsh[i] : 0)];
     };
     auto mma_step = [&](const float (&av)[NI], const float (&bv)[NBI][NJ]) {
 #pragma unroll
       for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[OUT_HI ? i : 0][j], acc[i][j],
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[SHIFT ? i : 0][j], acc[i][j],
                                                            0, 0, 0);
     };
     // sched_barrier pins "reads of step s+1, then MFMAs of step s" so the LDS latency of the
-    // next operands is covered by the 4 x 64-cycle MFMAs instead of being exposed
+    // next operands is covered by the MFMAs instead of being exposed
     read_step(0, av0, bv0);
 #pragma unroll
     for (int s = 0; s < KC / 2; s += 2) {
@@ -298,13 +295,13 @@ __global__ __launch_bounds__(256, 2) void corr_kernel(const CorrArgs a) {
   }
 
   // ---- epilogue ----
+  if (!OUT_HI) {
 #pragma unroll
-  for (int i = 0; i < NI; ++i) {
+    for (int i = 0; i < NI; ++i) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int row = m0 + wm * (MB / 2) + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
-      if (row >= a.Rvalid) continue;
-      if (!OUT_HI) {
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + 32 * (wm * NI + i) + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (row >= a.Rvalid) continue;
         // LO store: out[b, row, t]
         float* dst;
         int oc, och;
@@ -319,30 +316,75 @@ __global__ __launch_bounds__(256, 2) void corr_kernel(const CorrArgs a) {
           if (a.act == SEGAN_ACT_TANH) v = tanhf(v);
           dst[((size_t)col_b[j] * oc + och) * (size_t)a.Lout + col_t[j]] = v;
         }
-      } else {
-        const int r = row / a.NP;
-        const int n = row - r * a.NP;
-        if (n >= a.Nout) continue;
-        const float bs = a.bias ? a.bias[n] : 0.0f;
+      }
+    }
+  } else {
+    // HI store.  Row block ib of the tile is phase r = 32*ib / NPT of channels n0 + nl.
+    constexpr bool QUAD = (S == 4 && WM == 1 && NI == 4);  // lane holds all 4 phases of (n, q)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          if (col_b[j] < 0) continue;
-          float v = acc[i][j][e] + bs;
-          if (a.act == SEGAN_ACT_TANH) v = tanhf(v);
-          const int P = S * col_t[j] + r;
-          int ii = P - a.o_padL;
+    for (int e = 0; e < 16; ++e) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        if (col_b[j] < 0) continue;
+        const int q = col_t[j];
+        if (QUAD) {
+          const int n = n0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (n >= a.Nout) continue;
+          const float bs = a.bias ? a.bias[n] : 0.0f;
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[r] = acc[r][j][e] + bs;
+            if (a.act == SEGAN_ACT_TANH) v[r] = tanhf(v[r]);
+          }
           const size_t rowoff = (size_t)col_b[j] * a.Nout + n;
-          if (ii >= 0 && ii < a.Lout) {
-            if (a.o_roll != 0) {
-              ii -= a.o_roll;
-              if (ii < 0) ii += a.Lout;
-              if (ii >= a.Lout) ii -= a.Lout;
+          const int i0 = 4 * q - a.o_padL;
+          if (a.o_roll == 0 && i0 >= 0 && i0 + 3 < a.Lout && (a.o_padL & 3) == 0) {
+            f32x4 o = {v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(a.out0 + rowoff * (size_t)a.Lout + i0) = o;
+            continue;
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int P = 4 * q + r;
+            int ii = P - a.o_padL;
+            if (ii >= 0 && ii < a.Lout) {
+              if (a.o_roll != 0) {
+                ii -= a.o_roll;
+                if (ii < 0) ii += a.Lout;
+                if (ii >= a.Lout) ii -= a.Lout;
+              }
+              a.out0[rowoff * (size_t)a.Lout + ii] = v[r];
+            } else if (a.halo != nullptr) {
+              const int hl = a.o_padL + a.o_padR;
+              if (ii < 0) a.halo[rowoff * hl + P] = v[r];
+              else if (ii - a.Lout < a.o_padR) a.halo[rowoff * hl + a.o_padL + (ii - a.Lout)] = v[r];
             }
-            a.out0[rowoff * (size_t)a.Lout + ii] = v;
-          } else if (a.halo != nullptr) {
-            const int hl = a.o_padL + a.o_padR;
-            if (ii < 0) a.halo[rowoff * hl + P] = v;
-            else if (ii - a.Lout < a.o_padR) a.halo[rowoff * hl + a.o_padL + (ii - a.Lout)] = v;
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < NI; ++i) {
+            const int rloc = 32 * (wm * NI + i) + (e & 3) + 8 * (e >> 2) + 4 * h;
+            const int r = rloc / NPT;
+            const int n = n0 + rloc % NPT;
+            if (n >= a.Nout) continue;
+            float v = acc[i][j][e] + (a.bias ? a.bias[n] : 0.0f);
+            if (a.act == SEGAN_ACT_TANH) v = tanhf(v);
+            const int P = S * q + r;
+            int ii = P - a.o_padL;
+            const size_t rowoff = (size_t)col_b[j] * a.Nout + n;
+            if (ii >= 0 && ii < a.Lout) {
+              if (a.o_roll != 0) {
+                ii -= a.o_roll;
+                if (ii < 0) ii += a.Lout;
+                if (ii >= a.Lout) ii -= a.Lout;
+              }
+              a.out0[rowoff * (size_t)a.Lout + ii] = v;
+            } else if (a.halo != nullptr) {
+              const int hl = a.o_padL + a.o_padR;
+              if (ii < 0) a.halo[rowoff * hl + P] = v;
+              else if (ii - a.Lout < a.o_padR) a.halo[rowoff * hl + a.o_padL + (ii - a.Lout)] = v;
+            }
           }
         }
       }
@@ -371,23 +413,22 @@ __global__ void fold_halo_kernel(float* dx, const float* halo, int rows, int L, 
 // packed-weight geometry (shared by the pack kernels and the launchers)
 static inline int f_pitch(int M) { return M <= 64 ? 64 : round_up(M, 128); }
 static inline int f_rows(int N) { return round_up(N * 32, KCH); }
-static inline int t_pitch(int N, int S) {
-  const int r = S * round_up(N, 32);
-  return r <= 64 ? 64 : round_up(r, 128);
-}
+// T form: channels are padded to whole tiles (128/S channels x S phases = 128 rows)
+static inline int t_np(int N, int S) { return round_up(N, 128 / S); }
+static inline int t_pitch(int N, int S) { return S * t_np(N, S); }
 static inline int t_rows(int M, int S) { return round_up(M * (32 / S), KCH); }
 
-template <int MB, int U, bool IN_HI, bool OUT_HI, int MAXPOS, int KC = KCH>
+template <int MB, int NB, int WM, int U, bool IN_HI, bool OUT_HI, bool SHIFT, int MAXPOS, int KC>
 static int launch_corr_t(const CorrArgs& a, hipStream_t st) {
-  constexpr int NB = 128;
   constexpr int CV = KC / U;
-  const int nrowtiles = ceil_div(a.Rvalid, MB);
+  constexpr int S = 32 / U;
+  const int nrowtiles = OUT_HI ? a.NP / (MB / S) : ceil_div(a.Rvalid, MB);
   const size_t lds = (size_t)(2 * KC * MB + 2 * CV * a.RLs) * sizeof(float);
   if (lds > 160 * 1024) {
     segan_set_error("corr: LDS tile %zu B too large (RLs=%d)", lds, a.RLs);
     return SEGAN_EUNSUPPORTED;
   }
-  auto kern = corr_kernel<MB, NB, U, IN_HI, OUT_HI, MAXPOS, KC>;
+  auto kern = corr_kernel<MB, NB, WM, U, IN_HI, OUT_HI, SHIFT, MAXPOS, KC>;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -399,48 +440,71 @@ static int launch_corr_t(const CorrArgs& a, hipStream_t st) {
   return segan_check_launch("corr_kernel");
 }
 
-template <int U, bool IN_HI, bool OUT_HI>
-static int launch_corr_u(const CorrArgs& a, hipStream_t st) {
-  // Tile choice.  All workgroups of a launch do the same amount of work and up to 3 are
-  // resident per CU sharing its MFMA pipes, so the launch takes ceil(blocks / 256) block
-  // times; 64-row tiles (half the work each) are used when that quantisation is better
-  // (the deep layers: few, long tiles).  SEGAN_CORR_MB / SEGAN_CORR_KC override for tuning.
-  static const int kc_env = [] { const char* e = getenv("SEGAN_CORR_KC"); return e ? atoi(e) : 0; }();
-  static const int mb_env = [] { const char* e = getenv("SEGAN_CORR_MB"); return e ? atoi(e) : 0; }();
-  bool small = a.Rvalid <= 64;
-  if (!small) {
-    const int nb128 = ceil_div(a.Rvalid, 128) * a.ncoltiles;
-    const int nb64 = ceil_div(a.Rvalid, 64) * a.ncoltiles;
-    const double t128 = (double)ceil_div(nb128, 256);
-    const double t64 = 0.5 * 1.06 * (double)ceil_div(nb64, 256);   // 6 % tile-size penalty
-    small = t64 < t128;
-    if (mb_env == 64) small = true;
-    if (mb_env == 128) small = false;
-  }
-  if (a.RLs <= 256) {
-    if (!small && kc_env != 64 && U <= 16)
-      return launch_corr_t<128, U, IN_HI, OUT_HI, 1, 32>(a, st);
-    return small ? launch_corr_t<64, U, IN_HI, OUT_HI, 1>(a, st)
-                 : launch_corr_t<128, U, IN_HI, OUT_HI, 1>(a, st);
-  }
-  return small ? launch_corr_t<64, U, IN_HI, OUT_HI, 2>(a, st)
-               : launch_corr_t<128, U, IN_HI, OUT_HI, 2>(a, st);
+static int samples_per_tile(int Tcols, int NB) {
+  if (Tcols >= NB) return (Tcols % NB == 0) ? 1 : 2;
+  return (NB % Tcols == 0) ? NB / Tcols : (NB + Tcols - 2) / Tcols + 1;
 }
 
-template <bool IN_HI, bool OUT_HI>
-static int launch_corr(CorrArgs& a, int U, hipStream_t st) {
+// All workgroups of a launch do the same amount of work and several are resident per CU
+// sharing its MFMA pipes, so a launch takes ceil(blocks / 256) block times; the half-size
+// tile is used when that quantisation is better (the deep layers: few, long tiles).
+static bool prefer_half_tile(int nb_full, int nb_half) {
+  static const int env = [] { const char* e = getenv("SEGAN_CORR_HALF"); return e ? atoi(e) : -1; }();
+  if (env == 0) return false;
+  if (env == 1) return true;
+  const double t_full = (double)ceil_div(nb_full, 256);
+  const double t_half = 0.5 * 1.06 * (double)ceil_div(nb_half, 256);   // 6 % tile-size penalty
+  return t_half < t_full;
+}
+
+// ---- F form (conv forward, deconv data gradient) ----
+template <int U>
+static int launch_corr_f(CorrArgs& a, hipStream_t st) {
   constexpr int NB = 128;
   a.ncoltiles = ceil_div(a.Ctot, NB);
-  // worst-case samples touched by one tile -> LDS row length
-  int NS;
-  if (a.Tcols >= NB) NS = (a.Tcols % NB == 0) ? 1 : 2;
-  else NS = (NB % a.Tcols == 0) ? NB / a.Tcols : (NB + a.Tcols - 2) / a.Tcols + 1;
-  a.RLs = NB + NS * a.H;
+  a.RLs = NB + samples_per_tile(a.Tcols, NB) * a.H;
+  bool small = a.Rvalid <= 64;
+  if (!small)
+    small = prefer_half_tile(ceil_div(a.Rvalid, 128) * a.ncoltiles, ceil_div(a.Rvalid, 64) * a.ncoltiles);
+  if (a.RLs <= 256) {
+    if (!small && U <= 16) return launch_corr_t<128, NB, 2, U, true, false, false, 1, 32>(a, st);
+    return small ? launch_corr_t<64, NB, 2, U, true, false, false, 1, KCH>(a, st)
+                 : launch_corr_t<128, NB, 2, U, true, false, false, 1, KCH>(a, st);
+  }
   if (a.RLs > 512) {
     segan_set_error("corr: sample length %d too short for stride %d (RLs=%d)", a.Tcols, 32 / U,
                     a.RLs);
     return SEGAN_EUNSUPPORTED;
   }
+  return small ? launch_corr_t<64, NB, 2, U, true, false, false, 2, KCH>(a, st)
+               : launch_corr_t<128, NB, 2, U, true, false, false, 2, KCH>(a, st);
+}
+
+// ---- T form (deconv forward, conv data gradient) ----
+template <int U, bool SHIFT>
+static int launch_corr_tt(CorrArgs& a, hipStream_t st) {
+  constexpr int S = 32 / U;
+  const int nrt = a.NP / (128 / S);
+  const int ct128 = ceil_div(a.Ctot, 128), ct64 = ceil_div(a.Ctot, 64);
+  const bool half = prefer_half_tile(nrt * ct128, nrt * ct64);
+  const int NB = half ? 64 : 128;
+  a.ncoltiles = half ? ct64 : ct128;
+  a.RLs = NB + samples_per_tile(a.Tcols, NB) * a.H;
+  if (a.RLs > 512) {
+    segan_set_error("corr: sample length %d too short for stride %d (RLs=%d)", a.Tcols, 32 / U,
+                    a.RLs);
+    return SEGAN_EUNSUPPORTED;
+  }
+  constexpr int KC = U <= 16 ? 32 : KCH;
+  if (a.RLs <= 256)
+    return half ? launch_corr_t<128, 64, 2, U, false, true, SHIFT, 1, KC>(a, st)
+                : launch_corr_t<128, 128, 1, U, false, true, SHIFT, 1, KC>(a, st);
+  return half ? launch_corr_t<128, 64, 2, U, false, true, SHIFT, 2, KCH>(a, st)
+              : launch_corr_t<128, 128, 1, U, false, true, SHIFT, 2, KCH>(a, st);
+}
+
+template <bool IN_HI, bool OUT_HI>
+static int launch_corr(CorrArgs& a, int U, hipStream_t st) {
   static const int prio_env = [] { const char* e = getenv("SEGAN_PRIO"); return e ? atoi(e) : 0; }();
   a.prio_mode = prio_env;
   if (int e = segan_src_defaults(&a.in, st, "corr")) return e;
@@ -449,10 +513,19 @@ static int launch_corr(CorrArgs& a, int U, hipStream_t st) {
     segan_set_error("corr: input of %ld elements exceeds the 2^31 indexing limit", in_elems);
     return SEGAN_EUNSUPPORTED;
   }
-  switch (U) {
-    case 8: return launch_corr_u<8, IN_HI, OUT_HI>(a, st);
-    case 16: return launch_corr_u<16, IN_HI, OUT_HI>(a, st);
-    case 32: return launch_corr_u<32, IN_HI, OUT_HI>(a, st);
+  if (!OUT_HI) {
+    switch (U) {
+      case 8: return launch_corr_f<8>(a, st);
+      case 16: return launch_corr_f<16>(a, st);
+      case 32: return launch_corr_f<32>(a, st);
+    }
+  } else {
+    const bool shift = a.rowshift[0] | a.rowshift[1] | a.rowshift[2] | a.rowshift[3];
+    switch (U) {
+      case 8: return shift ? launch_corr_tt<8, true>(a, st) : launch_corr_tt<8, false>(a, st);
+      case 16: return shift ? launch_corr_tt<16, true>(a, st) : launch_corr_tt<16, false>(a, st);
+      case 32: return shift ? launch_corr_tt<32, true>(a, st) : launch_corr_tt<32, false>(a, st);
+    }
   }
   segan_set_error("corr: unsupported stride (U=%d)", U);
   return SEGAN_EUNSUPPORTED;
@@ -977,7 +1050,7 @@ extern "C" int segan_pack_weights(const float* w, float* wf, float* wt, int M, i
                        rows);
   }
   if (wt) {
-    const int NP = round_up(N, 32);
+    const int NP = t_np(N, S);
     const int pitch = t_pitch(N, S), rows = t_rows(M, S);
     const size_t total = (size_t)rows * pitch;
     const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
@@ -1064,7 +1137,7 @@ extern "C" int segan_deconv1d_fwd(const segan_src* x, const float* wt, const flo
   a.in = *x;
   a.wp = wt;
   a.out0 = y; a.out1 = nullptr; a.bias = bias; a.halo = nullptr;
-  a.NP = round_up(N, 32); a.Nout = N;
+  a.NP = t_np(N, S); a.Nout = N;
   a.B = B; a.Cv = M; a.Ktot = M * U; a.RP = t_pitch(N, S); a.Rvalid = S * a.NP;
   a.Tcols = Ls; a.Ctot = B * Ls;
   a.Lin = Ls; a.padL = 0; a.mode = SEGAN_PAD_ZERO; a.roll = 0;
@@ -1101,7 +1174,7 @@ extern "C" int segan_conv1d_dgrad(const float* da, const float* wt, const float*
   a.in.scale = a.in.shift = a.in.slope = nullptr;
   a.wp = wt;
   a.out0 = dx; a.out1 = nullptr; a.bias = nullptr; a.halo = halo;
-  a.NP = round_up(N, 32); a.Nout = N;
+  a.NP = t_np(N, S); a.Nout = N;
   a.B = B; a.Cv = M; a.Ktot = M * U; a.RP = t_pitch(N, S); a.Rvalid = S * a.NP;
   // padded coordinates P = S*q + r in [0, L + padL + padR)
   a.Tcols = (L + padL + padR - 1) / S + 1;

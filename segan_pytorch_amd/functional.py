@@ -19,6 +19,39 @@ from . import ops
 from .ops import ACT_NONE, ACT_TANH, PAD_REFLECT, PAD_ZERO, Src
 
 
+class _SideStream(object):
+    """Runs the weight-gradient kernels of a backward pass on a second HIP stream so that
+    they overlap the data-gradient chain (they only share the read-only `da`): the tail of
+    one launch (equal-size workgroups leave CUs idle at the end) is filled by the other.
+    Every tensor handed to the side stream is kept alive until `join()`.
+    Enabled with SEGAN_WGRAD_STREAM=1."""
+    _stream = None
+
+    def __init__(self):
+        import os
+        self.on = os.environ.get('SEGAN_WGRAD_STREAM', '0') == '1' and torch.cuda.is_available()
+        self.keep = []
+        if self.on and _SideStream._stream is None:
+            _SideStream._stream = torch.cuda.Stream()
+        self.used = False
+
+    def run(self, fn, *tensors):
+        if not self.on:
+            fn()
+            return
+        side = _SideStream._stream
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fn()
+        self.keep.extend(tensors)
+        self.used = True
+
+    def join(self):
+        if self.on and self.used:
+            torch.cuda.current_stream().wait_stream(_SideStream._stream)
+        self.keep = []
+
+
 def grad_buf(p):
     """The tensor the kernels accumulate this parameter's gradient into."""
     if p.grad is None:
@@ -117,6 +150,7 @@ class GeneratorFn(torch.autograd.Function):
             return (None,) * len(ctx.needs_input_grad)
         dy = dy.contiguous()
         dh = dy
+        side = _SideStream()
         dskip = {}          # enc index -> gradient w.r.t. alpha * a_enc
         dh_last_enc = None  # gradient w.r.t. h of the last encoder layer
         # ---- decoder, last to first ----
@@ -132,7 +166,9 @@ class GeneratorFn(torch.autograd.Function):
                                  dslope=_gb(blk.act.weight), dbias=_gb(blk.deconv.bias))
             src = src_dec[li]
             if w.requires_grad:
-                ops.wgrad(src, Src(da), grad_buf(w), K, S, ops.deconv_pad(K, S), PAD_ZERO)
+                gw = grad_buf(w)
+                side.run(lambda: ops.wgrad(src, Src(da), gw, K, S, ops.deconv_pad(K, S),
+                                           PAD_ZERO), da)
             if li == 0:
                 if gen.no_z:
                     _d0, dh_last_enc = ops.deconv1d_dgrad(da, w, S, 0, pack=blk._pack)
@@ -162,11 +198,13 @@ class GeneratorFn(torch.autograd.Function):
                              dbias=_gb(blk.conv.bias))
             padL = ops.conv_pad(K, S)[0]
             if w.requires_grad:
-                ops.wgrad(Src(da), src_enc[l], grad_buf(w), K, S, padL, PAD_REFLECT)
+                gw = grad_buf(w)
+                side.run(lambda: ops.wgrad(Src(da), src_enc[l], gw, K, S, padL, PAD_REFLECT), da)
             if l > 0:
                 dh = ops.conv1d_dgrad(da, w, src_enc[l].L, S, pack=blk._pack)
             elif ctx.x_needs:
                 dx = ops.conv1d_dgrad(da, w, src_enc[l].L, S, pack=blk._pack)
+        side.join()
         ctx.state = None
         return (None, None, dx, None) + (None,) * (len(ctx.needs_input_grad) - 4)
 
@@ -253,6 +291,7 @@ class DiscriminatorFn(torch.autograd.Function):
         dh = ops.linear_dgrad(dy1, fc[0].weight).view(cs[-1].shape)
         # ---- conv stack ----
         dx = None
+        side = _SideStream()
         for l in range(len(blocks) - 1, -1, -1):
             blk = blocks[l]
             w = blk.conv.weight
@@ -270,11 +309,14 @@ class DiscriminatorFn(torch.autograd.Function):
                                  dbias=_gb(blk.conv.bias))
             padL = ops.conv_pad(K, S)[0]
             if w.requires_grad:
-                ops.wgrad(Src(dc), srcs[l], grad_buf(w), K, S, padL, PAD_REFLECT, roll=ctx.rolls[l])
+                gw, rl = grad_buf(w), ctx.rolls[l]
+                side.run(lambda: ops.wgrad(Src(dc), srcs[l], gw, K, S, padL, PAD_REFLECT, roll=rl),
+                         dc)
             if l > 0:
                 dh = ops.conv1d_dgrad(dc, w, srcs[l].L, S, roll=ctx.rolls[l], pack=blk._pack)
             elif ctx.x_needs:
                 dx = ops.conv1d_dgrad(dc, w, srcs[l].L, S, roll=ctx.rolls[l], pack=blk._pack)
+        side.join()
         ctx.state = None
         del any_param
         return (None, None, dx) + (None,) * (len(ctx.needs_input_grad) - 3)
