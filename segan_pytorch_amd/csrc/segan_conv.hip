@@ -392,12 +392,23 @@ __global__ __launch_bounds__(256, 2) void corr_kernel(const CorrArgs a) {
   }
 }
 
-// fold the reflect halo of a conv dgrad back into dx: one thread per (b, n) row.
+// fold the reflect halo of a conv dgrad back into dx.  When L > padL + padR + 1 the padL left
+// and padR right halo samples mirror onto distinct elements of a row, so one thread per
+// (row, halo sample) is race-free; shorter rows fall back to one thread per row.
 __global__ void fold_halo_kernel(float* dx, const float* halo, int rows, int L, int padL,
-                                 int padR, int roll) {
+                                 int padR, int roll, int per_sample) {
+  const int hl = padL + padR;
+  if (per_sample) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)rows * hl) return;
+    const int row = (int)(t / hl), j = (int)(t - (long)row * hl);
+    const int P = j < padL ? j : L + j;       // right halo sample j-padL sits at L + padL + (j-padL)
+    const int idx = segan_hi_index(P, L, padL, SEGAN_PAD_REFLECT, roll);
+    if (idx >= 0) dx[(size_t)row * L + idx] += halo[(size_t)row * hl + j];
+    return;
+  }
   const int row = blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= rows) return;
-  const int hl = padL + padR;
   float* d = dx + (size_t)row * L;
   const float* hrow = halo + (size_t)row * hl;
   for (int P = 0; P < padL; ++P) {
@@ -557,17 +568,24 @@ __global__ __launch_bounds__(256) void tsmall_kernel(const CorrArgs a, const flo
 #pragma unroll
     for (int n = 0; n < N; ++n) acc[r][n] = 0.0f;
 
+  // staging: thread owns window positions tid and 256 + tid (the latter only for tid < U);
+  // addresses are clamped so the loads are unconditional
+  const int t0 = q0 + a.win_start + tid, t1 = t0 + 256;
+  const bool ok0 = t0 >= 0 && t0 < a.Lin, ok1 = tid < U && t1 >= 0 && t1 < a.Lin;
+  const int o0 = ok0 ? t0 : 0, o1 = ok1 ? t1 : 0;
+  const int bo0 = b * a.in.C0 * a.Lin, bo1 = b * a.in.C1 * a.Lin;
   for (int mc0 = 0; mc0 < M; mc0 += MC) {
-    for (int e = tid; e < MC * TW; e += 256) {
-      const int mc = e / TW, j = e - mc * TW;
-      const int m = mc0 + mc;
-      const int t = q0 + a.win_start + j;
-      float v = 0.0f;
-      if (m < M && t >= 0 && t < a.Lin) {
-        const ChanXf xf = segan_chan_xf(a.in, m);
-        v = segan_apply_xf(xf, segan_src_row(a.in, b, m, a.Lin)[t]);
-      }
-      xs[mc][j] = v;
+#pragma unroll 4
+    for (int mc = 0; mc < MC; ++mc) {
+      const int m = mc0 + mc < M ? mc0 + mc : 0;
+      const bool seg1 = m >= a.in.C0;
+      const float* rowp = seg1 ? a.in.p1 + (size_t)(m - a.in.C0) * a.Lin + bo1
+                               : a.in.p0 + (size_t)m * a.Lin + bo0;
+      const ChanXf xf = segan_chan_xf(a.in, m);
+      const float v0 = rowp[o0], v1 = rowp[o1];
+      const bool mok = mc0 + mc < M;
+      xs[mc][tid] = (mok && ok0) ? segan_apply_xf(xf, v0) : 0.0f;
+      if (tid < U) xs[mc][256 + tid] = (mok && ok1) ? segan_apply_xf(xf, v1) : 0.0f;
     }
     __syncthreads();
     const int mcn = min(MC, M - mc0);
@@ -1190,8 +1208,11 @@ extern "C" int segan_conv1d_dgrad(const float* da, const float* wt, const float*
   if (e) return e;
   if (padL + padR > 0) {
     const int rows = B * N;
-    hipLaunchKernelGGL(fold_halo_kernel, dim3(ceil_div(rows, 256)), dim3(256), 0, st, dx, halo,
-                       rows, L, padL, padR, roll);
+    // left targets are 1..padL, right targets L-1-padR..L-2: disjoint iff padL < L-1-padR
+    const int per_sample = (padL < L - 1 - padR) ? 1 : 0;
+    const long nthreads = per_sample ? (long)rows * (padL + padR) : rows;
+    hipLaunchKernelGGL(fold_halo_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st,
+                       dx, halo, rows, L, padL, padR, roll, per_sample);
     return segan_check_launch("fold_halo_kernel");
   }
   return SEGAN_OK;

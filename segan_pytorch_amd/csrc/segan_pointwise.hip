@@ -392,34 +392,45 @@ extern "C" int segan_bias_prelu_rows(const float* x, const float* bias, const fl
   return segan_check_launch("bias_prelu_rows");
 }
 
-// one thread per column walks the rows (rows = batch, a few hundred): deterministic
-__global__ void bias_prelu_rows_bwd_kernel(const float* __restrict__ x, const float* bias,
-                                           const float* slope, const float* __restrict__ dy,
-                                           float* __restrict__ dx, float* dslope, float* dbias,
-                                           int rows, int cols) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= cols) return;
-  const float bs = bias ? bias[c] : 0.0f;
-  const float sl = slope ? slope[c] : 1.0f;
+// one 256-thread workgroup per 64 columns: 4 row-groups walk the rows in parallel and are
+// combined through LDS in a fixed order (deterministic)
+__global__ __launch_bounds__(256) void bias_prelu_rows_bwd_kernel(
+    const float* __restrict__ x, const float* bias, const float* slope,
+    const float* __restrict__ dy, float* __restrict__ dx, float* dslope, float* dbias, int rows,
+    int cols) {
+  __shared__ float sm[2][4][64];
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   float s_sl = 0.f, s_b = 0.f;
-  for (int r = 0; r < rows; ++r) {
-    const size_t i = (size_t)r * cols + c;
-    const float v = x[i] + bs;
-    const float g = dy[i];
-    const float d = g * (v > 0.f ? 1.0f : sl);
-    s_sl += g * (v > 0.f ? 0.0f : v);
-    s_b += d;
-    dx[i] = d;
+  if (c < cols) {
+    const float bs = bias ? bias[c] : 0.0f;
+    const float sl = slope ? slope[c] : 1.0f;
+    for (int r = rg; r < rows; r += 4) {
+      const size_t i = (size_t)r * cols + c;
+      const float v = x[i] + bs;
+      const float g = dy[i];
+      const float d = g * (v > 0.f ? 1.0f : sl);
+      s_sl += g * (v > 0.f ? 0.0f : v);
+      s_b += d;
+      dx[i] = d;
+    }
   }
-  if (dslope && slope) dslope[c] += s_sl;
-  if (dbias) dbias[c] += s_b;
+  sm[0][rg][cl] = s_sl;
+  sm[1][rg][cl] = s_b;
+  __syncthreads();
+  if (rg == 0 && c < cols) {
+    const float a = sm[0][0][cl] + sm[0][1][cl] + sm[0][2][cl] + sm[0][3][cl];
+    const float b = sm[1][0][cl] + sm[1][1][cl] + sm[1][2][cl] + sm[1][3][cl];
+    if (dslope && slope) dslope[c] += a;
+    if (dbias) dbias[c] += b;
+  }
 }
 
 extern "C" int segan_bias_prelu_rows_bwd(const float* x, const float* bias, const float* slope,
                                          const float* dy, float* dx, float* dslope, float* dbias,
                                          int rows, int cols, void* stream) {
   SEGAN_REQUIRE(x && dy && dx && rows > 0 && cols > 0, "bias_prelu_rows_bwd: bad arguments");
-  hipLaunchKernelGGL(bias_prelu_rows_bwd_kernel, dim3(ceil_div(cols, 64)), dim3(64), 0,
+  hipLaunchKernelGGL(bias_prelu_rows_bwd_kernel, dim3(ceil_div(cols, 64)), dim3(256), 0,
                      (hipStream_t)stream, x, bias, slope, dy, dx, dslope, dbias, rows, cols);
   return segan_check_launch("bias_prelu_rows_bwd");
 }

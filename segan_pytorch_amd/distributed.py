@@ -43,9 +43,7 @@ def init_from_env(backend=None):
     lr = int(os.environ.get('LOCAL_RANK', '0'))
     if ws <= 1:
         return 0, 1, lr
-    if not dist.is_initialized():
-        if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+XX
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend == 'nccl':
