@@ -43,7 +43,14 @@ def init_from_env(backend=None):
     lr = int(os.environ.get('LOCAL_RANK', '0'))
     if ws <= 1:
         return 0, 1, lr
-XX
+    # testing hooks: SEGAN_DIST_BACKEND=gloo and SEGAN_LOCAL_DEVICE=<i> let several ranks share
+    # one GPU (RCCL refuses duplicate devices); never set in production
+    backend = backend or os.environ.get('SEGAN_DIST_BACKEND')
+    if 'SEGAN_LOCAL_DEVICE' in os.environ:
+        lr = int(os.environ['SEGAN_LOCAL_DEVICE'])
+    if not dist.is_initialized():
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend == 'nccl':
