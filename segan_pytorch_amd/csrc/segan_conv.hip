@@ -999,41 +999,52 @@ static int launch_wgrad_t(WgradArgs& a, hipStream_t st) {
 // ====================================================================================
 // weight packing
 // ====================================================================================
-__global__ void pack_f_kernel(const float* __restrict__ w, float* __restrict__ wf, int M, int N,
-                              int K, int S, int U, int pitch, int rows) {
-  const size_t total = (size_t)rows * pitch;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
-       i += (size_t)gridDim.x * blockDim.x) {
-    const int m = (int)(i % pitch);
-    size_t t = i / pitch;          // row = (n*S + r)*U + u
-    const int u = (int)(t % U);
-    t /= U;
-    const int r = (int)(t % S);
-    const int n = (int)(t / S);
-    const int k = S * u + r;
-    float v = 0.0f;
-    if (m < M && n < N && k < K) v = w[((size_t)m * N + n) * K + k];
-    wf[i] = v;
+// Both packings are [*, K] -> [K', *] transposes of a 64 x 32 tile through LDS so that the
+// global reads (31 contiguous taps per (m,n)) and the writes (64 contiguous m / n) are both
+// coalesced.  grid.x = tiles of 64 along the transposed axis, grid.y = the other axis.
+__global__ __launch_bounds__(256) void pack_f_kernel(const float* __restrict__ w,
+                                                     float* __restrict__ wf, int M, int N, int K,
+                                                     int S, int U, int pitch, int rows) {
+  __shared__ float t[64][33];
+  const int n = blockIdx.y;                 // may run past N into the zero padding rows
+  const int m0 = blockIdx.x * 64;
+  const int tid = threadIdx.x;
+  for (int e = tid; e < 64 * 32; e += 256) {
+    const int ml = e >> 5, k = e & 31;
+    const int m = m0 + ml;
+    t[ml][k] = (m < M && n < N && k < K) ? w[((size_t)m * N + n) * K + k] : 0.0f;
+  }
+  __syncthreads();
+  for (int e = tid; e < 32 * 64; e += 256) {
+    const int kk = e >> 6, ml = e & 63;     // kk = r*U + u  ->  tap k = S*u + r
+    const int r = kk / U, u = kk - r * U;
+    const int row = (n * S + r) * U + u;
+    if (row < rows && m0 + ml < pitch) wf[(size_t)row * pitch + m0 + ml] = t[ml][S * u + r];
   }
 }
 
-__global__ void pack_t_kernel(const float* __restrict__ w, float* __restrict__ wt, int M, int N,
-                              int K, int S, int U, int NP, int pad, int pitch, int rows) {
-  const size_t total = (size_t)rows * pitch;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
-       i += (size_t)gridDim.x * blockDim.x) {
-    const int col = (int)(i % pitch);
-    size_t t = i / pitch;          // row = m*U + u'
-    const int up = (int)(t % U);
-    const int m = (int)(t / U);
-    const int r = col / NP, n = col % NP;
-    float v = 0.0f;
-    if (r < S && m < M && n < N) {
-      const int rho = (r + pad) % S;
-      const int k = S * (U - 1 - up) + rho;
-      if (k < K) v = w[((size_t)m * N + n) * K + k];
-    }
-    wt[i] = v;
+__global__ __launch_bounds__(256) void pack_t_kernel(const float* __restrict__ w,
+                                                     float* __restrict__ wt, int M, int N, int K,
+                                                     int S, int U, int NP, int pad, int pitch,
+                                                     int rows) {
+  __shared__ float t[64][33];
+  const int m = blockIdx.y;                 // may run past M into the zero padding rows
+  const int n0 = blockIdx.x * 64;
+  const int tid = threadIdx.x;
+  for (int e = tid; e < 64 * 32; e += 256) {
+    const int nl = e >> 5, k = e & 31;
+    const int n = n0 + nl;
+    t[nl][k] = (m < M && n < N && k < K) ? w[((size_t)m * N + n) * K + k] : 0.0f;
+  }
+  __syncthreads();
+  for (int e = tid; e < 32 * 64; e += 256) {
+    const int kk = e >> 6, nl = e & 63;     // kk = u'*S + r
+    const int up = kk / S, r = kk - up * S;
+    const int rho = (r + pad) % S;
+    const int k = S * (U - 1 - up) + rho;   // < 32 always; taps >= K hold zeros in t
+    const int row = m * U + up;
+    const int n = n0 + nl;
+    if (row < rows && n < NP) wt[(size_t)row * pitch + r * NP + n] = t[nl][k];
   }
 }
 
@@ -1062,18 +1073,15 @@ extern "C" int segan_pack_weights(const float* w, float* wf, float* wt, int M, i
   const int U = 32 / S;
   if (wf) {
     const int pitch = f_pitch(M), rows = f_rows(N);
-    const size_t total = (size_t)rows * pitch;
-    const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
-    hipLaunchKernelGGL(pack_f_kernel, dim3(blocks), dim3(256), 0, st, w, wf, M, N, K, S, U, pitch,
-                       rows);
+    // rows = round_up(N*32, 64): cover the padding rows with one extra n when N is odd
+    hipLaunchKernelGGL(pack_f_kernel, dim3(pitch / 64, ceil_div(rows, 32)), dim3(256), 0, st, w,
+                       wf, M, N, K, S, U, pitch, rows);
   }
   if (wt) {
     const int NP = t_np(N, S);
     const int pitch = t_pitch(N, S), rows = t_rows(M, S);
-    const size_t total = (size_t)rows * pitch;
-    const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
-    hipLaunchKernelGGL(pack_t_kernel, dim3(blocks), dim3(256), 0, st, w, wt, M, N, K, S, U, NP,
-                       pad_t, pitch, rows);
+    hipLaunchKernelGGL(pack_t_kernel, dim3(ceil_div(NP, 64), ceil_div(rows, U)), dim3(256), 0, st,
+                       w, wt, M, N, K, S, U, NP, pad_t, pitch, rows);
   }
   return segan_check_launch("pack_weights");
 }

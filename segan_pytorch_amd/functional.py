@@ -216,11 +216,13 @@ class DiscriminatorFn(torch.autograd.Function):
     """logit = D(x) (discriminator.py:150-194) with the phase shifts given as rolls."""
 
     @staticmethod
-    def forward(ctx, disc, rolls, x, *params):
+    def forward(ctx, disc, rolls, x, x1, *params):
+        # x1 (optional): second channel group; D(cat(x, x1)) without materialising the cat
+        # (model.py:174): the first conv reads two pointers
         x = x.contiguous()
         blocks = list(disc.enc_blocks)
         training = disc.training
-        src = Src(x)
+        src = Src(x) if x1 is None else Src(x, x1.contiguous())
         cs, srcs, bns, xfs = [], [], [], []
         for l, blk in enumerate(blocks):
             c = ops.conv1d_fwd(src, blk.conv.weight, blk.conv.bias, blk.stride, roll=rolls[l],
@@ -261,7 +263,8 @@ class DiscriminatorFn(torch.autograd.Function):
         out = ops.bias_prelu_rows(y3, fc[4].bias, None)
         ctx.disc = disc
         ctx.rolls = tuple(rolls)
-        ctx.x_needs = x.requires_grad
+        ctx.x_needs = x.requires_grad or (x1 is not None and x1.requires_grad)
+        ctx.split = None if x1 is None else (x.shape[1], x.requires_grad, x1.requires_grad)
         ctx.state = (cs, srcs, bns, hf, y1, a1, y2, a2, y3)
         disc._last_fwd = (cs, xfs)      # for the lazy int_act dict
         return out
@@ -319,7 +322,12 @@ class DiscriminatorFn(torch.autograd.Function):
         side.join()
         ctx.state = None
         del any_param
-        return (None, None, dx) + (None,) * (len(ctx.needs_input_grad) - 3)
+        dx1 = None
+        if dx is not None and ctx.split is not None:
+            c0, need0, need1 = ctx.split
+            dx1 = dx[:, c0:].contiguous() if need1 else None
+            dx = dx[:, :c0].contiguous() if need0 else None
+        return (None, None, dx, dx1) + (None,) * (len(ctx.needs_input_grad) - 4)
 
 
 # =====================================================================================

@@ -98,8 +98,12 @@ class Discriminator(Model):
             rolls.append(shift if right else -shift)
         return rolls
 
-    def forward(self, x):
-        if x.dim() != 3 or x.shape[1] != self.enc_blocks[0].conv.in_channels:
+    def forward(self, x, x1=None):
+        """x: [B, C, L]; or the two halves (x, x1) of the channel axis, which is
+        D(torch.cat((x, x1), 1)) of the reference (model.py:174) without the copy."""
+        nch = x.shape[1] + (x1.shape[1] if x1 is not None else 0) if x.dim() == 3 else -1
+        if x.dim() != 3 or nch != self.enc_blocks[0].conv.in_channels or \
+                (x1 is not None and x1.shape[::2] != x.shape[::2]):
             raise ValueError('Discriminator expects [B, {}, L], got {}'.format(
                 self.enc_blocks[0].conv.in_channels, tuple(x.shape)))
         L = x.shape[2]
@@ -109,5 +113,5 @@ class Discriminator(Model):
             raise ValueError('input length {} does not match the dense head ({} features after '
                              'pooling by {})'.format(L, self.fc[0].in_features, self._total_pool))
         rolls = self.draw_rolls()
-        y = Fn.DiscriminatorFn.apply(self, rolls, x, *self._fn_params())
+        y = Fn.DiscriminatorFn.apply(self, rolls, x, x1, *self._fn_params())
         return y, _LazyIntAct(self, y)

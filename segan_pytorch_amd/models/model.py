@@ -145,7 +145,9 @@ class SEGAN(Model):
         return self.G(nwav, z=z, ret_hid=ret_hid)
 
     def infer_D(self, x_, ref):
-        return self.D(torch.cat((x_, ref), dim=1))
+        # D(torch.cat((x_, ref), dim=1)) of model.py:173-175; the concatenation is folded
+        # into the first conv's two-pointer load
+        return self.D(x_, ref)
 
     # ---- training ---------------------------------------------------------------------
     def build_optimizers(self, opts):
