@@ -78,6 +78,11 @@ struct CorrArgs {
   int OC0, OC1, Lout, act;
   int o_padL, o_roll, o_padR;  // HI store (conv dgrad: reflect halo)
   int prio_mode;               // 0: none, 1: hashed static wave priority per workgroup
+  int sk_nfull;                // tiles processed whole (strided over the grid)
+  int sk_units;                // stream-K part: (tile, chunk) units per workgroup
+  long sk_total;               // stream-K part: total units of the remaining tiles
+  int rt0;                     // first row tile (rows below it have a NULL destination)
+  size_t out0_elems, out1_elems, halo_elems;   // host side: what stream-K must zero
 };
 
 // Staging discipline (both kernels): load_chunk() only ISSUES global loads — every
@@ -112,14 +117,39 @@ __global__ __launch_bounds__(256, 2) void corr_kernel(const CorrArgs a) {
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, h = lane >> 5;
 
-  const int rowtile = blockIdx.x / a.ncoltiles;
-  const int coltile = blockIdx.x - rowtile * a.ncoltiles;
+  // Work decomposition (data-parallel + stream-K hybrid).  The first a.sk_nfull tiles are
+  // whole-tile work items, strided over the grid.  The remaining tiles — fewer than the
+  // grid, i.e. the partial last round that would leave CUs idle — are cut in the (tile,
+  // chunk) iteration space into equal contiguous ranges, one per workgroup; a tile cut
+  // across workgroups is combined with fp32 atomics into the zero-initialised output (its
+  // bias is added by the piece that holds chunk 0).  Classic launch: sk_nfull = #tiles.
+  const int nch = (a.Ktot + KC - 1) / KC;
+  int tileA = blockIdx.x;
+  long unit = (long)blockIdx.x * a.sk_units;
+  const long unit_end = min(unit + (long)a.sk_units, a.sk_total);
+  for (;;) {
+  int tile, c0, c1;
+  if (tileA < a.sk_nfull) {
+    tile = tileA; c0 = 0; c1 = nch;
+    tileA += gridDim.x;
+  } else if (unit < unit_end) {
+    const int t = (int)(unit / nch);
+    c0 = (int)(unit - (long)t * nch);
+    c1 = min(nch, c0 + (int)(unit_end - unit));
+    unit += c1 - c0;
+    tile = a.sk_nfull + t;
+  } else {
+    break;
+  }
+  const bool partial = (c0 != 0) || (c1 != nch);
+  const int rowtile = a.rt0 + tile / a.ncoltiles;
+  const int coltile = tile % a.ncoltiles;
   const int m0 = rowtile * MB;          // F form: first row; T form: n0 = rowtile * NPT
   const int n0 = rowtile * NPT;
   if (!OUT_HI) {
     // dual destination: skip tiles whose rows all go to a NULL destination
-    if (a.out0 == nullptr && m0 + MB <= a.OC0) return;
-    if (a.out1 == nullptr && m0 >= a.OC0) return;
+    if (a.out0 == nullptr && m0 + MB <= a.OC0) continue;
+    if (a.out1 == nullptr && m0 >= a.OC0) continue;
   }
   const ColTile ct = make_coltile(coltile * NB, a.Tcols, NB);
 
@@ -243,13 +273,12 @@ __global__ __launch_bounds__(256, 2) void corr_kernel(const CorrArgs a) {
     }
   };
 
-  const int nch = (a.Ktot + KC - 1) / KC;
-  load_chunk(0);
-  store_chunk(0, 0);
+  load_chunk(c0);
+  store_chunk(c0, 0);
   __syncthreads();
-  for (int ch = 0; ch < nch; ++ch) {
-    const int buf = ch & 1;
-    if (ch + 1 < nch) load_chunk(ch + 1);
+  for (int ch = c0; ch < c1; ++ch) {
+    const int buf = (ch - c0) & 1;
+    if (ch + 1 < c1) load_chunk(ch + 1);
     const float* Wl = Wl0 + buf * (KC * MB);
     const float* Il = Il0 + buf * (CV * RLs);
     // operands of step s+1 are read from LDS before the MFMAs of step s are issued
@@ -290,11 +319,12 @@ __global__ __launch_bounds__(256, 2) void corr_kernel(const CorrArgs a) {
       mma_step(av1, bv1);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (ch + 1 < nch) store_chunk(ch + 1, buf ^ 1);
+    if (ch + 1 < c1) store_chunk(ch + 1, buf ^ 1);
     __syncthreads();
   }
 
   // ---- epilogue ----
+  const bool add_bias = (c0 == 0);
   if (!OUT_HI) {
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
@@ -308,13 +338,15 @@ __global__ __launch_bounds__(256, 2) void corr_kernel(const CorrArgs a) {
         if (row < a.OC0) { dst = a.out0; oc = a.OC0; och = row; }
         else { dst = a.out1; oc = a.OC1; och = row - a.OC0; }
         if (dst == nullptr) continue;
-        const float bs = a.bias ? a.bias[row] : 0.0f;
+        const float bs = (a.bias && add_bias) ? a.bias[row] : 0.0f;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
           if (col_b[j] < 0) continue;
           float v = acc[i][j][e] + bs;
+          float* o = dst + ((size_t)col_b[j] * oc + och) * (size_t)a.Lout + col_t[j];
+          if (partial) { atomicAdd(o, v); continue; }
           if (a.act == SEGAN_ACT_TANH) v = tanhf(v);
-          dst[((size_t)col_b[j] * oc + och) * (size_t)a.Lout + col_t[j]] = v;
+          *o = v;
         }
       }
     }
@@ -330,16 +362,16 @@ __global__ __launch_bounds__(256, 2) void corr_kernel(const CorrArgs a) {
         if (QUAD) {
           const int n = n0 + (e & 3) + 8 * (e >> 2) + 4 * h;
           if (n >= a.Nout) continue;
-          const float bs = a.bias ? a.bias[n] : 0.0f;
+          const float bs = (a.bias && add_bias) ? a.bias[n] : 0.0f;
           float v[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             v[r] = acc[r][j][e] + bs;
-            if (a.act == SEGAN_ACT_TANH) v[r] = tanhf(v[r]);
+            if (!partial && a.act == SEGAN_ACT_TANH) v[r] = tanhf(v[r]);
           }
           const size_t rowoff = (size_t)col_b[j] * a.Nout + n;
           const int i0 = 4 * q - a.o_padL;
-          if (a.o_roll == 0 && i0 >= 0 && i0 + 3 < a.Lout && (a.o_padL & 3) == 0) {
+          if (!partial && a.o_roll == 0 && i0 >= 0 && i0 + 3 < a.Lout && (a.o_padL & 3) == 0) {
             f32x4 o = {v[0], v[1], v[2], v[3]};
             *reinterpret_cast<f32x4*>(a.out0 + rowoff * (size_t)a.Lout + i0) = o;
             continue;
@@ -354,11 +386,14 @@ __global__ __launch_bounds__(256, 2) void corr_kernel(const CorrArgs a) {
                 if (ii < 0) ii += a.Lout;
                 if (ii >= a.Lout) ii -= a.Lout;
               }
-              a.out0[rowoff * (size_t)a.Lout + ii] = v[r];
+              float* o = a.out0 + rowoff * (size_t)a.Lout + ii;
+              if (partial) atomicAdd(o, v[r]); else *o = v[r];
             } else if (a.halo != nullptr) {
               const int hl = a.o_padL + a.o_padR;
-              if (ii < 0) a.halo[rowoff * hl + P] = v[r];
-              else if (ii - a.Lout < a.o_padR) a.halo[rowoff * hl + a.o_padL + (ii - a.Lout)] = v[r];
+              float* o = nullptr;
+              if (ii < 0) o = a.halo + rowoff * hl + P;
+              else if (ii - a.Lout < a.o_padR) o = a.halo + rowoff * hl + a.o_padL + (ii - a.Lout);
+              if (o) { if (partial) atomicAdd(o, v[r]); else *o = v[r]; }
             }
           }
         } else {
@@ -368,8 +403,8 @@ __global__ __launch_bounds__(256, 2) void corr_kernel(const CorrArgs a) {
             const int r = rloc / NPT;
             const int n = n0 + rloc % NPT;
             if (n >= a.Nout) continue;
-            float v = acc[i][j][e] + (a.bias ? a.bias[n] : 0.0f);
-            if (a.act == SEGAN_ACT_TANH) v = tanhf(v);
+            float v = acc[i][j][e] + ((a.bias && add_bias) ? a.bias[n] : 0.0f);
+            if (!partial && a.act == SEGAN_ACT_TANH) v = tanhf(v);
             const int P = S * q + r;
             int ii = P - a.o_padL;
             const size_t rowoff = (size_t)col_b[j] * a.Nout + n;
@@ -379,17 +414,21 @@ __global__ __launch_bounds__(256, 2) void corr_kernel(const CorrArgs a) {
                 if (ii < 0) ii += a.Lout;
                 if (ii >= a.Lout) ii -= a.Lout;
               }
-              a.out0[rowoff * (size_t)a.Lout + ii] = v;
+              float* o = a.out0 + rowoff * (size_t)a.Lout + ii;
+              if (partial) atomicAdd(o, v); else *o = v;
             } else if (a.halo != nullptr) {
               const int hl = a.o_padL + a.o_padR;
-              if (ii < 0) a.halo[rowoff * hl + P] = v;
-              else if (ii - a.Lout < a.o_padR) a.halo[rowoff * hl + a.o_padL + (ii - a.Lout)] = v;
+              float* o = nullptr;
+              if (ii < 0) o = a.halo + rowoff * hl + P;
+              else if (ii - a.Lout < a.o_padR) o = a.halo + rowoff * hl + a.o_padL + (ii - a.Lout);
+              if (o) { if (partial) atomicAdd(o, v); else *o = v; }
             }
           }
         }
       }
     }
   }
+  }  // segment loop
 }
 
 // fold the reflect halo of a conv dgrad back into dx.  When L > padL + padR + 1 the padL left
@@ -429,8 +468,13 @@ static inline int t_np(int N, int S) { return round_up(N, 128 / S); }
 static inline int t_pitch(int N, int S) { return S * t_np(N, S); }
 static inline int t_rows(int M, int S) { return round_up(M * (32 / S), KCH); }
 
+static bool streamk_enabled() {
+  static const int env = [] { const char* e = getenv("SEGAN_STREAMK"); return e ? atoi(e) : 1; }();
+  return env != 0;
+}
+
 template <int MB, int NB, int WM, int U, bool IN_HI, bool OUT_HI, bool SHIFT, int MAXPOS, int KC>
-static int launch_corr_t(const CorrArgs& a, hipStream_t st) {
+static int launch_corr_t(CorrArgs a, hipStream_t st, bool allow_sk) {
   constexpr int CV = KC / U;
   constexpr int S = 32 / U;
   const int nrowtiles = OUT_HI ? a.NP / (MB / S) : ceil_div(a.Rvalid, MB);
@@ -446,8 +490,49 @@ static int launch_corr_t(const CorrArgs& a, hipStream_t st) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
-  dim3 grid((unsigned)(nrowtiles * a.ncoltiles));
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
+  // rows below rt0 all go to a NULL destination (the z half of the first decoder layer)
+  a.rt0 = (!OUT_HI && a.out0 == nullptr) ? a.OC0 / MB : 0;
+  const int ntiles = (nrowtiles - a.rt0) * a.ncoltiles;
+  const int nch = ceil_div(a.Ktot, KC);
+  a.sk_nfull = ntiles;
+  a.sk_units = 0;
+  a.sk_total = 0;
+  unsigned grid = (unsigned)ntiles;
+  // hybrid when one-tile-per-workgroup would leave >3 % of the CU-time idle at the end
+  const double classic_eff = (double)ntiles / (256.0 * ceil_div(ntiles, 256));
+  if (allow_sk && streamk_enabled() && a.act == SEGAN_ACT_NONE && ntiles >= 64 && nch >= 8 &&
+      classic_eff < 0.97) {
+    // workgroups resident per CU (registers / LDS): the grid is exactly one resident round
+    static int occ_cache = 0;
+    static size_t occ_lds = 0;
+    if (occ_cache == 0 || occ_lds != lds) {
+      int nb = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern),
+                                                       256, lds) != hipSuccess || nb < 1)
+        nb = 2;
+      occ_cache = nb > 4 ? 4 : nb;
+      occ_lds = lds;
+    }
+    const int occ = occ_cache;
+    const int G = 256 * occ;
+    a.sk_nfull = (ntiles / G) * G;
+    const int rem = ntiles - a.sk_nfull;
+    a.sk_total = (long)rem * nch;
+    a.sk_units = (int)((a.sk_total + G - 1) / G);
+    grid = (unsigned)G;
+    // tiles cut across workgroups are accumulated with atomics: zero the destinations
+    hipError_t e = hipSuccess;
+    if (a.out0 && a.out0_elems) e = hipMemsetAsync(a.out0, 0, a.out0_elems * sizeof(float), st);
+    if (e == hipSuccess && a.out1 && a.out1_elems)
+      e = hipMemsetAsync(a.out1, 0, a.out1_elems * sizeof(float), st);
+    if (e == hipSuccess && a.halo && a.halo_elems)
+      e = hipMemsetAsync(a.halo, 0, a.halo_elems * sizeof(float), st);
+    if (e != hipSuccess) {
+      segan_set_error("corr: memset failed: %s", hipGetErrorString(e));
+      return SEGAN_ELAUNCH;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
   return segan_check_launch("corr_kernel");
 }
 
@@ -475,20 +560,21 @@ static int launch_corr_f(CorrArgs& a, hipStream_t st) {
   a.ncoltiles = ceil_div(a.Ctot, NB);
   a.RLs = NB + samples_per_tile(a.Tcols, NB) * a.H;
   bool small = a.Rvalid <= 64;
-  if (!small)
+  if (!small && !streamk_enabled())
     small = prefer_half_tile(ceil_div(a.Rvalid, 128) * a.ncoltiles, ceil_div(a.Rvalid, 64) * a.ncoltiles);
   if (a.RLs <= 256) {
-    if (!small && U <= 16) return launch_corr_t<128, NB, 2, U, true, false, false, 1, 32>(a, st);
-    return small ? launch_corr_t<64, NB, 2, U, true, false, false, 1, KCH>(a, st)
-                 : launch_corr_t<128, NB, 2, U, true, false, false, 1, KCH>(a, st);
+    if (!small && U <= 16)
+      return launch_corr_t<128, NB, 2, U, true, false, false, 1, 32>(a, st, true);
+    return small ? launch_corr_t<64, NB, 2, U, true, false, false, 1, KCH>(a, st, false)
+                 : launch_corr_t<128, NB, 2, U, true, false, false, 1, KCH>(a, st, true);
   }
   if (a.RLs > 512) {
     segan_set_error("corr: sample length %d too short for stride %d (RLs=%d)", a.Tcols, 32 / U,
                     a.RLs);
     return SEGAN_EUNSUPPORTED;
   }
-  return small ? launch_corr_t<64, NB, 2, U, true, false, false, 2, KCH>(a, st)
-               : launch_corr_t<128, NB, 2, U, true, false, false, 2, KCH>(a, st);
+  return small ? launch_corr_t<64, NB, 2, U, true, false, false, 2, KCH>(a, st, false)
+               : launch_corr_t<128, NB, 2, U, true, false, false, 2, KCH>(a, st, true);
 }
 
 // ---- T form (deconv forward, conv data gradient) ----
@@ -497,7 +583,7 @@ static int launch_corr_tt(CorrArgs& a, hipStream_t st) {
   constexpr int S = 32 / U;
   const int nrt = a.NP / (128 / S);
   const int ct128 = ceil_div(a.Ctot, 128), ct64 = ceil_div(a.Ctot, 64);
-  const bool half = prefer_half_tile(nrt * ct128, nrt * ct64);
+  const bool half = !streamk_enabled() && prefer_half_tile(nrt * ct128, nrt * ct64);
   const int NB = half ? 64 : 128;
   a.ncoltiles = half ? ct64 : ct128;
   a.RLs = NB + samples_per_tile(a.Tcols, NB) * a.H;
@@ -508,10 +594,10 @@ static int launch_corr_tt(CorrArgs& a, hipStream_t st) {
   }
   constexpr int KC = U <= 16 ? 32 : KCH;
   if (a.RLs <= 256)
-    return half ? launch_corr_t<128, 64, 2, U, false, true, SHIFT, 1, KC>(a, st)
-                : launch_corr_t<128, 128, 1, U, false, true, SHIFT, 1, KC>(a, st);
-  return half ? launch_corr_t<128, 64, 2, U, false, true, SHIFT, 2, KCH>(a, st)
-              : launch_corr_t<128, 128, 1, U, false, true, SHIFT, 2, KCH>(a, st);
+    return half ? launch_corr_t<128, 64, 2, U, false, true, SHIFT, 1, KC>(a, st, false)
+                : launch_corr_t<128, 128, 1, U, false, true, SHIFT, 1, KC>(a, st, true);
+  return half ? launch_corr_t<128, 64, 2, U, false, true, SHIFT, 2, KCH>(a, st, false)
+              : launch_corr_t<128, 128, 1, U, false, true, SHIFT, 2, KCH>(a, st, true);
 }
 
 template <bool IN_HI, bool OUT_HI>
@@ -1118,6 +1204,7 @@ extern "C" int segan_conv1d_fwd(const segan_src* x, const float* wf, const float
   a.win_start = 0; a.H = U - 1;
   a.NP = 1; a.Nout = 0;
   a.OC0 = M; a.OC1 = 0; a.Lout = a.Tcols; a.act = SEGAN_ACT_NONE;
+  a.out0_elems = (size_t)B * M * a.Tcols;
   return launch_corr<true, false>(a, U, (hipStream_t)stream);
 }
 
@@ -1144,6 +1231,8 @@ extern "C" int segan_deconv1d_dgrad(const float* dy, const float* wf, float* dx0
   if (M0 == 0) { a.out0 = dx1; a.OC0 = M; a.out1 = nullptr; a.OC1 = 0; }
   else { a.out0 = dx0; a.OC0 = M0; a.out1 = dx1; a.OC1 = M - M0; }
   a.Lout = Ls; a.act = SEGAN_ACT_NONE;
+  a.out0_elems = (size_t)B * a.OC0 * Ls;
+  a.out1_elems = (size_t)B * a.OC1 * Ls;
   return launch_corr<true, false>(a, U, (hipStream_t)stream);
 }
 
@@ -1178,6 +1267,7 @@ extern "C" int segan_deconv1d_fwd(const segan_src* x, const float* wt, const flo
   a.H = U - 1 + (cmax - cmin);
   a.OC0 = N; a.OC1 = 0; a.Lout = S * Ls; a.act = act;
   a.o_padL = 0; a.o_roll = 0; a.o_padR = 0;
+  a.out0_elems = (size_t)B * N * S * Ls;
   if (w && N <= 2) return launch_tsmall(a, w, K, M, N, S, pad, (hipStream_t)stream);
   return launch_corr<false, true>(a, U, (hipStream_t)stream);
 }
@@ -1211,6 +1301,8 @@ extern "C" int segan_conv1d_dgrad(const float* da, const float* wt, const float*
   a.H = U - 1;
   a.OC0 = N; a.OC1 = 0; a.Lout = L; a.act = SEGAN_ACT_NONE;
   a.o_padL = padL; a.o_roll = roll; a.o_padR = padR;
+  a.out0_elems = (size_t)B * N * L;
+  a.halo_elems = (size_t)B * N * (padL + padR);
   int e = (w && N <= 2) ? launch_tsmall(a, w, K, M, N, S, 0, st)
                         : launch_corr<false, true>(a, U, st);
   if (e) return e;

@@ -220,7 +220,9 @@ def test_default_segan_plus_step_matches_reference(segan_plus_b2):
 def test_generator_full_batch_is_per_sample_independent():
     """BASELINE size (B=300, 16384 samples): G has no cross-sample coupling, so every
     row of a batch-300 forward must equal the same row run alone (size-independent
-    property; the oracle cannot run B=300 in seconds)."""
+    property; the oracle cannot run B=300 in seconds).  Agreement is to fp32 roundoff, not
+    bitwise: at B=300 the last partial round of tiles is split along K across workgroups
+    (stream-K), which changes the association of the sums."""
     from segan_pytorch_amd.models import Generator
     torch.manual_seed(1)
     G = Generator(1, [64, 128, 256, 512, 1024], 31, [4] * 5, z_dim=1024, skip_merge='concat',
@@ -238,7 +240,7 @@ def test_generator_full_batch_is_per_sample_independent():
         assert torch.isfinite(y).all()
         for rows in ((0, 2), (151, 153), (298, 300)):
             ys = G(x[rows[0]:rows[1]].contiguous(), z=z[rows[0]:rows[1]].contiguous())
-            assert (ys - y[rows[0]:rows[1]]).abs().max().item() < 1e-6
+            assert (ys - y[rows[0]:rows[1]]).abs().max().item() < 2e-5
 
 
 def test_generator_grads_are_batch_shardable():
