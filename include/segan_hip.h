@@ -133,6 +133,11 @@ int segan_bn_stats(const float* x, const float* gamma, const float* beta, float 
 int segan_affine_prelu(const float* x, const float* scale, const float* shift, const float* slope,
                        float* y, int B, int C, int L, void* stream);
 
+/* GSkip with merge_mode 'sum' (generator.py:64-74): out = prelu(x0, slope0) + alpha[c]*x1
+ * (slope0 NULL = identity); all [B,C,L]. */
+int segan_sum_skip(const float* x0, const float* slope0, const float* x1, const float* alpha,
+                   float* out, int B, int C, int L, void* stream);
+
 /* Backward through an (optional BN) + PReLU/identity + optional alpha-skip tap of a
  * pre-activation a[B,C,L]:
  *   v  = a*scale + shift (BN folded; identity when NULL)
@@ -174,6 +179,10 @@ int segan_bias_prelu_rows_bwd(const float* x, const float* bias, const float* sl
  * upstream scalar gradient as a DEVICE pointer (no host sync). */
 int segan_mse_const(const float* x, float target, float* loss, float* grad, const float* gout,
                     float gscale, int n, void* stream);
+/* F.binary_cross_entropy_with_logits against a constant label (WSEGAN --vanilla_gan,
+ * model.py:582-583); same argument meaning as segan_mse_const. */
+int segan_bce_logits_const(const float* x, float target, float* loss, float* grad,
+                           const float* gout, float gscale, int n, void* stream);
 /* loss[0] = mean(|x - y|)  (n may be large; ws: scratch of 1024 floats). */
 int segan_l1_mean(const float* x, const float* y, float* loss, float* ws, int64_t n,
                   void* stream);

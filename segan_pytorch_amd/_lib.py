@@ -47,6 +47,8 @@ SIGNATURES = {
     'segan_bn_stats': (c_int, [_P, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, _P, c_int, c_int,
                                c_int, _P]),
     'segan_affine_prelu': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    'segan_sum_skip': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    'segan_bce_logits_const': (c_int, [_P, c_float, _P, _P, _P, c_float, c_int, _P]),
     'segan_act_bwd': (c_int, [_P] * 16 + [c_int, c_int, c_int, _P]),
     'segan_tanh_bwd': (c_int, [_P, _P, _P, c_float, _P, _P, _P, c_int, c_int, c_int, _P]),
     'segan_gemm': (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int64, c_int, c_int,

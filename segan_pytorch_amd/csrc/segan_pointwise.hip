@@ -169,6 +169,30 @@ extern "C" int segan_affine_prelu(const float* x, const float* scale, const floa
   return segan_check_launch("affine_prelu");
 }
 
+// out = prelu(x0, slope0) + alpha * x1   (GSkip with merge_mode 'sum', generator.py:64-74)
+__global__ void sum_skip_kernel(const float* __restrict__ x0, const float* slope0,
+                                const float* __restrict__ x1, const float* alpha,
+                                float* __restrict__ out, size_t total, int C, int L) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)((i / L) % C);
+    float v = x0[i];
+    if (slope0) v = v > 0.f ? v : v * slope0[c];
+    out[i] = fmaf(alpha[c], x1[i], v);
+  }
+}
+
+extern "C" int segan_sum_skip(const float* x0, const float* slope0, const float* x1,
+                              const float* alpha, float* out, int B, int C, int L, void* stream) {
+  SEGAN_REQUIRE(x0 && x1 && alpha && out, "sum_skip: NULL pointer");
+  SEGAN_REQUIRE(B > 0 && C > 0 && L > 0, "sum_skip: bad sizes");
+  const size_t total = (size_t)B * C * L;
+  const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipLaunchKernelGGL(sum_skip_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x0, slope0,
+                     x1, alpha, out, total, C, L);
+  return segan_check_launch("sum_skip");
+}
+
 // ---------------------------------------------------------------------------------
 // backward of (BN +) PReLU + alpha-skip tap
 // ---------------------------------------------------------------------------------
@@ -459,6 +483,31 @@ extern "C" int segan_mse_const(const float* x, float target, float* loss, float*
   hipLaunchKernelGGL(mse_const_kernel, dim3(1), dim3(PW_THREADS), 0, (hipStream_t)stream, x, target,
                      loss, grad, gout, gscale, n);
   return segan_check_launch("mse_const");
+}
+
+// F.binary_cross_entropy_with_logits against a constant label (WSEGAN --vanilla_gan,
+// model.py:582-583): loss = mean(max(x,0) - x*t + log1p(exp(-|x|))), d/dx = (sigmoid(x)-t)/n
+__global__ void bce_const_kernel(const float* __restrict__ x, float target, float* loss,
+                                 float* grad, const float* gout, float gscale, int n) {
+  __shared__ float sm[16];
+  float r[1] = {0.f};
+  const float inv = 1.0f / (float)n;
+  if (gout) gscale *= gout[0];
+  for (int i = threadIdx.x; i < n; i += PW_THREADS) {
+    const float v = x[i];
+    r[0] += fmaxf(v, 0.f) - v * target + log1pf(expf(-fabsf(v)));
+    if (grad) grad[i] = (1.0f / (1.0f + expf(-v)) - target) * inv * gscale;
+  }
+  block_sum<1>(r, sm);
+  if (threadIdx.x == 0 && loss) loss[0] = r[0] * inv;
+}
+
+extern "C" int segan_bce_logits_const(const float* x, float target, float* loss, float* grad,
+                                      const float* gout, float gscale, int n, void* stream) {
+  SEGAN_REQUIRE(x && n > 0 && (loss || grad), "bce_logits_const: bad arguments");
+  hipLaunchKernelGGL(bce_const_kernel, dim3(1), dim3(PW_THREADS), 0, (hipStream_t)stream, x, target,
+                     loss, grad, gout, gscale, n);
+  return segan_check_launch("bce_logits_const");
 }
 
 __global__ void l1_partial_kernel(const float* __restrict__ x, const float* __restrict__ y,

@@ -107,11 +107,16 @@ class GeneratorFn(torch.autograd.Function):
                 prev = a_dec[-1]
                 s_prev = dec[li - 1].act.weight
                 if gen.skip and enc_idx in gen.skips and gen.dec_poolings[li] > 1:
-                    alpha = gen.skips[enc_idx]['alpha'].skip_k
+                    gskip = gen.skips[enc_idx]['alpha']
+                    alpha = gskip.skip_k
                     aj = a_enc[enc_idx]
-                    src = Src(prev, aj,
-                              scale=_cat(_ones(prev.shape[1], prev), alpha),
-                              slope=_cat(s_prev, _ones(aj.shape[1], aj)))
+                    if gskip.merge_mode == 'concat':
+                        src = Src(prev, aj,
+                                  scale=_cat(_ones(prev.shape[1], prev), alpha),
+                                  slope=_cat(s_prev, _ones(aj.shape[1], aj)))
+                    else:   # 'sum' (generator.py:71-73): prelu(prev) + alpha*a_j, materialised
+                        src = Src(ops.sum_skip(prev, s_prev, aj, alpha.detach().reshape(-1)))
+                        src.sum_of = True
                 else:
                     src = Src(prev, slope=s_prev)
             act = ACT_TANH if blk.is_tanh else ACT_NONE
@@ -182,6 +187,8 @@ class GeneratorFn(torch.autograd.Function):
                     dskip[n_enc - 1 - li] = dsk
                 else:
                     _d0, dh = ops.deconv1d_dgrad(da, w, S, 0, pack=blk._pack)
+                    if getattr(src, 'sum_of', False):
+                        dskip[n_enc - 1 - li] = dh    # d(prelu(prev) + alpha*a_j): same gradient
         # ---- encoder, last to first ----
         dh = dh_last_enc
         dx = None
@@ -450,6 +457,23 @@ class MSEConstFn(torch.autograd.Function):
     def backward(ctx, g):
         (x,) = ctx.saved_tensors
         return ops.mse_const_bwd(x, ctx.target, gout=g.contiguous()), None
+
+
+class BCELogitsConstFn(torch.autograd.Function):
+    """F.binary_cross_entropy_with_logits(x, label) for a constant label (WSEGAN
+    --vanilla_gan, model.py:582-583)."""
+
+    @staticmethod
+    def forward(ctx, x, target):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        ctx.target = float(target)
+        return ops.bce_logits_const(x, target)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return ops.bce_logits_const_bwd(x, ctx.target, gout=g.contiguous()), None
 
 
 class L1MeanFn(torch.autograd.Function):

@@ -18,6 +18,15 @@ class MSELoss(nn.Module):
         return Fn.MSEConstFn.apply(input, float(target))
 
 
+class BCEWithLogitsLoss(nn.Module):
+    """F.binary_cross_entropy_with_logits against a constant label (WSEGAN --vanilla_gan)."""
+
+    def forward(self, input, target):
+        if torch.is_tensor(target):
+            target = float(target.reshape(-1)[0].item())
+        return Fn.BCELogitsConstFn.apply(input, float(target))
+
+
 def mse_loss(input, target):
     return MSELoss()(input, target)
 

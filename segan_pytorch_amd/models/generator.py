@@ -45,10 +45,6 @@ class GSkip(nn.Module):
             raise NotImplementedError('skip_dropout > 0 is not implemented in segan_pytorch_amd')
         if merge_mode not in ('sum', 'concat'):
             raise TypeError('Unrecognized skip merge mode: ', merge_mode)
-        if merge_mode == 'sum':
-            raise NotImplementedError(
-                "skip_merge='sum' is not implemented yet in segan_pytorch_amd; SEGAN+/WSEGAN "
-                "train with --skip_merge concat (train.py:184)")
 
     def __repr__(self):
         if self.skip_type == 'alpha':

@@ -259,9 +259,6 @@ class WSEGAN(SEGAN):
         self.pow_weight = opts.pow_weight
         self.vanilla_gan = opts.vanilla_gan
         self.n_fft = opts.n_fft
-        if self.vanilla_gan:
-            raise NotImplementedError('--vanilla_gan (BCE-with-logits cost, model.py:582-583) is '
-                                      'not implemented; the LSGAN cost is')
         # like the reference: SEGAN.__init__ builds and initialises with weights_init
         # (consuming the same RNG draws), then both nets are re-initialised Xavier-uniform
         super(WSEGAN, self).__init__(opts, name, None, None)
@@ -285,7 +282,7 @@ class WSEGAN(SEGAN):
         """One WSEGAN step (model.py:577-669).  Returns (d_loss, G_cost, pow_loss,
         den_loss) as device scalars."""
         from random import shuffle
-        cost = losses.MSELoss()
+        cost = losses.BCEWithLogitsLoss() if self.vanilla_gan else losses.MSELoss()
         bsz = clean.size(0)
         Dopt.zero_grad()
         d_real, _ = self.infer_D(clean, noisy)

@@ -275,6 +275,19 @@ def affine_prelu(x, scale=None, shift=None, slope=None):
     return y
 
 
+def sum_skip(x0, slope0, x1, alpha):
+    """prelu(x0, slope0) + alpha * x1 (GSkip merge_mode 'sum')."""
+    _chk(x0, 'x0', 3)
+    _chk(x1, 'x1', 3)
+    if x0.shape != x1.shape:
+        raise ValueError('sum_skip: shapes differ {} vs {}'.format(tuple(x0.shape), tuple(x1.shape)))
+    B, C, L = x0.shape
+    out = torch.empty_like(x0)
+    check(_lib.load().segan_sum_skip(_ptr(x0), _ptr(slope0), _ptr(x1), _ptr(alpha), _ptr(out), B, C,
+                                     L, _stream()), 'sum_skip')
+    return out
+
+
 def act_bwd(a, dh, dskip=None, slope=None, alpha=None, bn=None, dslope=None, dalpha=None,
             dgamma=None, dbeta=None, dbias=None):
     """Backward of (BN+)PReLU(+alpha skip) on pre-activation a; returns da.
@@ -373,6 +386,23 @@ def mse_const_bwd(x, target, gout=None, gscale=1.0):
     grad = torch.empty_like(x)
     check(_lib.load().segan_mse_const(_ptr(x), float(target), None, _ptr(grad), _ptr(gout),
                                       float(gscale), x.numel(), _stream()), 'mse_const_bwd')
+    return grad
+
+
+def bce_logits_const(x, target):
+    _chk(x, 'x')
+    loss = torch.empty((), device=x.device, dtype=torch.float32)
+    check(_lib.load().segan_bce_logits_const(_ptr(x), float(target), _ptr(loss), None, None, 1.0,
+                                             x.numel(), _stream()), 'bce_logits_const')
+    return loss
+
+
+def bce_logits_const_bwd(x, target, gout=None, gscale=1.0):
+    _chk(x, 'x')
+    grad = torch.empty_like(x)
+    check(_lib.load().segan_bce_logits_const(_ptr(x), float(target), None, _ptr(grad), _ptr(gout),
+                                             float(gscale), x.numel(), _stream()),
+          'bce_logits_const_bwd')
     return grad
 
 

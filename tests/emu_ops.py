@@ -116,6 +116,25 @@ def affine_prelu(x, scale=None, shift=None, slope=None):
     return _mat(ops.Src(x, scale=scale, shift=shift, slope=slope)).float()
 
 
+def sum_skip(x0, slope0, x1, alpha):
+    v = x0.double()
+    if slope0 is not None:
+        v = torch.where(v > 0, v, v * slope0.detach().double().view(1, -1, 1))
+    return (v + alpha.detach().double().view(1, -1, 1) * x1.double()).float()
+
+
+def bce_logits_const(x, target):
+    t = torch.full_like(x.double(), target)
+    return F.binary_cross_entropy_with_logits(x.double(), t).float()
+
+
+def bce_logits_const_bwd(x, target, gout=None, gscale=1.0):
+    g = (torch.sigmoid(x.double()) - target) / x.numel() * gscale
+    if gout is not None:
+        g = g * gout.double()
+    return g.float()
+
+
 def _acc(dst, val):
     if dst is not None:
         dst.add_(val.float().view(dst.shape))
@@ -243,7 +262,7 @@ def _chk(t, name, ndim=None):
 
 
 _NAMES = ['conv1d_fwd', 'conv1d_dgrad', 'wgrad', 'deconv1d_fwd', 'deconv1d_dgrad', 'bn_stats',
-          'affine_prelu', 'act_bwd', 'tanh_bwd', 'linear_fwd', 'linear_dgrad', 'linear_wgrad',
+          'affine_prelu', 'sum_skip', 'bce_logits_const', 'bce_logits_const_bwd', 'act_bwd', 'tanh_bwd', 'linear_fwd', 'linear_dgrad', 'linear_wgrad',
           'bias_prelu_rows', 'bias_prelu_rows_bwd', 'mse_const', 'mse_const_bwd', 'l1_mean',
           'l1_bwd', 'rmsprop_step', 'adam_step', 'fill_', 'scale_', '_chk']
 

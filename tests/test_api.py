@@ -103,7 +103,7 @@ def test_argument_validation_mirrors_reference_errors():
         GConv1DBlock(1, 4, 31, stride=4, norm_type='bogus')
     with pytest.raises(AssertionError):      # generator.py:105
         Generator(1, (8, 16), 31, [4, 4])
-    g = Generator(1, [8, 16], 31, [4, 4], z_dim=8, skip_merge='concat')
+    g = Generator(1, [8, 16], 31, [4, 4], z_dim=8)        # default skip_merge='sum' builds
     with pytest.raises(ValueError):
         g(torch.zeros(1, 1, 30))             # not divisible by the pooling
     with pytest.raises(ValueError):          # generator.py:200-202

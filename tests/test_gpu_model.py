@@ -339,3 +339,17 @@ def test_wsegan_literal_train_matches_reference(tmp_path):
             o['l1_dec_epoch'], 1000, va_dloader=None, device=DEV)
     assert_weights_after_step(m.G.state_dict(), fx['G_final'])
     assert_weights_after_step(m.D.state_dict(), fx['D_final'], skip=NOISE_KEYS)
+
+
+def test_generator_sum_merge_on_gpu():
+    from test_host_orchestration import _sum_merge_reference, make_sum_generator
+    g = make_sum_generator(DEV)
+    x, z = torch.randn(2, 1, 1024), torch.randn(2, 32, 16)
+    y = g(x.to(DEV), z=z.to(DEV))
+    y.square().sum().backward()
+    sd = {k: v.detach().cpu().double().requires_grad_(True) for k, v in g.state_dict().items()}
+    yr = _sum_merge_reference(sd, x.double(), z.double())
+    yr.square().sum().backward()
+    assert max_rel(y, yr) < ACT_TOL
+    for k, p in g.named_parameters():
+        assert max_rel(p.grad, sd[k].grad) < GRAD_TOL, k

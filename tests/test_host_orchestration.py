@@ -186,3 +186,62 @@ def test_wsegan_literal_train(tiny_wsegan2, tmp_path):
             o['l1_dec_epoch'], 1000, va_dloader=None, device='cpu')
     assert_weights_after_step(m.G.state_dict(), fx['G_final'])
     assert_weights_after_step(m.D.state_dict(), fx['D_final'], skip=NOISE_KEYS)
+
+
+def _sum_merge_reference(sd, x, z):
+    """generator.py:180-230 with skip_merge='sum' (GSkip.forward 64-74)."""
+    import segan_oracle as O
+    hi, skips = x, {}
+    for l in range(3):
+        p = 'enc_blocks.%d.' % l
+        hi, lin = O.gconv_block(hi, sd[p + 'conv.weight'], sd[p + 'conv.bias'], sd[p + 'act.weight'], 4)
+        if l < 2:
+            skips[l] = lin
+    hi = torch.cat((z, hi), 1)
+    e = 2
+    for l in range(3):
+        if e in skips:
+            hi = sd['alpha_%d.skip_k' % e] * skips[e] + hi
+        p = 'dec_blocks.%d.' % l
+        hi = O.gdeconv_block(hi, sd[p + 'deconv.weight'], sd[p + 'deconv.bias'],
+                             sd.get(p + 'act.weight'), 4, tanh=(l == 2))
+        e -= 1
+    return hi
+
+
+def make_sum_generator(device='cpu'):
+    from segan_pytorch_amd.models import Generator
+    torch.manual_seed(0)
+    g = Generator(1, [8, 16, 32], 31, [4, 4, 4], z_dim=32, skip_merge='sum', bias=True)
+    for p in g.parameters():
+        if p.dim() == 1:
+            p.data.uniform_(0.05, 0.3)
+    for i in range(2):
+        getattr(g, 'alpha_%d' % i).skip_k.data.uniform_(0.5, 1.5)
+    return g.to(device)
+
+
+def test_generator_sum_merge():
+    """skip_merge='sum' is the Generator's own default (generator.py:95)."""
+    g = make_sum_generator()
+    x, z = torch.randn(2, 1, 1024), torch.randn(2, 32, 16)
+    y = g(x, z=z)
+    y.square().sum().backward()
+    sd = {k: v.detach().double().requires_grad_(True) for k, v in g.state_dict().items()}
+    yr = _sum_merge_reference(sd, x.double(), z.double())
+    yr.square().sum().backward()
+    assert max_rel(y, yr) < 2e-5
+    for k, p in g.named_parameters():
+        assert max_rel(p.grad, sd[k].grad) < 1e-4, k
+
+
+def test_bce_cost():
+    import torch.nn.functional as F
+    from segan_pytorch_amd import losses
+    d = torch.randn(7, 1, requires_grad=True)
+    l = losses.BCEWithLogitsLoss()(d.view(-1), 1.0)
+    (0.5 * l).backward()
+    dd = d.detach().double().requires_grad_(True)
+    lr = F.binary_cross_entropy_with_logits(dd.view(-1), torch.ones(7, dtype=torch.float64))
+    (0.5 * lr).backward()
+    assert abs(l.item() - lr.item()) < 1e-6 and max_rel(d.grad, dd.grad) < 1e-5
