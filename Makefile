@@ -2,14 +2,14 @@
 HIPCC ?= /opt/rocm/bin/hipcc
 ARCH ?= gfx950
 CSRC := segan_pytorch_amd/csrc
-SRCS := $(CSRC)/segan_api.hip $(CSRC)/segan_conv.hip $(CSRC)/segan_pointwise.hip $(CSRC)/segan_gemm.hip
+SRCS := $(CSRC)/segan_api.hip $(CSRC)/segan_conv.hip $(CSRC)/segan_conv_bf.hip $(CSRC)/segan_pointwise.hip $(CSRC)/segan_gemm.hip
 OBJS := $(SRCS:.hip=.o)
 LIB := segan_pytorch_amd/libsegan_hip.so
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wall -Wno-unused-function
 
 all: $(LIB)
 
-$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/segan_common.h include/segan_hip.h
+$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/segan_common.h $(CSRC)/segan_conv_shared.h include/segan_hip.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(LIB): $(OBJS)

@@ -193,6 +193,10 @@ def main():
     ap.add_argument('--batch', type=int, default=300, help='chunks per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timer', action='store_true')
+    ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16x3', 'bf16'],
+                    help='forward/data-gradient contraction precision (default: exact fp32, the '
+                         'BASELINE configuration; bf16x3 = exact 3-way bf16 split of fp32 operands; '
+                         'bf16 = BASELINE config 5)')
     args = ap.parse_args()
 
     from segan_pytorch_amd import distributed as sdist
@@ -200,6 +204,8 @@ def main():
     from segan_pytorch_amd.datasets import synthetic_pairs
     from segan_pytorch_amd.models import SEGAN
 
+    from segan_pytorch_amd import ops as _ops
+    _ops.set_precision(args.precision)
     rank, world, local = sdist.init_from_env()
     if world != max(1, args.gpus) and world > 1:
         raise SystemExit('--gpus {} but WORLD_SIZE {}'.format(args.gpus, world))
@@ -259,7 +265,8 @@ def main():
             'metric': '16384-sample waveform chunks/sec (GAN step)', 'value': value,
             'unit': 'chunks/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
+            'dtype': {'fp32': 'f32', 'bf16x3': 'f32 operands as 3 bf16 planes (6 products), f32 accumulate',
+                      'bf16': 'bf16 operands, f32 accumulate'}[args.precision], 'data': 'synthetic',
             'config': {'workload': 'SEGAN+ default G+D (5+5 layers, k31, stride 4, z 1024x16), '
                                    'batch {} x 16384-sample chunks per GPU, full GAN step '
                                    '(model.py:292-321), RMSprop, fp32'.format(B),

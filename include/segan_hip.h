@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SEGAN_ABI_VERSION 1
+#define SEGAN_ABI_VERSION 2
 
 #define SEGAN_PAD_REFLECT 0
 #define SEGAN_PAD_ZERO 1
@@ -69,6 +69,21 @@ size_t segan_packed_t_bytes(int M, int N, int S);
 int segan_pack_weights(const float* w, float* wf, float* wt, int M, int N, int K, int S,
                        int pad_t, void* stream);
 
+/* Precision of the four forward / data-gradient contractions below (`precision` argument):
+ *   SEGAN_PREC_FP32   exact fp32 on v_mfma_f32_32x32x2_f32; packed weights from
+ *                     segan_pack_weights (the default, and the benchmarked configuration)
+ *   SEGAN_PREC_BF16   operands rounded to bf16, fp32 accumulate (BASELINE config 5)
+ *   SEGAN_PREC_BF16X3 every fp32 operand split exactly into 3 bf16 planes, 6 partial products:
+ *                     fp32-class accuracy on the bf16 matrix cores
+ * The two bf16 modes read weights packed by segan_pack_weights_bf (planes = 1 / 3); a
+ * geometry they do not cover returns -3 (unsupported) and the caller uses fp32. */
+#define SEGAN_PREC_FP32 0
+#define SEGAN_PREC_BF16 1
+#define SEGAN_PREC_BF16X3 3
+size_t segan_packed_bf_bytes(int M, int N, int S, int tform, int planes);
+int segan_pack_weights_bf(const float* w, void* out, int M, int N, int K, int S, int tform,
+                          int pad_t, int planes, void* stream);
+
 /* GConv1DBlock forward without norm/activation (modules.py:91-99):
  *   out[b,m,t] = bias[m] + sum_{n,k} w[m,n,k] * pad(roll(x))[b,n,S*t+k]
  * x: [B, N, L] (segan_src), out: [B, M, L/S].  mode = reflect with
@@ -76,17 +91,18 @@ int segan_pack_weights(const float* w, float* wf, float* wt, int M, int N, int K
  * `roll` is the discriminator phase shift (discriminator.py:160-172; the conv sees
  * torch.roll(x, roll, 2)).  The output is the PRE-activation; its consumer applies
  * PReLU/BN through its own segan_src. */
-int segan_conv1d_fwd(const segan_src* x, const float* wf, const float* bias, float* out, int B,
+int segan_conv1d_fwd(const segan_src* x, const void* wf, const float* bias, float* out, int B,
                      int N, int M, int L, int K, int S, int padL, int mode, int roll,
-                     void* stream);
+                     int precision, void* stream);
 
 /* Data gradient of the above (autograd of modules.py:98-99): dx[b,n,i] += over the
  * reflect-padded, rolled coordinates.  da: [B, M, L/S]; dx: [B, N, L] is fully
  * overwritten.  `halo` is scratch of B*N*(K-1) floats.  `w` (optional) is the UNPACKED
  * weight [M][N][K]: when given and N <= 2 (the first layer: 1-2 input channels) a direct
  * VALU kernel is used instead of the MFMA tile kernel and `wt` may be NULL. */
-int segan_conv1d_dgrad(const float* da, const float* wt, const float* w, float* dx, float* halo,
-                       int B, int N, int M, int L, int K, int S, int padL, int roll, void* stream);
+int segan_conv1d_dgrad(const float* da, const void* wt, const float* w, float* dx, float* halo,
+                       int B, int N, int M, int L, int K, int S, int padL, int roll, int precision,
+                       void* stream);
 
 /* Weight gradient shared by both layer types (W form):
  *   dw[m,n,k] += sum_{b,t} lo[b,m,t] * pad(roll(hi))[b,n,S*t+k]
@@ -103,16 +119,16 @@ int segan_wgrad(const segan_src* lo, const segan_src* hi, float* dw, int B, int 
  * generator.py:64-76 are its second segment), y: [B, N, S*Ls].  `w` (optional): the
  * UNPACKED weight; with N <= 2 (the last generator layer, Cout = 1) the direct VALU
  * kernel is used and `wt` may be NULL. */
-int segan_deconv1d_fwd(const segan_src* x, const float* wt, const float* w, const float* bias,
+int segan_deconv1d_fwd(const segan_src* x, const void* wt, const float* w, const float* bias,
                        float* y, int B, int M, int N, int Ls, int K, int S, int pad, int act,
-                       void* stream);
+                       int precision, void* stream);
 
 /* Data gradient of the deconv: dx[b,m,t] = sum_{n,k} w[m,n,k] * dy[b,n,S*t+k-pad].
  * The M rows are split at M0 into two destinations (dx0: [B,M0,Ls], dx1:
  * [B,M-M0,Ls]); a NULL destination skips that half's tiles entirely (the z half of
  * the first decoder layer needs no gradient). */
-int segan_deconv1d_dgrad(const float* dy, const float* wf, float* dx0, float* dx1, int B, int M,
-                         int M0, int N, int Ls, int K, int S, int pad, void* stream);
+int segan_deconv1d_dgrad(const float* dy, const void* wf, float* dx0, float* dx1, int B, int M,
+                         int M0, int N, int Ls, int K, int S, int pad, int precision, void* stream);
 
 /* ---- per-channel pointwise / reduction kernels ------------------------------------ */
 

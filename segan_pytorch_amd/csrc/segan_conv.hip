@@ -19,71 +19,7 @@
 // discriminator's circular phase shift, both torch.cat's, the alpha skip scale,
 // BatchNorm-normalise and PReLU are all applied while the tile is staged
 // (segan_src), so none of those tensors is ever materialised in HBM.
-#include "segan_common.h"
-#include <stdlib.h>
-
-#define KCH 64  // contraction elements per LDS chunk (= 32 MFMA k-steps of 2)
-
-// ------------------------------------------------------------------------------------
-// column bookkeeping: the GEMM column space is the flattened (sample, time) axis.  A
-// tile of NB consecutive columns may cover several short samples; in LDS every sample
-// segment carries its own halo of H entries, so column `cl` of local sample s sits at
-// LDS position cl + s*H and tap u of it at cl + s*H + u.
-// ------------------------------------------------------------------------------------
-struct ColTile {
-  int col0, b0, t_first, len0;
-};
-
-__device__ __forceinline__ ColTile make_coltile(int col0, int Tcols, int NBcols) {
-  ColTile t;
-  t.col0 = col0;
-  t.b0 = col0 / Tcols;
-  t.t_first = col0 - t.b0 * Tcols;
-  t.len0 = min(Tcols - t.t_first, NBcols);
-  return t;
-}
-
-// LDS position j -> (local sample s, window coordinate tau)
-__device__ __forceinline__ void lds_pos_decode(const ColTile& ct, int j, int Tcols, int H, int& s,
-                                               int& tau) {
-  if (j < ct.len0 + H) {
-    s = 0;
-    tau = ct.t_first + j;
-  } else {
-    const int jj = j - (ct.len0 + H);
-    const int per = Tcols + H;
-    const int q = jj / per;
-    s = 1 + q;
-    tau = jj - q * per;
-  }
-}
-
-// ====================================================================================
-// corr kernel
-// ====================================================================================
-struct CorrArgs {
-  segan_src in;
-  const float* wp;  // packed weights [KtotP][RP] (zero padded: no guards on the loads)
-  float* out0;
-  float* out1;
-  const float* bias;
-  float* halo;
-  int B, Cv, Ktot, RP, Rvalid;
-  int Tcols, Ctot, ncoltiles;
-  int Lin;                // stored row length of the input tensor
-  int padL, mode, roll;   // HI input view
-  int win_start, H, RLs;  // window geometry
-  int rowshift[4];
-  int NP, Nout;           // T form row decode: row = r*NP + n
-  int OC0, OC1, Lout, act;
-  int o_padL, o_roll, o_padR;  // HI store (conv dgrad: reflect halo)
-  int prio_mode;               // 0: none, 1: hashed static wave priority per workgroup
-  int sk_nfull;                // tiles processed whole (strided over the grid)
-  int sk_units;                // stream-K part: (tile, chunk) units per workgroup
-  long sk_total;               // stream-K part: total units of the remaining tiles
-  int rt0;                     // first row tile (rows below it have a NULL destination)
-  size_t out0_elems, out1_elems, halo_elems;   // host side: what stream-K must zero
-};
+#include "segan_conv_shared.h"
 
 // Staging discipline (both kernels): load_chunk() only ISSUES global loads — every
 // address is clamped to a valid element, so there is no branch and no wait between
@@ -463,8 +399,6 @@ __global__ void fold_halo_kernel(float* dx, const float* halo, int rows, int L, 
 // packed-weight geometry (shared by the pack kernels and the launchers)
 static inline int f_pitch(int M) { return M <= 64 ? 64 : round_up(M, 128); }
 static inline int f_rows(int N) { return round_up(N * 32, KCH); }
-// T form: channels are padded to whole tiles (128/S channels x S phases = 128 rows)
-static inline int t_np(int N, int S) { return round_up(N, 128 / S); }
 static inline int t_pitch(int N, int S) { return S * t_np(N, S); }
 static inline int t_rows(int M, int S) { return round_up(M * (32 / S), KCH); }
 
@@ -534,11 +468,6 @@ static int launch_corr_t(CorrArgs a, hipStream_t st, bool allow_sk) {
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
   return segan_check_launch("corr_kernel");
-}
-
-static int samples_per_tile(int Tcols, int NB) {
-  if (Tcols >= NB) return (Tcols % NB == 0) ? 1 : 2;
-  return (NB % Tcols == 0) ? NB / Tcols : (NB + Tcols - 2) / Tcols + 1;
 }
 
 // All workgroups of a launch do the same amount of work and several are resident per CU
@@ -1180,9 +1109,12 @@ static int check_src(const segan_src* s, int C, const char* what) {
   return SEGAN_OK;
 }
 
-extern "C" int segan_conv1d_fwd(const segan_src* x, const float* wf, const float* bias, float* out,
+static bool precision_ok(int p) { return p == 0 || p == 1 || p == 3; }
+
+extern "C" int segan_conv1d_fwd(const segan_src* x, const void* wf, const float* bias, float* out,
                                 int B, int N, int M, int L, int K, int S, int padL, int mode,
-                                int roll, void* stream) {
+                                int roll, int precision, void* stream) {
+  SEGAN_REQUIRE(precision_ok(precision), "conv1d_fwd: precision must be 0, 1 or 3");
   SEGAN_REQUIRE(stride_ok(S), "conv1d_fwd: stride %d not in {1,2,4}", S);
   SEGAN_REQUIRE(K >= 1 && K <= 32, "conv1d_fwd: kernel width %d not in [1,32]", K);
   SEGAN_REQUIRE(B > 0 && N > 0 && M > 0 && L > 0, "conv1d_fwd: bad sizes");
@@ -1196,7 +1128,7 @@ extern "C" int segan_conv1d_fwd(const segan_src* x, const float* wf, const float
   const int U = 32 / S;
   CorrArgs a = {};
   a.in = *x;
-  a.wp = wf;
+  a.wp = (const float*)wf;
   a.out0 = out; a.out1 = nullptr; a.bias = bias; a.halo = nullptr;
   a.B = B; a.Cv = N * S; a.Ktot = N * 32; a.RP = f_pitch(M); a.Rvalid = M;
   a.Tcols = L / S; a.Ctot = B * a.Tcols;
@@ -1205,12 +1137,14 @@ extern "C" int segan_conv1d_fwd(const segan_src* x, const float* wf, const float
   a.NP = 1; a.Nout = 0;
   a.OC0 = M; a.OC1 = 0; a.Lout = a.Tcols; a.act = SEGAN_ACT_NONE;
   a.out0_elems = (size_t)B * M * a.Tcols;
+  if (precision) return segan_corr_bf_f(a, U, wf, precision, (hipStream_t)stream);
   return launch_corr<true, false>(a, U, (hipStream_t)stream);
 }
 
-extern "C" int segan_deconv1d_dgrad(const float* dy, const float* wf, float* dx0, float* dx1, int B,
+extern "C" int segan_deconv1d_dgrad(const float* dy, const void* wf, float* dx0, float* dx1, int B,
                                     int M, int M0, int N, int Ls, int K, int S, int pad,
-                                    void* stream) {
+                                    int precision, void* stream) {
+  SEGAN_REQUIRE(precision_ok(precision), "deconv1d_dgrad: precision must be 0, 1 or 3");
   SEGAN_REQUIRE(stride_ok(S), "deconv1d_dgrad: stride %d not in {1,2,4}", S);
   SEGAN_REQUIRE(K >= 1 && K <= 32, "deconv1d_dgrad: kernel width %d not in [1,32]", K);
   SEGAN_REQUIRE(B > 0 && N > 0 && M > 0 && Ls > 0, "deconv1d_dgrad: bad sizes");
@@ -1221,7 +1155,7 @@ extern "C" int segan_deconv1d_dgrad(const float* dy, const float* wf, float* dx0
   CorrArgs a = {};
   a.in.p0 = dy; a.in.p1 = nullptr; a.in.C0 = N; a.in.C1 = 0;
   a.in.scale = a.in.shift = a.in.slope = nullptr;
-  a.wp = wf;
+  a.wp = (const float*)wf;
   a.bias = nullptr; a.halo = nullptr;
   a.B = B; a.Cv = N * S; a.Ktot = N * 32; a.RP = f_pitch(M); a.Rvalid = M;
   a.Tcols = Ls; a.Ctot = B * Ls;
@@ -1233,12 +1167,14 @@ extern "C" int segan_deconv1d_dgrad(const float* dy, const float* wf, float* dx0
   a.Lout = Ls; a.act = SEGAN_ACT_NONE;
   a.out0_elems = (size_t)B * a.OC0 * Ls;
   a.out1_elems = (size_t)B * a.OC1 * Ls;
+  if (precision) return segan_corr_bf_f(a, U, wf, precision, (hipStream_t)stream);
   return launch_corr<true, false>(a, U, (hipStream_t)stream);
 }
 
-extern "C" int segan_deconv1d_fwd(const segan_src* x, const float* wt, const float* w,
+extern "C" int segan_deconv1d_fwd(const segan_src* x, const void* wt, const float* w,
                                   const float* bias, float* y, int B, int M, int N, int Ls, int K,
-                                  int S, int pad, int act, void* stream) {
+                                  int S, int pad, int act, int precision, void* stream) {
+  SEGAN_REQUIRE(precision_ok(precision), "deconv1d_fwd: precision must be 0, 1 or 3");
   SEGAN_REQUIRE(stride_ok(S), "deconv1d_fwd: stride %d not in {1,2,4}", S);
   SEGAN_REQUIRE(K >= 1 && K <= 32, "deconv1d_fwd: kernel width %d not in [1,32]", K);
   SEGAN_REQUIRE(B > 0 && N > 0 && M > 0 && Ls > 0, "deconv1d_fwd: bad sizes");
@@ -1250,7 +1186,7 @@ extern "C" int segan_deconv1d_fwd(const segan_src* x, const float* wt, const flo
   const int U = 32 / S;
   CorrArgs a = {};
   a.in = *x;
-  a.wp = wt;
+  a.wp = (const float*)wt;
   a.out0 = y; a.out1 = nullptr; a.bias = bias; a.halo = nullptr;
   a.NP = t_np(N, S); a.Nout = N;
   a.B = B; a.Cv = M; a.Ktot = M * U; a.RP = t_pitch(N, S); a.Rvalid = S * a.NP;
@@ -1269,12 +1205,16 @@ extern "C" int segan_deconv1d_fwd(const segan_src* x, const float* wt, const flo
   a.o_padL = 0; a.o_roll = 0; a.o_padR = 0;
   a.out0_elems = (size_t)B * N * S * Ls;
   if (w && N <= 2) return launch_tsmall(a, w, K, M, N, S, pad, (hipStream_t)stream);
+  if (precision && act == SEGAN_ACT_NONE)
+    return segan_corr_bf_t(a, U, wt, precision, (hipStream_t)stream);
+  SEGAN_REQUIRE(precision == 0, "deconv1d_fwd: tanh epilogue only on the fp32 path");
   return launch_corr<false, true>(a, U, (hipStream_t)stream);
 }
 
-extern "C" int segan_conv1d_dgrad(const float* da, const float* wt, const float* w, float* dx,
+extern "C" int segan_conv1d_dgrad(const float* da, const void* wt, const float* w, float* dx,
                                   float* halo, int B, int N, int M, int L, int K, int S, int padL,
-                                  int roll, void* stream) {
+                                  int roll, int precision, void* stream) {
+  SEGAN_REQUIRE(precision_ok(precision), "conv1d_dgrad: precision must be 0, 1 or 3");
   SEGAN_REQUIRE(stride_ok(S), "conv1d_dgrad: stride %d not in {1,2,4}", S);
   SEGAN_REQUIRE(K >= 1 && K <= 32, "conv1d_dgrad: kernel width %d not in [1,32]", K);
   SEGAN_REQUIRE(B > 0 && N > 0 && M > 0 && L > 0 && L % S == 0, "conv1d_dgrad: bad sizes");
@@ -1288,7 +1228,7 @@ extern "C" int segan_conv1d_dgrad(const float* da, const float* wt, const float*
   CorrArgs a = {};
   a.in.p0 = da; a.in.p1 = nullptr; a.in.C0 = M; a.in.C1 = 0;
   a.in.scale = a.in.shift = a.in.slope = nullptr;
-  a.wp = wt;
+  a.wp = (const float*)wt;
   a.out0 = dx; a.out1 = nullptr; a.bias = nullptr; a.halo = halo;
   a.NP = t_np(N, S); a.Nout = N;
   a.B = B; a.Cv = M; a.Ktot = M * U; a.RP = t_pitch(N, S); a.Rvalid = S * a.NP;
@@ -1304,6 +1244,7 @@ extern "C" int segan_conv1d_dgrad(const float* da, const float* wt, const float*
   a.out0_elems = (size_t)B * N * L;
   a.halo_elems = (size_t)B * N * (padL + padR);
   int e = (w && N <= 2) ? launch_tsmall(a, w, K, M, N, S, 0, st)
+          : precision   ? segan_corr_bf_t(a, U, wt, precision, st)
                         : launch_corr<false, true>(a, U, st);
   if (e) return e;
   if (padL + padR > 0) {

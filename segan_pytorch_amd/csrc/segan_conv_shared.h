@@ -1,0 +1,81 @@
+// Declarations shared by the fp32 (segan_conv.hip) and split-bf16 (segan_conv_bf.hip)
+// contraction kernels: column bookkeeping, launch arguments, packed-weight geometry.
+#pragma once
+#include "segan_common.h"
+#include <stdlib.h>
+
+#define KCH 64  // contraction elements per LDS chunk (= 32 MFMA k-steps of 2)
+
+// ------------------------------------------------------------------------------------
+// column bookkeeping: the GEMM column space is the flattened (sample, time) axis.  A
+// tile of NB consecutive columns may cover several short samples; in LDS every sample
+// segment carries its own halo of H entries, so column `cl` of local sample s sits at
+// LDS position cl + s*H and tap u of it at cl + s*H + u.
+// ------------------------------------------------------------------------------------
+struct ColTile {
+  int col0, b0, t_first, len0;
+};
+
+__device__ __forceinline__ ColTile make_coltile(int col0, int Tcols, int NBcols) {
+  ColTile t;
+  t.col0 = col0;
+  t.b0 = col0 / Tcols;
+  t.t_first = col0 - t.b0 * Tcols;
+  t.len0 = min(Tcols - t.t_first, NBcols);
+  return t;
+}
+
+// LDS position j -> (local sample s, window coordinate tau)
+__device__ __forceinline__ void lds_pos_decode(const ColTile& ct, int j, int Tcols, int H, int& s,
+                                               int& tau) {
+  if (j < ct.len0 + H) {
+    s = 0;
+    tau = ct.t_first + j;
+  } else {
+    const int jj = j - (ct.len0 + H);
+    const int per = Tcols + H;
+    const int q = jj / per;
+    s = 1 + q;
+    tau = jj - q * per;
+  }
+}
+
+// ====================================================================================
+// corr kernel
+// ====================================================================================
+struct CorrArgs {
+  segan_src in;
+  const float* wp;  // packed weights [KtotP][RP] (zero padded: no guards on the loads)
+  float* out0;
+  float* out1;
+  const float* bias;
+  float* halo;
+  int B, Cv, Ktot, RP, Rvalid;
+  int Tcols, Ctot, ncoltiles;
+  int Lin;                // stored row length of the input tensor
+  int padL, mode, roll;   // HI input view
+  int win_start, H, RLs;  // window geometry
+  int rowshift[4];
+  int NP, Nout;           // T form row decode: row = r*NP + n
+  int OC0, OC1, Lout, act;
+  int o_padL, o_roll, o_padR;  // HI store (conv dgrad: reflect halo)
+  int prio_mode;               // 0: none, 1: hashed static wave priority per workgroup
+  int sk_nfull;                // tiles processed whole (strided over the grid)
+  int sk_units;                // stream-K part: (tile, chunk) units per workgroup
+  long sk_total;               // stream-K part: total units of the remaining tiles
+  int rt0;                     // first row tile (rows below it have a NULL destination)
+  size_t out0_elems, out1_elems, halo_elems;   // host side: what stream-K must zero
+};
+
+
+static inline int samples_per_tile(int Tcols, int NB) {
+  if (Tcols >= NB) return (Tcols % NB == 0) ? 1 : 2;
+  return (NB % Tcols == 0) ? NB / Tcols : (NB + Tcols - 2) / Tcols + 1;
+}
+
+// T form: channels are padded to whole tiles (128/S channels x S phases = 128 rows)
+static inline int t_np(int N, int S) { return round_up(N, 128 / S); }
+
+// split-bf16 entry points (segan_conv_bf.hip); `a` is filled exactly as for the fp32 kernels
+int segan_corr_bf_f(CorrArgs& a, int U, const void* wp3, int planes, hipStream_t st);
+int segan_corr_bf_t(CorrArgs& a, int U, const void* wp3, int planes, hipStream_t st);

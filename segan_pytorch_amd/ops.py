@@ -14,6 +14,30 @@ from . import layout
 from ._lib import ACT_NONE, ACT_TANH, PAD_REFLECT, PAD_ZERO, SeganSrc, check
 
 
+import os as _os
+
+PREC_FP32, PREC_BF16, PREC_BF16X3 = 0, 1, 3
+_PREC_NAMES = {'fp32': PREC_FP32, 'bf16': PREC_BF16, 'bf16x3': PREC_BF16X3}
+_precision = _PREC_NAMES[_os.environ.get('SEGAN_PRECISION', 'fp32')]
+_EUNSUPPORTED = -3
+
+
+def set_precision(mode):
+    """Precision of the forward / data-gradient contractions: 'fp32' (exact fp32 MFMA, the
+    default and the benchmarked configuration), 'bf16' (bf16 operands, fp32 accumulate:
+    BASELINE config 5) or 'bf16x3' (exact 3-way bf16 split of every fp32 operand, six
+    partial products: fp32-class accuracy on the bf16 matrix cores).  Weight gradients,
+    BatchNorm, activations, losses and optimizers always run in fp32."""
+    global _precision
+    if mode not in _PREC_NAMES:
+        raise ValueError('precision must be one of {}'.format(sorted(_PREC_NAMES)))
+    _precision = _PREC_NAMES[mode]
+
+
+def get_precision():
+    return [k for k, v in _PREC_NAMES.items() if v == _precision][0]
+
+
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -141,6 +165,28 @@ class WeightPack(object):
     def t(self, w, S, pad_t):
         return self._get(w, S, pad_t, 't')
 
+    def bf(self, w, S, pad_t, tform, planes):
+        """bf16-plane packing (segan_pack_weights_bf) for the bf16 / bf16x3 kernels."""
+        _chk(w, 'weight', 3)
+        want = ('bf', tform, planes)
+        key = (w.data_ptr(), w._version, _weights_epoch, getattr(w, '_segan_epoch', 0),
+               tuple(w.shape), S, pad_t)
+        if self._key.get(want) == key:
+            return self._buf[want]
+        lib = _lib.load()
+        M, N, K = w.shape
+        nbytes = lib.segan_packed_bf_bytes(M, N, S, tform, planes)
+        if nbytes == 0:
+            raise ValueError('unsupported geometry for bf16 packing')
+        buf = self._buf.get(want)
+        if buf is None or buf.numel() * 2 != nbytes or buf.device != w.device:
+            buf = torch.empty(nbytes // 2, device=w.device, dtype=torch.bfloat16)
+        check(lib.segan_pack_weights_bf(_ptr(w), _ptr(buf), M, N, K, S, tform, pad_t, planes,
+                                        _stream()), 'pack_weights_bf')
+        self._buf[want] = buf
+        self._key[want] = key
+        return buf
+
 
 # ---------------------------------------------------------------------------------
 # contractions
@@ -157,9 +203,17 @@ def conv1d_fwd(src, w, bias, S, roll=0, pad_mode=PAD_REFLECT, padL=None, pack=No
         padL = conv_pad(K, S)[0]
     out = torch.empty((B, M, L // S), device=w.device, dtype=torch.float32)
     cs = src.c_struct()
-    check(_lib.load().segan_conv1d_fwd(ctypes.byref(cs), _ptr((pack or WeightPack()).f(w, S)),
-                                       _ptr(bias), _ptr(out),
-                                       B, N, M, L, K, S, padL, pad_mode, roll, _stream()),
+    pack = pack or WeightPack()
+    lib = _lib.load()
+    if _precision and pad_mode == PAD_REFLECT:
+        rc = lib.segan_conv1d_fwd(ctypes.byref(cs), _ptr(pack.bf(w, S, 0, 0, _precision)),
+                                  _ptr(bias), _ptr(out), B, N, M, L, K, S, padL, pad_mode, roll,
+                                  _precision, _stream())
+        if rc != _EUNSUPPORTED:
+            check(rc, 'conv1d_fwd')
+            return out
+    check(lib.segan_conv1d_fwd(ctypes.byref(cs), _ptr(pack.f(w, S)), _ptr(bias), _ptr(out), B, N,
+                               M, L, K, S, padL, pad_mode, roll, PREC_FP32, _stream()),
           'conv1d_fwd')
     return out
 
@@ -178,11 +232,20 @@ def conv1d_dgrad(da, w, L, S, roll=0, padL=None, pack=None):
     halo = torch.empty((B * N * max(K - 1, 1),), device=da.device, dtype=torch.float32)
     small = N <= 2          # first layer: direct VALU kernel on the unpacked weight
     _chk(w, 'weight', 3)
-    check(_lib.load().segan_conv1d_dgrad(_ptr(da),
-                                         None if small else _ptr((pack or WeightPack()).t(w, S, 0)),
-                                         _ptr(w.detach()) if small else None,
-                                         _ptr(dx), _ptr(halo), B,
-                                         N, M, L, K, S, padL, roll, _stream()), 'conv1d_dgrad')
+    pack = pack or WeightPack()
+    lib = _lib.load()
+    if small:
+        check(lib.segan_conv1d_dgrad(_ptr(da), None, _ptr(w.detach()), _ptr(dx), _ptr(halo), B, N,
+                                     M, L, K, S, padL, roll, PREC_FP32, _stream()), 'conv1d_dgrad')
+        return dx
+    if _precision:
+        rc = lib.segan_conv1d_dgrad(_ptr(da), _ptr(pack.bf(w, S, 0, 1, _precision)), None, _ptr(dx),
+                                    _ptr(halo), B, N, M, L, K, S, padL, roll, _precision, _stream())
+        if rc != _EUNSUPPORTED:
+            check(rc, 'conv1d_dgrad')
+            return dx
+    check(lib.segan_conv1d_dgrad(_ptr(da), _ptr(pack.t(w, S, 0)), None, _ptr(dx), _ptr(halo), B, N,
+                                 M, L, K, S, padL, roll, PREC_FP32, _stream()), 'conv1d_dgrad')
     return dx
 
 
@@ -211,10 +274,22 @@ def deconv1d_fwd(src, w, bias, S, act=ACT_NONE, pack=None):
     cs = src.c_struct()
     small = N <= 2          # last generator layer (Cout = 1): direct VALU kernel
     _chk(w, 'weight', 3)
-    check(_lib.load().segan_deconv1d_fwd(ctypes.byref(cs),
-                                         None if small else _ptr((pack or WeightPack()).t(w, S, pad)),
-                                         _ptr(w.detach()) if small else None, _ptr(bias),
-                                         _ptr(y), B, M, N, Ls, K, S, pad, act, _stream()),
+    pack = pack or WeightPack()
+    lib = _lib.load()
+    if small:
+        check(lib.segan_deconv1d_fwd(ctypes.byref(cs), None, _ptr(w.detach()), _ptr(bias), _ptr(y),
+                                     B, M, N, Ls, K, S, pad, act, PREC_FP32, _stream()),
+              'deconv1d_fwd')
+        return y
+    if _precision and act == ACT_NONE:
+        rc = lib.segan_deconv1d_fwd(ctypes.byref(cs), _ptr(pack.bf(w, S, pad, 1, _precision)), None,
+                                    _ptr(bias), _ptr(y), B, M, N, Ls, K, S, pad, act, _precision,
+                                    _stream())
+        if rc != _EUNSUPPORTED:
+            check(rc, 'deconv1d_fwd')
+            return y
+    check(lib.segan_deconv1d_fwd(ctypes.byref(cs), _ptr(pack.t(w, S, pad)), None, _ptr(bias),
+                                 _ptr(y), B, M, N, Ls, K, S, pad, act, PREC_FP32, _stream()),
           'deconv1d_fwd')
     return y
 
@@ -236,9 +311,16 @@ def deconv1d_dgrad(dy, w, S, M0=0, need0=True, need1=True, pack=None):
         dx1 = torch.empty((B, M - M0, Ls), device=dy.device, dtype=torch.float32)
     if dx0 is None and dx1 is None:
         return None, None
-    check(_lib.load().segan_deconv1d_dgrad(_ptr(dy), _ptr((pack or WeightPack()).f(w, S)),
-                                           _ptr(dx0), _ptr(dx1), B, M,
-                                           M0, N, Ls, K, S, pad, _stream()), 'deconv1d_dgrad')
+    pack = pack or WeightPack()
+    lib = _lib.load()
+    if _precision:
+        rc = lib.segan_deconv1d_dgrad(_ptr(dy), _ptr(pack.bf(w, S, 0, 0, _precision)), _ptr(dx0),
+                                      _ptr(dx1), B, M, M0, N, Ls, K, S, pad, _precision, _stream())
+        if rc != _EUNSUPPORTED:
+            check(rc, 'deconv1d_dgrad')
+            return dx0, dx1
+    check(lib.segan_deconv1d_dgrad(_ptr(dy), _ptr(pack.f(w, S)), _ptr(dx0), _ptr(dx1), B, M, M0, N,
+                                   Ls, K, S, pad, PREC_FP32, _stream()), 'deconv1d_dgrad')
     return dx0, dx1
 
 

@@ -418,3 +418,60 @@ def test_unsupported_geometry_reports_error_not_crash():
     with pytest.raises(RuntimeError, match='multiple of 4'):
         ops.wgrad(ops.Src(torch.zeros(1, 3, 6, device=DEV)), ops.Src(torch.zeros(1, 2, 24, device=DEV)),
                   torch.zeros(3, 2, 31, device=DEV), 31, 4, 14, ops.PAD_REFLECT)
+
+
+# ---- bf16 matrix-core modes of the forward / data-gradient contractions -----------------
+# bf16x3: every fp32 operand split exactly into 3 bf16 planes, 6 partial products -> the
+#         error bound is fp32-class; stated tolerance 5e-5 * max|ref| (fp32 path: 3e-5).
+# bf16  : operands rounded to bf16 (8-bit mantissa), fp32 accumulate (BASELINE config 5);
+#         stated tolerance 2e-2 * max|ref|.
+PREC_TOL = {'bf16x3': 5e-5, 'bf16': 2e-2}
+PREC_CASES = [(3, 64, 128, 256, 4, 2), (2, 256, 130, 512, 4, 0), (9, 32, 200, 64, 4, 5),
+              (2, 16, 72, 128, 2, -1), (300, 128, 256, 64, 4, 3)]
+
+
+@pytest.mark.parametrize('prec', ['bf16x3', 'bf16'])
+@pytest.mark.parametrize('B,N,M,L,S,roll', PREC_CASES)
+def test_conv_bf16_modes(prec, B, N, M, L, S, roll):
+    ops = _ops()
+    K = 31
+    x, w, b = rnd(B, N, L, seed=1), rnd(M, N, K, seed=2, scale=0.1), rnd(M, seed=3)
+    sl = rnd(N, seed=9).abs() * 0.3
+    xin = xform_ref(x, slope=sl).requires_grad_(True)
+    ref = conv_ref(xin, w.double(), b.double(), S, roll)
+    da = rnd(*ref.shape, seed=4)
+    ref.backward(da.double())
+    tol = PREC_TOL[prec]
+    ops.set_precision(prec)
+    try:
+        out = ops.conv1d_fwd(ops.Src(x.to(DEV), slope=sl.to(DEV)), w.to(DEV), b.to(DEV), S, roll=roll)
+        dx = ops.conv1d_dgrad(da.to(DEV), w.to(DEV), L, S, roll=roll)
+    finally:
+        ops.set_precision('fp32')
+    assert max_rel(out, ref) < tol
+    # data gradient w.r.t. the transformed input (dgrad does not apply the transform)
+    assert max_rel(dx, xin.grad) < tol
+
+
+@pytest.mark.parametrize('prec', ['bf16x3', 'bf16'])
+@pytest.mark.parametrize('B,M,N,Ls,S', [(3, 128, 64, 64, 4), (9, 40, 33, 16, 4), (2, 64, 48, 32, 2),
+                                        (300, 2048, 512, 16, 4)])
+def test_deconv_bf16_modes(prec, B, M, N, Ls, S):
+    ops = _ops()
+    K = 31
+    if B * M * Ls > 4e6:      # keep the fp64 CPU reference affordable
+        B = 6
+    x, w, b = rnd(B, M, Ls, seed=1), rnd(M, N, K, seed=2, scale=0.1), rnd(N, seed=3)
+    xd = x.double().requires_grad_(True)
+    ref = deconv_ref(xd, w.double(), b.double(), S)
+    dy = rnd(*ref.shape, seed=4)
+    ref.backward(dy.double())
+    tol = PREC_TOL[prec]
+    ops.set_precision(prec)
+    try:
+        y = ops.deconv1d_fwd(ops.Src(x.to(DEV)), w.to(DEV), b.to(DEV), S)
+        dx0, dx1 = ops.deconv1d_dgrad(dy.to(DEV), w.to(DEV), S, M // 2)
+    finally:
+        ops.set_precision('fp32')
+    assert max_rel(y, ref) < tol
+    assert max_rel(torch.cat((dx0, dx1), 1), xd.grad) < tol

@@ -353,3 +353,38 @@ def test_generator_sum_merge_on_gpu():
     assert max_rel(y, yr) < ACT_TOL
     for k, p in g.named_parameters():
         assert max_rel(p.grad, sd[k].grad) < GRAD_TOL, k
+
+
+@pytest.mark.parametrize('prec,out_tol,grad_tol', [('bf16x3', 2e-5, 2e-4), ('bf16', 3e-2, 2e-1)])
+def test_precision_modes_on_the_default_net(segan_plus_b2, prec, out_tol, grad_tol):
+    """BASELINE config 5 (bf16 MFMA, tolerance re-stated) and the bf16x3 split mode on the
+    full SEGAN+ net: generator output and discriminator-phase gradients vs the reference.
+    Stated tolerances: bf16x3 as fp32 (output max-abs 2e-5, MSE < 1e-9); bf16 output max-abs
+    3e-2 (MSE < 1e-4, the north-star bar), gradients 20 % of the tensor's max."""
+    from segan_pytorch_amd import ops
+    from segan_pytorch_amd.datasets import synthetic_pairs
+    fx = segan_plus_b2
+    m = build(fx, seed=fx['seed'])
+    clean, noisy = synthetic_pairs(2, 16384, fx['data_seed'])
+    clean, noisy = clean.unsqueeze(1), noisy.unsqueeze(1)
+    z = torch.randn(2, 1024, 16, generator=torch.Generator().manual_seed(fx['z_seed']))
+    ops.set_precision(prec)
+    try:
+        with torch.no_grad():
+            m.G.train()
+            y = m.G(noisy.to(DEV), z=z.to(DEV))
+        err = (y.cpu() - fx['Genh']).abs().max().item()
+        mse = ((y.cpu().double() - fx['Genh'].double()) ** 2).mean().item()
+        assert err < out_tol and mse < 1e-4, (err, mse)
+        if prec == 'bf16x3':
+            assert mse < 1e-9
+        (d_real_loss, d_fake_loss, g_adv, g_l1), Gopt, Dopt = run_step(m, fx, clean, noisy, z)
+    finally:
+        ops.set_precision('fp32')
+    loss_tol = 1e-4 if prec == 'bf16x3' else 5e-2
+    for got, key in ((d_real_loss, 'd_real_loss'), (d_fake_loss, 'd_fake_loss'), (g_l1, 'g_l1_loss')):
+        assert max_rel(got, fx[key]) < loss_tol, key
+    dn = dict(m.D.named_parameters())
+    for k, v in fx['small_d_grads'].items():
+        if not k.endswith('conv.bias'):
+            assert max_rel(dn[k].grad, v) < grad_tol, k
