@@ -681,20 +681,6 @@ static int launch_tsmall(CorrArgs& a, const float* w, int K, int M, int N, int S
 // ====================================================================================
 // wgrad kernel
 // ====================================================================================
-struct WgradArgs {
-  segan_src lo;
-  segan_src hi;
-  float* dw;
-  int B, M, N, K, Ls, Lhi;
-  int Cv;                 // N*S virtual channels
-  int padL, mode, roll;
-  int Ctot;               // B*Ls
-  int cols_per_split;
-  int H, RLw;
-  int ls_magic;           // ceil(65536 / Ls): x / Ls for small x when Ls < TK
-  int per_magic;          // ceil(65536 / (Ls + H)): LDS position -> sample when Ls < TK
-  int prio_mode;
-};
 
 // x / Ls for 0 <= x < Ls + TK (Ls >= TK: one compare; else exact multiply-shift, x < 64)
 template <int TK>
@@ -1260,7 +1246,9 @@ extern "C" int segan_conv1d_dgrad(const float* da, const void* wt, const float* 
 }
 
 extern "C" int segan_wgrad(const segan_src* lo, const segan_src* hi, float* dw, int B, int M, int N,
-                           int Ls, int K, int S, int padL, int mode, int roll, void* stream) {
+                           int Ls, int K, int S, int padL, int mode, int roll, int precision,
+                           void* stream) {
+  SEGAN_REQUIRE(precision_ok(precision), "wgrad: bad precision %d", precision);
   SEGAN_REQUIRE(stride_ok(S), "wgrad: stride %d not in {1,2,4}", S);
   SEGAN_REQUIRE(K >= 1 && K <= 32, "wgrad: kernel width %d not in [1,32]", K);
   SEGAN_REQUIRE(B > 0 && N > 0 && M > 0 && Ls > 0, "wgrad: bad sizes");
@@ -1276,6 +1264,8 @@ extern "C" int segan_wgrad(const segan_src* lo, const segan_src* hi, float* dw, 
   a.Cv = N * S; a.padL = padL; a.mode = mode; a.roll = roll;
   a.Ctot = B * Ls;
   hipStream_t st = (hipStream_t)stream;
+  if (precision != SEGAN_PREC_FP32)
+    return segan_wgrad_bf(a, 32 / S, precision == SEGAN_PREC_BF16 ? 1 : 3, st);
   switch (S) {
     case 4: return launch_wgrad_t<8>(a, st);
     case 2: return launch_wgrad_t<16>(a, st);

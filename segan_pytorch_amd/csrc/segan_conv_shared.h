@@ -76,6 +76,28 @@ static inline int samples_per_tile(int Tcols, int NB) {
 // T form: channels are padded to whole tiles (128/S channels x S phases = 128 rows)
 static inline int t_np(int N, int S) { return round_up(N, 128 / S); }
 
+// ====================================================================================
+// wgrad kernels
+// ====================================================================================
+struct WgradArgs {
+  segan_src lo;
+  segan_src hi;
+  float* dw;
+  int B, M, N, K, Ls, Lhi;
+  int Cv;                 // N*S virtual channels
+  int padL, mode, roll;
+  int Ctot;               // B*Ls
+  int cols_per_split;
+  int H, RLw;
+  int ls_magic;           // ceil(65536 / Ls): x / Ls for small x when Ls < TK
+  int per_magic;          // ceil(65536 / (Ls + H)): LDS position -> sample when Ls < TK
+  int prio_mode;
+  int bf_qc;              // bf16 kernel: time chunks per sample group
+  int bf_cps;             // bf16 kernel: chunks per workgroup (split of the contraction)
+};
+
 // split-bf16 entry points (segan_conv_bf.hip); `a` is filled exactly as for the fp32 kernels
 int segan_corr_bf_f(CorrArgs& a, int U, const void* wp3, int planes, hipStream_t st);
 int segan_corr_bf_t(CorrArgs& a, int U, const void* wp3, int planes, hipStream_t st);
+// wgrad on the bf16 matrix cores (segan_wgrad_bf.hip); planes = 1 (bf16) or 3 (bf16x3)
+int segan_wgrad_bf(WgradArgs& a, int U, int planes, hipStream_t st);

@@ -1,0 +1,308 @@
+// segan_wgrad_bf.hip — the W contraction form (both weight gradients) on the bf16 matrix
+// cores, the companion of segan_conv_bf.hip:
+//
+//   dW[m, n, S*u + r] += sum_{b,t} lo[b, m, t] * HI_r[b, n, t + u]
+//
+// The fp32 kernel contracts over consecutive time positions; a 16-wide bf16 MFMA would then
+// need its 8-element B fragment at the unaligned position t + u.  Here the contraction index
+// of one MFMA is (time half, SAMPLE): a lane's 8 contiguous bf16 are the same (row, time)
+// of 8 consecutive samples, so the fragment of tap u is simply the 16-byte piece at position
+// t + u — aligned for every tap.  LDS keeps
+//     lo tile  [plane][time q][row m]      16-B pieces (8 samples), rows XOR-swizzled by q
+//     hi tile  [plane][virtual ch][pos]    16-B pieces, row pitch chosen per stride so the
+//                                          (channel, tap) read pattern is conflict-free
+// NPL = 1 ("bf16") or 3 ("bf16x3": exact 3-way split, six partial products) as in
+// segan_conv_bf.hip.  A chunk is 8 samples x TQ time positions; the contraction is split
+// over blockIdx.z and reduced with fp32 atomics like the fp32 kernel.
+#include "segan_conv_shared.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void wsplit3(float x, __bf16& p1, __bf16& p2, __bf16& p3) {
+  p1 = (__bf16)x;
+  const float r1 = x - (float)p1;
+  p2 = (__bf16)r1;
+  const float r2 = r1 - (float)p2;
+  p3 = (__bf16)r2;
+}
+
+// hi-tile row pitch (pieces): >= PW and = 8 (mod 16) for U = 8, = 0 (mod 16) for U = 16
+__host__ __device__ constexpr int wbf_pitch(int U, int PW) {
+  return U == 8 ? ((PW + 7) / 16) * 16 + 8 : (U == 16 ? ((PW + 15) / 16) * 16 : PW + (PW & 1));
+}
+
+template <int U, int NPL, int TQ>
+__global__ __launch_bounds__(256, 2) void wgrad_bf_kernel(const WgradArgs a) {
+  constexpr int S = 32 / U;
+  constexpr int MB = 128;
+  constexpr int CVW = 128 / U;         // virtual channels per block
+  constexpr int PW = TQ + U - 1;       // hi positions per chunk
+  constexpr int QW = wbf_pitch(U, PW);
+  constexpr int F4 = TQ / 4;           // float4 loads per lo row and chunk
+  constexpr int NAU = (MB * F4) / 256; // lo units per thread
+  constexpr int NBU = (CVW * PW + 255) / 256;
+  constexpr int SWM = 8 / F4;          // swizzle step
+  static_assert(QW >= PW, "pitch");
+  static_assert(NAU >= 1, "TQ >= 8");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  u32x4* Al = reinterpret_cast<u32x4*>(smem_raw);     // [NPL][TQ][MB]
+  u32x4* Bl = Al + NPL * TQ * MB;                      // [NPL][CVW][QW]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, h = lane >> 5;
+
+  const int cv0 = blockIdx.x * CVW;
+  const int m0 = blockIdx.y * MB;
+  const int nchunks = ((a.B + 7) / 8) * a.bf_qc;
+  const int c_beg = blockIdx.z * a.bf_cps;
+  const int c_end = min(c_beg + a.bf_cps, nchunks);
+  if (c_beg >= c_end) return;
+  const int Ls = a.Ls;
+
+  // ---- MFMA operand offsets (pieces) ----
+  int arow[2], bbase[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) arow[i] = wm * 64 + 32 * i + l31;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int cc = wn * 64 + 32 * j + l31;
+    bbase[j] = (cc / U) * QW + cc % U + h * (TQ / 2);
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+  // ---- lo staging units: (row m, float4 f) -> 8 samples x 4 time positions ----
+  const float* a_ptr[NAU];
+  int a_cs[NAU];            // sample stride of the segment the row lives in
+  bool a_rok[NAU];
+  ChanXf a_xf[NAU];
+  int a_f[NAU], a_m[NAU];
+#pragma unroll
+  for (int k = 0; k < NAU; ++k) {
+    const int id = tid + 256 * k;
+    a_f[k] = id % F4;
+    a_m[k] = id / F4;
+    int m = m0 + a_m[k];
+    a_rok[k] = m < a.M;
+    m = a_rok[k] ? m : 0;
+    const bool s1 = m >= a.lo.C0;
+    a_ptr[k] = s1 ? a.lo.p1 + (size_t)(m - a.lo.C0) * Ls : a.lo.p0 + (size_t)m * Ls;
+    a_cs[k] = (s1 ? a.lo.C1 : a.lo.C0) * Ls;
+    a_xf[k] = segan_chan_xf(a.lo, m);
+  }
+  // ---- hi staging units: (virtual channel, position) -> 8 samples ----
+  const float* b_ptr[NBU];
+  int b_cs[NBU], b_pos[NBU], b_r[NBU], b_cvl[NBU];
+  bool b_cok[NBU];
+  ChanXf b_xf[NBU];
+#pragma unroll
+  for (int k = 0; k < NBU; ++k) {
+    const int id = tid + 256 * k;
+    const int nl = id / (S * PW);
+    const int x = id - nl * (S * PW);
+    b_pos[k] = x / S;
+    b_r[k] = x % S;
+    b_cvl[k] = nl * S + b_r[k];
+    const bool uok = id < CVW * PW;
+    int n = cv0 / S + nl;
+    b_cok[k] = uok && n < a.N;
+    n = b_cok[k] ? n : 0;
+    const bool s1 = n >= a.hi.C0;
+    b_ptr[k] = s1 ? a.hi.p1 + (size_t)(n - a.hi.C0) * a.Lhi : a.hi.p0 + (size_t)n * a.Lhi;
+    b_cs[k] = (s1 ? a.hi.C1 : a.hi.C0) * a.Lhi;
+    b_xf[k] = segan_chan_xf(a.hi, n);
+    if (!uok) { b_pos[k] = 0; b_cvl[k] = 0; }
+  }
+
+  f32x4 areg[NAU][8];
+  float breg[NBU][8];
+  bool a_qok[NAU];
+  bool b_iok[NBU];
+  int cur_b0 = 0;
+
+  auto load_chunk = [&](int c) {
+    const int sg = c / a.bf_qc;
+    const int q0 = (c - sg * a.bf_qc) * TQ;
+    const int b0 = 8 * sg;
+    cur_b0 = b0;
+#pragma unroll
+    for (int k = 0; k < NAU; ++k) {
+      const int q = q0 + 4 * a_f[k];
+      a_qok[k] = q < Ls;
+      const int qq = a_qok[k] ? q : 0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int b = (b0 + e < a.B) ? b0 + e : 0;
+        areg[k][e] = *reinterpret_cast<const f32x4*>(a_ptr[k] + b * a_cs[k] + qq);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NBU; ++k) {
+      const int idx = segan_hi_index(S * (q0 + b_pos[k]) + b_r[k], a.Lhi, a.padL, a.mode, a.roll);
+      b_iok[k] = idx >= 0;
+      const int ii = b_iok[k] ? idx : 0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int b = (b0 + e < a.B) ? b0 + e : 0;
+        breg[k][e] = b_ptr[k][b * b_cs[k] + ii];
+      }
+    }
+  };
+  auto store_chunk = [&]() {
+    const int nvalid = a.B - cur_b0;   // samples e < nvalid exist
+#pragma unroll
+    for (int k = 0; k < NAU; ++k) {
+      const bool ok = a_rok[k] && a_qok[k];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        bf16x8 pl[3];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float v = segan_apply_xf(a_xf[k], areg[k][e][i]);
+          v = (ok && e < nvalid) ? v : 0.0f;
+          __bf16 p1, p2, p3;
+          wsplit3(v, p1, p2, p3);
+          pl[0][e] = p1; pl[1][e] = p2; pl[2][e] = p3;
+        }
+        const int q = 4 * a_f[k] + i;
+        const int mm = a_m[k] ^ (a_f[k] * SWM);
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) Al[(p * TQ + q) * MB + mm] = __builtin_bit_cast(u32x4, pl[p]);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NBU; ++k) {
+      if (tid + 256 * k >= CVW * PW) continue;
+      const bool ok = b_cok[k] && b_iok[k];
+      bf16x8 pl[3];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float v = segan_apply_xf(b_xf[k], breg[k][e]);
+        v = (ok && e < nvalid) ? v : 0.0f;
+        __bf16 p1, p2, p3;
+        wsplit3(v, p1, p2, p3);
+        pl[0][e] = p1; pl[1][e] = p2; pl[2][e] = p3;
+      }
+#pragma unroll
+      for (int p = 0; p < NPL; ++p)
+        Bl[(p * CVW + b_cvl[k]) * QW + b_pos[k]] = __builtin_bit_cast(u32x4, pl[p]);
+    }
+  };
+
+  load_chunk(c_beg);
+  store_chunk();
+  __syncthreads();
+  for (int c = c_beg; c < c_end; ++c) {
+    const bool more = c + 1 < c_end;
+    if (more) load_chunk(c + 1);
+#pragma unroll
+    for (int kk = 0; kk < TQ / 2; ++kk) {
+      // lane half h contracts time position q = kk + h*TQ/2; its rows sit at m ^ swz(q)
+      const int qa = kk + h * (TQ / 2);
+      const int sw = ((qa >> 2) % F4) * SWM;
+      bf16x8 af[2][NPL], bf[2][NPL];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int p = 0; p < NPL; ++p)
+          af[i][p] = __builtin_bit_cast(bf16x8, Al[(p * TQ + qa) * MB + (arow[i] ^ sw)]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int p = 0; p < NPL; ++p)
+          bf[j][p] = __builtin_bit_cast(bf16x8, Bl[p * CVW * QW + bbase[j] + kk]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if (NPL == 1) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+          } else {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+          }
+        }
+    }
+    __syncthreads();
+    if (more) {
+      store_chunk();
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: dw[m][n][S*u + r] += acc ----
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int cc = wn * 64 + 32 * j + l31;
+    const int cv = cv0 + cc / U;
+    const int u = cc % U;
+    const int n = cv / S, r = cv % S;
+    const int k = S * u + r;
+    if (cv >= a.Cv || k >= a.K) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * 64 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (m < a.M) atomicAdd(a.dw + ((size_t)m * a.N + n) * a.K + k, acc[i][j][e]);
+      }
+  }
+}
+
+template <int U, int NPL>
+static int launch_wgrad_bf(WgradArgs& a, hipStream_t st) {
+  constexpr int TQ = NPL == 3 ? 8 : 16;
+  constexpr int CVW = 128 / U;
+  constexpr int QW = wbf_pitch(U, TQ + U - 1);
+  if (a.Ls % 4 != 0 || 2 * a.Ls < TQ) {
+    segan_set_error("wgrad_bf: low-rate length %d stays on the fp32 kernel", a.Ls);
+    return SEGAN_EUNSUPPORTED;
+  }
+  if ((long)a.B * a.M * a.Ls >= (1L << 31) || (long)a.B * a.N * a.Lhi >= (1L << 31)) {
+    segan_set_error("wgrad_bf: operand exceeds the 2^31 element indexing limit");
+    return SEGAN_EUNSUPPORTED;
+  }
+  if (int e = segan_src_defaults(&a.lo, st, "wgrad(lo)")) return e;
+  if (int e = segan_src_defaults(&a.hi, st, "wgrad(hi)")) return e;
+  a.bf_qc = ceil_div(a.Ls, TQ);
+  const int chunks = ceil_div(a.B, 8) * a.bf_qc;
+  const int ncol = ceil_div(a.Cv, CVW);
+  const int nrow = ceil_div(a.M, 128);
+  const int tiles = ncol * nrow;
+  static const int tgt_env = [] { const char* e = getenv("SEGAN_WGRAD_BLOCKS"); return e ? atoi(e) : 0; }();
+  int nsplit = ceil_div(tgt_env > 0 ? tgt_env : 1536, tiles);
+  if (nsplit > chunks / 4) nsplit = chunks / 4;
+  if (nsplit < 1) nsplit = 1;
+  a.bf_cps = ceil_div(chunks, nsplit);
+  nsplit = ceil_div(chunks, a.bf_cps);
+  const size_t lds = (size_t)(NPL * TQ * 128 + NPL * CVW * QW) * 16;
+  auto kern = wgrad_bf_kernel<U, NPL, TQ>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(ncol, nrow, nsplit), dim3(256), lds, st, a);
+  return segan_check_launch("wgrad_bf_kernel");
+}
+
+int segan_wgrad_bf(WgradArgs& a, int U, int planes, hipStream_t st) {
+  if (U == 8) return planes == 3 ? launch_wgrad_bf<8, 3>(a, st) : launch_wgrad_bf<8, 1>(a, st);
+  if (U == 16) return planes == 3 ? launch_wgrad_bf<16, 3>(a, st) : launch_wgrad_bf<16, 1>(a, st);
+  return planes == 3 ? launch_wgrad_bf<32, 3>(a, st) : launch_wgrad_bf<32, 1>(a, st);
+}

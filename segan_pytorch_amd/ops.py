@@ -259,8 +259,15 @@ def wgrad(lo, hi, dw, K, S, padL, pad_mode, roll=0):
         raise ValueError('wgrad: lo [{}x{}] / hi [{}x{}] inconsistent for stride {}'.format(
             lo.B, lo.L, hi.B, hi.L, S))
     cl, ch = lo.c_struct(), hi.c_struct()
-    check(_lib.load().segan_wgrad(ctypes.byref(cl), ctypes.byref(ch), _ptr(dw), lo.B, M, N, lo.L,
-                                  K, S, padL, pad_mode, roll, _stream()), 'wgrad')
+    lib = _lib.load()
+    if _precision != PREC_FP32:
+        rc = lib.segan_wgrad(ctypes.byref(cl), ctypes.byref(ch), _ptr(dw), lo.B, M, N, lo.L, K, S,
+                             padL, pad_mode, roll, _precision, _stream())
+        if rc != -3:
+            check(rc, 'wgrad')
+            return
+    check(lib.segan_wgrad(ctypes.byref(cl), ctypes.byref(ch), _ptr(dw), lo.B, M, N, lo.L, K, S, padL,
+                          pad_mode, roll, PREC_FP32, _stream()), 'wgrad')
 
 
 def deconv1d_fwd(src, w, bias, S, act=ACT_NONE, pack=None):

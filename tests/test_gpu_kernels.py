@@ -438,17 +438,22 @@ def test_conv_bf16_modes(prec, B, N, M, L, S, roll):
     x, w, b = rnd(B, N, L, seed=1), rnd(M, N, K, seed=2, scale=0.1), rnd(M, seed=3)
     sl = rnd(N, seed=9).abs() * 0.3
     xin = xform_ref(x, slope=sl).requires_grad_(True)
-    ref = conv_ref(xin, w.double(), b.double(), S, roll)
+    wd = w.double().requires_grad_(True)
+    ref = conv_ref(xin, wd, b.double(), S, roll)
     da = rnd(*ref.shape, seed=4)
     ref.backward(da.double())
     tol = PREC_TOL[prec]
+    dw = torch.zeros(M, N, K, device=DEV)
     ops.set_precision(prec)
     try:
         out = ops.conv1d_fwd(ops.Src(x.to(DEV), slope=sl.to(DEV)), w.to(DEV), b.to(DEV), S, roll=roll)
         dx = ops.conv1d_dgrad(da.to(DEV), w.to(DEV), L, S, roll=roll)
+        ops.wgrad(ops.Src(da.to(DEV)), ops.Src(x.to(DEV), slope=sl.to(DEV)), dw, K, S,
+                  ops.conv_pad(K, S)[0], ops.PAD_REFLECT, roll=roll)
     finally:
         ops.set_precision('fp32')
     assert max_rel(out, ref) < tol
+    assert max_rel(dw, wd.grad) < tol
     # data gradient w.r.t. the transformed input (dgrad does not apply the transform)
     assert max_rel(dx, xin.grad) < tol
 
@@ -463,15 +468,20 @@ def test_deconv_bf16_modes(prec, B, M, N, Ls, S):
         B = 6
     x, w, b = rnd(B, M, Ls, seed=1), rnd(M, N, K, seed=2, scale=0.1), rnd(N, seed=3)
     xd = x.double().requires_grad_(True)
-    ref = deconv_ref(xd, w.double(), b.double(), S)
+    wd = w.double().requires_grad_(True)
+    ref = deconv_ref(xd, wd, b.double(), S)
     dy = rnd(*ref.shape, seed=4)
     ref.backward(dy.double())
     tol = PREC_TOL[prec]
+    dw = torch.zeros(M, N, K, device=DEV)
     ops.set_precision(prec)
     try:
         y = ops.deconv1d_fwd(ops.Src(x.to(DEV)), w.to(DEV), b.to(DEV), S)
         dx0, dx1 = ops.deconv1d_dgrad(dy.to(DEV), w.to(DEV), S, M // 2)
+        ops.wgrad(ops.Src(x.to(DEV)), ops.Src(dy.to(DEV)), dw, K, S, ops.deconv_pad(K, S),
+                  ops.PAD_ZERO)
     finally:
         ops.set_precision('fp32')
     assert max_rel(y, ref) < tol
+    assert max_rel(dw, wd.grad) < tol
     assert max_rel(torch.cat((dx0, dx1), 1), xd.grad) < tol
