@@ -186,7 +186,8 @@ def test_default_segan_plus_step_matches_reference(segan_plus_b2):
     (d_real_loss, d_fake_loss, g_adv, g_l1), Gopt, Dopt = run_step(m, fx, clean, noisy, z)
     for got, key in ((d_real_loss, 'd_real_loss'), (d_fake_loss, 'd_fake_loss'),
                      (g_adv, 'g_adv_loss'), (g_l1, 'g_l1_loss')):
-        assert max_rel(got, fx[key]) < ACT_TOL, key
+        # g_adv is taken through the discriminator after its (ill-conditioned, see (2)) step
+        assert max_rel(got, fx[key]) < (5e-5 if key == 'g_adv_loss' else ACT_TOL), key
     dn, gn = dict(m.D.named_parameters()), dict(m.G.named_parameters())
     # (1) discriminator-phase gradients against the reference: strict
     for k, c in fx['d_grads'].items():
@@ -200,9 +201,10 @@ def test_default_segan_plus_step_matches_reference(segan_plus_b2):
     # ill-conditioned wherever |g| is at roundoff level (at B=2 a sizeable share of D's
     # 25.8 M weights): two correct fp32 implementations end up with post-step weights that
     # differ by up to a full step (5e-4) on those elements, and the generator gradient
-    # inherits ~1e-3 of that.  Loose bound here, strict bound in (3).
+    # inherits ~1e-3 of that (worst sampled element over repeated runs: 1e-2, varying with
+    # the order of the fp32 atomics; scripts/diag_flaky.py).  Loose bound here, strict in (3).
     for k, c in fx['g_grads'].items():
-        _chk(gn[k].grad, c, 1e-2)
+        _chk(gn[k].grad, c, 5e-2)
     # (3) strict: the same generator-phase gradients against the CPU oracle evaluated with
     # the discriminator weights the GPU actually stepped to.
     import torch.nn.functional as F
