@@ -38,6 +38,10 @@ for it in range(N):
     clean, noisy = clean.unsqueeze(1), noisy.unsqueeze(1)
     z = torch.randn(2, 1024, 16, generator=torch.Generator().manual_seed(fx['z_seed']))
     g0 = {k: v.detach().cpu().clone() for k, v in m.G.state_dict().items()}
+    with torch.no_grad():
+        m.G.train()
+        y = m.G(noisy.to('cuda'), z=z.to('cuda'))
+    rec('G_out_maxabs', (y.cpu() - fx['Genh']).abs().max().item())
     (d_real_loss, d_fake_loss, g_adv, g_l1), Gopt, Dopt = T.run_step(m, fx, clean, noisy, z)
     for got, key in ((d_real_loss, 'd_real_loss'), (d_fake_loss, 'd_fake_loss'),
                      (g_adv, 'g_adv_loss'), (g_l1, 'g_l1_loss')):

@@ -572,6 +572,9 @@ __global__ __launch_bounds__(256) void tsmall_kernel(const CorrArgs a, const flo
   constexpr int MC = 16;                 // input channels per LDS chunk
   constexpr int TW = 256 + U;            // window: 256 positions + (U-1) taps + 1 phase shift
   __shared__ float xs[MC][TW + 1];
+  // taps of the chunk, zero padded to 32 per (channel, output channel): the FMA loop then has
+  // no `k < K` branches and reads its weights as 16-byte LDS broadcasts
+  __shared__ __attribute__((aligned(16))) float ws[MC][N][32];
   const int tid = threadIdx.x;
   const int b = blockIdx.y;
   const int q0 = blockIdx.x * 256;
@@ -590,7 +593,15 @@ __global__ __launch_bounds__(256) void tsmall_kernel(const CorrArgs a, const flo
   const int o0 = ok0 ? t0 : 0, o1 = ok1 ? t1 : 0;
   const int bo0 = b * a.in.C0 * a.Lin, bo1 = b * a.in.C1 * a.Lin;
   for (int mc0 = 0; mc0 < M; mc0 += MC) {
-#pragma unroll 4
+#pragma unroll
+    for (int i = 0; i < (MC * N * 32) / 256; ++i) {
+      const int e = tid + 256 * i;
+      const int k = e & 31, n = (e >> 5) % N, mc = e / (32 * N);
+      const bool ok = mc0 + mc < M && k < K;
+      const float v = w[ok ? ((size_t)(mc0 + mc) * N + n) * K + k : 0];
+      ws[mc][n][k] = ok ? v : 0.0f;
+    }
+#pragma unroll 8
     for (int mc = 0; mc < MC; ++mc) {
       const int m = mc0 + mc < M ? mc0 + mc : 0;
       const bool seg1 = m >= a.in.C0;
@@ -608,7 +619,11 @@ __global__ __launch_bounds__(256) void tsmall_kernel(const CorrArgs a, const flo
       float xv[U + 1];
 #pragma unroll
       for (int j = 0; j <= U; ++j) xv[j] = xs[mc][tid + j];
-      const float* wm = w + (size_t)(mc0 + mc) * N * K;
+      f32x4 wv[N][8];
+#pragma unroll
+      for (int n = 0; n < N; ++n)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) wv[n][i] = *reinterpret_cast<const f32x4*>(&ws[mc][n][4 * i]);
 #pragma unroll
       for (int r = 0; r < S; ++r) {
         const int rho = (r + PM) % S;     // tap phase of output phase r
@@ -616,11 +631,9 @@ __global__ __launch_bounds__(256) void tsmall_kernel(const CorrArgs a, const flo
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const int k = S * u + rho;
-          if (k < K) {
 #pragma unroll
-            for (int n = 0; n < N; ++n)
-              acc[r][n] = fmaf(wm[n * K + k], xv[cs + (U - 1) - u], acc[r][n]);
-          }
+          for (int n = 0; n < N; ++n)
+            acc[r][n] = fmaf(wv[n][k >> 2][k & 3], xv[cs + (U - 1) - u], acc[r][n]);
         }
       }
     }

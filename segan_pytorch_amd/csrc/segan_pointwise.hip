@@ -68,22 +68,50 @@ __global__ void bn_partial_kernel(const float* __restrict__ x, float* __restrict
   const ChanRange cr = chan_range(B, nsplit);
   const int nb = cr.b_end - cr.b_beg;
   const long cnt = (long)(nb > 0 ? nb : 0) * L;
+  // slice = rows (b, cr.c, :) for b in [b_beg, b_end): `tr` threads walk a row (float4 when
+  // 4 | L), PW_THREADS/tr rows at a time; 32-bit index math only
+  const float* base = x + ((size_t)cr.b_beg * C + cr.c) * L;
+  const size_t sstride = (size_t)C * L;
+  const bool vec = (L & 3) == 0 && ((uintptr_t)x & 15) == 0;
+  const int Lv = vec ? L >> 2 : L;
+  int tr = PW_THREADS;
+  while (tr > Lv && tr > 1) tr >>= 1;
+  const int rp = PW_THREADS / tr;
+  const int t0 = threadIdx.x % tr, r0 = threadIdx.x / tr;
   float v[1] = {0.f};
-  for (long e = threadIdx.x; e < cnt; e += PW_THREADS) {
-    const int b = cr.b_beg + (int)(e / L);
-    const int t = (int)(e % L);
-    v[0] += x[((size_t)b * C + cr.c) * L + t];
+  for (int b = r0; b < nb; b += rp) {
+    const float* row = base + b * sstride;
+    if (vec) {
+      for (int t = t0; t < Lv; t += tr) {
+        const f32x4 u = *reinterpret_cast<const f32x4*>(row + 4 * t);
+        v[0] += (u[0] + u[1]) + (u[2] + u[3]);
+      }
+    } else {
+      for (int t = t0; t < Lv; t += tr) v[0] += row[t];
+    }
   }
   block_sum<1>(v, sm);
   if (threadIdx.x == 0) s_mean = cnt > 0 ? v[0] / (float)cnt : 0.f;
   __syncthreads();
   const float mean = s_mean;
   float q[1] = {0.f};
-  for (long e = threadIdx.x; e < cnt; e += PW_THREADS) {
-    const int b = cr.b_beg + (int)(e / L);
-    const int t = (int)(e % L);
-    const float d = x[((size_t)b * C + cr.c) * L + t] - mean;
-    q[0] = fmaf(d, d, q[0]);
+  for (int b = r0; b < nb; b += rp) {
+    const float* row = base + b * sstride;
+    if (vec) {
+      for (int t = t0; t < Lv; t += tr) {
+        const f32x4 u = *reinterpret_cast<const f32x4*>(row + 4 * t);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float d = u[e] - mean;
+          q[0] = fmaf(d, d, q[0]);
+        }
+      }
+    } else {
+      for (int t = t0; t < Lv; t += tr) {
+        const float d = row[t] - mean;
+        q[0] = fmaf(d, d, q[0]);
+      }
+    }
   }
   block_sum<1>(q, sm);
   if (threadIdx.x == 0) {
@@ -235,34 +263,62 @@ __global__ void act_bwd_kernel(const ActBwdArgs p) {
     dgamma_m = tot[1] * invn;
   }
   float r[3] = {0.f, 0.f, 0.f};
-  for (long e = threadIdx.x; e < cnt; e += PW_THREADS) {
-    const int b = cr.b_beg + (int)(e / p.L);
-    const int t = (int)(e % p.L);
-    const size_t i = ((size_t)b * p.C + c) * p.L + t;
-    const float av = p.a[i];
-    const float dh = p.dh ? p.dh[i] : 0.0f;
+  const bool has_skip = p.dskip != nullptr;
+  // one element: returns the gradient written to da (phases 0 and 2), accumulates r
+  auto elem = [&](float av, float dh, float ds) -> float {
     if (PHASE == 0) {
       float g = dh * (av > 0.f ? 1.0f : sl);
       r[0] += dh * (av > 0.f ? 0.0f : av);
-      if (p.dskip) {
-        const float ds = p.dskip[i];
+      if (has_skip) {
         g = fmaf(al, ds, g);
         r[1] = fmaf(ds, av, r[1]);
       }
       r[2] += g;
-      p.da[i] = g;
+      return g;
+    }
+    const float xh = (av - mu) * rs;
+    const float v = fmaf(ga, xh, be);
+    const float g = dh * (v > 0.f ? 1.0f : sl);
+    if (PHASE == 1) {
+      r[0] += dh * (v > 0.f ? 0.0f : v);
+      r[1] += g;
+      r[2] = fmaf(g, xh, r[2]);
+      return 0.0f;
+    }
+    const float d = ga * rs * (g - dbeta_m - xh * dgamma_m);
+    r[0] += d;
+    return d;
+  };
+  // rows (b, c, :) of the slice: `tr` threads walk a row (float4 when 4 | L), PW_THREADS/tr
+  // rows at a time; 32-bit index math only
+  const size_t base = ((size_t)cr.b_beg * p.C + c) * p.L;
+  const size_t sstride = (size_t)p.C * p.L;
+  const bool vec = (p.L & 3) == 0 &&
+                   (((uintptr_t)p.a | (uintptr_t)p.dh | (uintptr_t)p.dskip | (uintptr_t)p.da) & 15) == 0;
+  const int Lv = vec ? p.L >> 2 : p.L;
+  int tr = PW_THREADS;
+  while (tr > Lv && tr > 1) tr >>= 1;
+  const int rp = PW_THREADS / tr;
+  const int t0 = threadIdx.x % tr, r0 = threadIdx.x / tr;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  for (int b = r0; b < nb; b += rp) {
+    const size_t ro = base + b * sstride;
+    if (vec) {
+      for (int t = t0; t < Lv; t += tr) {
+        const size_t i = ro + 4 * (size_t)t;
+        const f32x4 av = *reinterpret_cast<const f32x4*>(p.a + i);
+        const f32x4 dh = p.dh ? *reinterpret_cast<const f32x4*>(p.dh + i) : z4;
+        const f32x4 ds = has_skip ? *reinterpret_cast<const f32x4*>(p.dskip + i) : z4;
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = elem(av[e], dh[e], ds[e]);
+        if (PHASE != 1) *reinterpret_cast<f32x4*>(p.da + i) = o;
+      }
     } else {
-      const float xh = (av - mu) * rs;
-      const float v = fmaf(ga, xh, be);
-      const float g = dh * (v > 0.f ? 1.0f : sl);
-      if (PHASE == 1) {
-        r[0] += dh * (v > 0.f ? 0.0f : v);
-        r[1] += g;
-        r[2] = fmaf(g, xh, r[2]);
-      } else {
-        const float d = ga * rs * (g - dbeta_m - xh * dgamma_m);
-        r[0] += d;
-        p.da[i] = d;
+      for (int t = t0; t < Lv; t += tr) {
+        const size_t i = ro + t;
+        const float o = elem(p.a[i], p.dh ? p.dh[i] : 0.0f, has_skip ? p.dskip[i] : 0.0f);
+        if (PHASE != 1) p.da[i] = o;
       }
     }
   }

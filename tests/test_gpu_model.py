@@ -186,8 +186,10 @@ def test_default_segan_plus_step_matches_reference(segan_plus_b2):
     (d_real_loss, d_fake_loss, g_adv, g_l1), Gopt, Dopt = run_step(m, fx, clean, noisy, z)
     for got, key in ((d_real_loss, 'd_real_loss'), (d_fake_loss, 'd_fake_loss'),
                      (g_adv, 'g_adv_loss'), (g_l1, 'g_l1_loss')):
-        # g_adv is taken through the discriminator after its (ill-conditioned, see (2)) step
-        assert max_rel(got, fx[key]) < (5e-5 if key == 'g_adv_loss' else ACT_TOL), key
+        # d_fake / g_adv are D(G(noisy)): the discriminator amplifies the generator's ~1e-6
+        # output roundoff (and g_adv sees D after its ill-conditioned step, see (2)); measured
+        # worst case over repeated runs 2.4e-5 (scripts/diag_flaky.py)
+        assert max_rel(got, fx[key]) < (1e-4 if key in ('g_adv_loss', 'd_fake_loss') else ACT_TOL), key
     dn, gn = dict(m.D.named_parameters()), dict(m.G.named_parameters())
     # (1) discriminator-phase gradients against the reference: strict
     for k, c in fx['d_grads'].items():
