@@ -208,6 +208,24 @@ int segan_l1_mean(const float* x, const float* y, float* loss, float* ws, int64_
 int segan_l1_bwd(const float* x, const float* y, const float* gout, float gscale, float* grad,
                  int64_t n, void* stream);
 
+/* ---- STFT power loss of the WSEGAN step (model.py:640-653) ------------------------------
+ * torch.stft(x, n_fft, hop_length=hop, win_length=win, normalized=True) with window=None:
+ * a rectangular window zero-padded to n_fft, centre (reflect) padding of n_fft/2.  Only `win`
+ * samples of a frame are non-zero, so the transform is frames[B*NF, win] x basis[win, 2*nbins]
+ * (NF = 1 + T/hop, nbins = n_fft/2+1; columns [0,nbins) real, [nbins,2nbins) imaginary) run
+ * through segan_gemm.  Requires n_fft/2 < T. */
+int segan_stft_basis(float* basis, int n_fft, int win, void* stream);
+int segan_stft_frames(const float* x, float* frames, int B, int T, int n_fft, int hop, int win,
+                      void* stream);
+/* db[r][k] = 10*log10(re^2 + im^2 + eps) of S[rows][2*nbins]  (eps = 10e-20, model.py:646) */
+int segan_powdb(const float* S, float* db, int64_t rows, int nbins, float eps, void* stream);
+/* dS = ddb * d(db)/d(re, im) */
+int segan_powdb_bwd(const float* S, const float* ddb, float* dS, int64_t rows, int nbins, float eps,
+                    void* stream);
+/* dx[B][T] = adjoint of segan_stft_frames applied to dframes[B*NF][win] (overwrites dx) */
+int segan_stft_overlap_add(const float* dframes, float* dx, int B, int T, int n_fft, int hop,
+                           int win, void* stream);
+
 /* ---- optimizers (model.py:219-228) ---------------------------------------------------- */
 /* torch.optim.RMSprop (no momentum, not centered): sq = alpha*sq + (1-alpha)*g*g;
  * p -= lr * g / (sqrt(sq) + eps), over a flat arena of n floats. */

@@ -60,6 +60,11 @@ SIGNATURES = {
     'segan_mse_const': (c_int, [_P, c_float, _P, _P, _P, c_float, c_int, _P]),
     'segan_l1_bwd': (c_int, [_P, _P, _P, c_float, _P, c_int64, _P]),
     'segan_l1_mean': (c_int, [_P, _P, _P, _P, c_int64, _P]),
+    'segan_stft_basis': (c_int, [_P, c_int, c_int, _P]),
+    'segan_stft_frames': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    'segan_powdb': (c_int, [_P, _P, c_int64, c_int, c_float, _P]),
+    'segan_powdb_bwd': (c_int, [_P, _P, _P, c_int64, c_int, c_float, _P]),
+    'segan_stft_overlap_add': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     'segan_rmsprop_step': (c_int, [_P, _P, _P, c_float, c_float, c_float, c_int64, _P]),
     'segan_adam_step': (c_int, [_P, _P, _P, _P, c_float, c_float, c_float, c_float, c_int, c_int64,
                                 _P]),

@@ -246,7 +246,6 @@ __global__ void act_bwd_kernel(const ActBwdArgs p) {
   const ChanRange cr = chan_range(p.B, p.nsplit);
   const int c = cr.c;
   const int nb = cr.b_end - cr.b_beg;
-  const long cnt = (long)(nb > 0 ? nb : 0) * p.L;
   const float sl = p.slope ? p.slope[c] : 1.0f;
   const float al = p.alpha ? p.alpha[c] : 0.0f;
   float mu = 0.f, rs = 1.f, ga = 1.f, be = 0.f, dbeta_m = 0.f, dgamma_m = 0.f;

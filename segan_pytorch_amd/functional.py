@@ -494,3 +494,32 @@ class L1MeanFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             gy = ops.l1_bwd(y, x, gout=g.contiguous())
         return gx, gy
+
+
+class STFTPowL1Fn(torch.autograd.Function):
+    """F.l1_loss(pow_db(STFT(x)), pow_db(STFT(y))) of the WSEGAN step (model.py:640-653):
+    rectangular window `win` centred in n_fft, hop `hop`, normalized, reflect centre padding;
+    pow_db = 10*log10(|X|^2 + 10e-20).  x, y: [B, 1, T] (or [B, T]); the gradient flows to x
+    only (y is the clean reference)."""
+
+    @staticmethod
+    def forward(ctx, x, y, n_fft, hop, win):
+        shape = x.shape
+        x2 = x.reshape(shape[0], shape[-1]).contiguous()
+        y2 = y.reshape(shape[0], shape[-1]).contiguous()
+        basis = ops.stft_basis(n_fft, win, x2.device)
+        Sx = ops.stft_spectrum(ops.stft_frames(x2, n_fft, hop, win), basis)
+        dbx = ops.powdb(Sx)
+        dby = ops.powdb(ops.stft_spectrum(ops.stft_frames(y2, n_fft, hop, win), basis))
+        ctx.save_for_backward(Sx, dbx, dby, basis)
+        ctx.geom = (shape, n_fft, hop, win)
+        return ops.l1_mean(dbx, dby)
+
+    @staticmethod
+    def backward(ctx, g):
+        Sx, dbx, dby, basis = ctx.saved_tensors
+        shape, n_fft, hop, win = ctx.geom
+        ddb = ops.l1_bwd(dbx, dby, gout=g.contiguous())
+        dfr = ops.stft_spectrum_bwd(ops.powdb_bwd(Sx, ddb), basis)
+        dx = ops.stft_overlap_add(dfr, shape[0], shape[-1], n_fft, hop, win)
+        return dx.view(shape), None, None, None, None

@@ -34,3 +34,8 @@ def mse_loss(input, target):
 def l1_loss(input, target):
     """mean(|input - target|)."""
     return Fn.L1MeanFn.apply(input, target)
+
+
+def stft_pow_l1(x, y, n_fft, hop_length=160, win_length=320):
+    """L1 between the dB power spectra of x and y (WSEGAN power loss, model.py:640-653)."""
+    return Fn.STFTPowL1Fn.apply(x, y, int(n_fft), int(hop_length), int(win_length))

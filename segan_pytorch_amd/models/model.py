@@ -271,13 +271,6 @@ class WSEGAN(SEGAN):
         return (uttname, clean.unsqueeze(1).to(device), noisy.unsqueeze(1).to(device),
                 slice_idx.to(device))
 
-    def _pow_db(self, x):
-        """10*log10(|STFT|^2 + 10e-20), rect window 320 / hop 160 / normalized
-        (model.py:640-653; torch.norm(stft, 2, dim=3) of the legacy real view = abs)."""
-        st = torch.stft(x.squeeze(1), n_fft=min(x.size(-1), self.n_fft), hop_length=160,
-                        win_length=320, normalized=True, return_complex=True)
-        return 10 * torch.log10(st.abs() ** 2 + 10e-20)
-
     def wgan_step(self, uttname, clean, noisy, Gopt, Dopt, l1_weight, z=None):
         """One WSEGAN step (model.py:577-669).  Returns (d_loss, G_cost, pow_loss,
         den_loss) as device scalars."""
@@ -322,7 +315,8 @@ class WSEGAN(SEGAN):
         with _frozen(self.D):
             d_fake_, _ = self.infer_D(Genh, noisy)
             g_adv_loss = cost(d_fake_.view(-1), 1.0)
-            pow_loss = self.pow_weight * losses.l1_loss(self._pow_db(Genh), self._pow_db(clean))
+            pow_loss = self.pow_weight * losses.stft_pow_l1(
+                Genh, clean, min(Genh.size(-1), self.n_fft), 160, 320)
             G_cost = g_adv_loss + pow_loss
             if l1_weight > 0:
                 mask = torch.zeros(bsz, 1, Genh.size(2), device=Genh.device)

@@ -515,6 +515,75 @@ def l1_mean(x, y):
     return loss
 
 
+# ---- STFT power loss (model.py:640-653) ----------------------------------------------------
+_stft_basis_cache = {}
+
+
+def stft_basis(n_fft, win, device):
+    """[win, 2*(n_fft/2+1)] real DFT basis of a centred rectangular window (cached)."""
+    key = (n_fft, win, str(device))
+    if key not in _stft_basis_cache:
+        bs = torch.empty((win, 2 * (n_fft // 2 + 1)), device=device, dtype=torch.float32)
+        check(_lib.load().segan_stft_basis(_ptr(bs), n_fft, win, _stream()), 'stft_basis')
+        _stft_basis_cache[key] = bs
+    return _stft_basis_cache[key]
+
+
+def stft_frames(x, n_fft, hop, win):
+    """x [B, T] -> frames [B*NF, win] of the reflect-padded signal."""
+    _chk(x, 'x', 2)
+    B, T = x.shape
+    NF = 1 + T // hop
+    fr = torch.empty((B * NF, win), device=x.device, dtype=torch.float32)
+    check(_lib.load().segan_stft_frames(_ptr(x), _ptr(fr), B, T, n_fft, hop, win, _stream()),
+          'stft_frames')
+    return fr
+
+
+def stft_spectrum(frames, basis):
+    """frames [R, win] @ basis [win, 2*nbins] -> [R, 2*nbins] (real | imaginary)."""
+    R, win = frames.shape
+    N2 = basis.shape[1]
+    S = torch.empty((R, N2), device=frames.device, dtype=torch.float32)
+    gemm(frames, win, 1, basis, N2, 1, S, R, N2, win, True)
+    return S
+
+
+def stft_spectrum_bwd(dS, basis):
+    """dS [R, 2*nbins] @ basis^T -> dframes [R, win]."""
+    R, N2 = dS.shape
+    win = basis.shape[0]
+    df = torch.empty((R, win), device=dS.device, dtype=torch.float32)
+    gemm(dS, N2, 1, basis, 1, N2, df, R, win, N2, True)
+    return df
+
+
+def powdb(S, eps=10e-20):
+    _chk(S, 'S', 2)
+    rows, nb = S.shape[0], S.shape[1] // 2
+    db = torch.empty((rows, nb), device=S.device, dtype=torch.float32)
+    check(_lib.load().segan_powdb(_ptr(S), _ptr(db), rows, nb, eps, _stream()), 'powdb')
+    return db
+
+
+def powdb_bwd(S, ddb, eps=10e-20):
+    _chk(S, 'S', 2)
+    _chk(ddb, 'ddb', 2)
+    rows, nb = S.shape[0], S.shape[1] // 2
+    dS = torch.empty_like(S)
+    check(_lib.load().segan_powdb_bwd(_ptr(S), _ptr(ddb), _ptr(dS), rows, nb, eps, _stream()),
+          'powdb_bwd')
+    return dS
+
+
+def stft_overlap_add(dframes, B, T, n_fft, hop, win):
+    _chk(dframes, 'dframes', 2)
+    dx = torch.empty((B, T), device=dframes.device, dtype=torch.float32)
+    check(_lib.load().segan_stft_overlap_add(_ptr(dframes), _ptr(dx), B, T, n_fft, hop, win,
+                                             _stream()), 'stft_overlap_add')
+    return dx
+
+
 def rmsprop_step(p, g, sq, lr, alpha, eps):
     check(_lib.load().segan_rmsprop_step(_ptr(p), _ptr(g), _ptr(sq), lr, alpha, eps, p.numel(),
                                          _stream()), 'rmsprop_step')

@@ -9,6 +9,8 @@ with a torch-CPU restatement of the SAME contract (include/segan_hip.h), so the 
 code runs end to end on CPU against the golden fixtures.  Nothing outside tests/ imports
 this module; the product never runs without the HIP library.
 """
+import math
+
 import torch
 import torch.nn.functional as F
 
@@ -232,6 +234,57 @@ def l1_bwd(x, y, gout=None, gscale=1.0):
     return g.float()
 
 
+def _frame_index(T, n_fft, hop, win):
+    NF = 1 + T // hop
+    off = (n_fft - win) // 2 - n_fft // 2
+    o = (torch.arange(NF).view(-1, 1) * hop + torch.arange(win).view(1, -1) + off)
+    o = o.abs()
+    o = torch.where(o >= T, 2 * (T - 1) - o, o)
+    return o                     # [NF, win] source sample of every frame element
+
+
+def stft_basis(n_fft, win, device):
+    nb = n_fft // 2 + 1
+    left = (n_fft - win) // 2
+    ang = 2 * math.pi * ((torch.arange(nb).view(1, -1) * (left + torch.arange(win)).view(-1, 1))
+                         % n_fft).double() / n_fft
+    return (torch.cat((torch.cos(ang), -torch.sin(ang)), 1) / math.sqrt(n_fft)).float()
+
+
+def stft_frames(x, n_fft, hop, win):
+    B, T = x.shape
+    idx = _frame_index(T, n_fft, hop, win)
+    return x[:, idx].reshape(-1, win).contiguous()
+
+
+def stft_spectrum(frames, basis):
+    return (frames.double() @ basis.double()).float()
+
+
+def stft_spectrum_bwd(dS, basis):
+    return (dS.double() @ basis.double().t()).float()
+
+
+def powdb(S, eps=10e-20):
+    nb = S.shape[1] // 2
+    p = S[:, :nb].double() ** 2 + S[:, nb:].double() ** 2
+    return (10 * torch.log10(p + eps)).float()
+
+
+def powdb_bwd(S, ddb, eps=10e-20):
+    nb = S.shape[1] // 2
+    re, im = S[:, :nb].double(), S[:, nb:].double()
+    g = ddb.double() * (20.0 / math.log(10.0)) / (re * re + im * im + eps)
+    return torch.cat((g * re, g * im), 1).float()
+
+
+def stft_overlap_add(dframes, B, T, n_fft, hop, win):
+    idx = _frame_index(T, n_fft, hop, win).reshape(-1)
+    dx = torch.zeros(B, T, dtype=torch.float64)
+    dx.index_add_(1, idx, dframes.double().view(B, -1))
+    return dx.float()
+
+
 def rmsprop_step(p, g, sq, lr, alpha, eps):
     sq.mul_(alpha).addcmul_(g, g, value=1 - alpha)
     p.addcdiv_(g, sq.sqrt().add_(eps), value=-lr)
@@ -264,7 +317,8 @@ def _chk(t, name, ndim=None):
 _NAMES = ['conv1d_fwd', 'conv1d_dgrad', 'wgrad', 'deconv1d_fwd', 'deconv1d_dgrad', 'bn_stats',
           'affine_prelu', 'sum_skip', 'bce_logits_const', 'bce_logits_const_bwd', 'act_bwd', 'tanh_bwd', 'linear_fwd', 'linear_dgrad', 'linear_wgrad',
           'bias_prelu_rows', 'bias_prelu_rows_bwd', 'mse_const', 'mse_const_bwd', 'l1_mean',
-          'l1_bwd', 'rmsprop_step', 'adam_step', 'fill_', 'scale_', '_chk']
+          'l1_bwd', 'stft_basis', 'stft_frames', 'stft_spectrum', 'stft_spectrum_bwd', 'powdb',
+          'powdb_bwd', 'stft_overlap_add', 'rmsprop_step', 'adam_step', 'fill_', 'scale_', '_chk']
 
 
 def install():
