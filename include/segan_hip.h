@@ -226,6 +226,14 @@ int segan_powdb_bwd(const float* S, const float* ddb, float* dS, int64_t rows, i
 int segan_stft_overlap_add(const float* dframes, float* dx, int B, int T, int n_fft, int hop,
                            int win, void* stream);
 
+/* ---- input side (se_dataset.py:108-117,196-197) ------------------------------------------
+ * int16 PCM slices -> (2/65535)(x-32767)+1 -> pre-emphasis y[n] = x[n] - coef*x[n-1], computed
+ * in double and rounded once like numpy does (bit-exact).  pcm: [B][2][T+1] (clean row, noisy
+ * row; element 0 of a row is the wav sample preceding the slice), first[B]: 1 when the slice
+ * starts its wav (then y[0] = x[0]).  Outputs clean/noisy [B][T] fp32. */
+int segan_pcm16_prep(const int16_t* pcm, const unsigned char* first, float* clean, float* noisy,
+                     int B, int T, double coef, void* stream);
+
 /* ---- optimizers (model.py:219-228) ---------------------------------------------------- */
 /* torch.optim.RMSprop (no momentum, not centered): sq = alpha*sq + (1-alpha)*g*g;
  * p -= lr * g / (sqrt(sq) + eps), over a flat arena of n floats. */

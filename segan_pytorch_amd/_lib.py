@@ -5,7 +5,7 @@ RuntimeError carrying ``segan_last_error()`` is raised.
 """
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libsegan_hip.so')
@@ -60,6 +60,7 @@ SIGNATURES = {
     'segan_mse_const': (c_int, [_P, c_float, _P, _P, _P, c_float, c_int, _P]),
     'segan_l1_bwd': (c_int, [_P, _P, _P, c_float, _P, c_int64, _P]),
     'segan_l1_mean': (c_int, [_P, _P, _P, _P, c_int64, _P]),
+    'segan_pcm16_prep': (c_int, [_P, _P, _P, _P, c_int, c_int, c_double, _P]),
     'segan_stft_basis': (c_int, [_P, c_int, c_int, _P]),
     'segan_stft_frames': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     'segan_powdb': (c_int, [_P, _P, c_int64, c_int, c_float, _P]),

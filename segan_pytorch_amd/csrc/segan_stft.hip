@@ -164,3 +164,44 @@ extern "C" int segan_stft_overlap_add(const float* dframes, float* dx, int B, in
                      dframes, dx, B, T, NF, hop, win, off);
   return segan_check_launch("stft_overlap_add");
 }
+
+// ====================================================================================
+// Input side: int16 PCM slices -> [-1,1] -> pre-emphasis, on the GPU.
+// se_dataset.py:108-117,196-197: x = (2/65535)(pcm - 32767) + 1 ; y[n] = x[n] - coef*x[n-1]
+// evaluated in float64 by numpy on the WHOLE wav before slicing, so a slice needs one sample
+// of left context: every stored row holds T+1 samples (row[0] = the sample before the slice)
+// and `first[b]` marks slices that start at sample 0 of their wav (y[0] = x[0] there).
+// The arithmetic is done in double and rounded once, like the reference: bit-exact.
+// ====================================================================================
+__global__ void pcm16_prep_kernel(const int16_t* __restrict__ pcm, const unsigned char* __restrict__ first,
+                                  float* __restrict__ clean, float* __restrict__ noisy, int B, int T,
+                                  double coef) {
+  const size_t total = (size_t)B * 2 * T;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i % T);
+    const size_t r = i / T;            // row = 2*b + which
+    const int b = (int)(r >> 1);
+    const int16_t* src = pcm + r * (size_t)(T + 1);
+    const double x = (2.0 / 65535.0) * ((double)src[n + 1] - 32767.0) + 1.0;
+    double y = x;
+    if (coef > 0.0 && !(n == 0 && first[b])) {
+      const double xp = (2.0 / 65535.0) * ((double)src[n] - 32767.0) + 1.0;
+      y = x - coef * xp;
+    }
+    float* dst = (r & 1) ? noisy : clean;
+    dst[(size_t)b * T + n] = (float)y;
+  }
+}
+
+extern "C" int segan_pcm16_prep(const int16_t* pcm, const unsigned char* first, float* clean,
+                                float* noisy, int B, int T, double coef, void* stream) {
+  SEGAN_REQUIRE(pcm && first && clean && noisy, "pcm16_prep: NULL pointer");
+  SEGAN_REQUIRE(B > 0 && T > 0, "pcm16_prep: bad sizes");
+  const size_t total = (size_t)B * 2 * T;
+  const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+  const double c = coef > 0.0 ? coef : 0.0;   // a double, like the reference's python float
+  hipLaunchKernelGGL(pcm16_prep_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pcm, first,
+                     clean, noisy, B, T, c);
+  return segan_check_launch("pcm16_prep");
+}

@@ -1,8 +1,14 @@
 """Batch format and waveform helpers of the reference's data side
 (segan/datasets/se_dataset.py:21-29,108-126), plus the synthetic dataset the benchmark
 and the tests use.  The on-disk dataset pipeline (wav slicing, caches) is outside the
-accelerated path ("next").
+accelerated path ("next"); `build_pcm_shard` / `PCMShardDataset` are
+the MI355X-side replacement for it: slices are cut ONCE into an int16 shard file, batches
+travel to the GPU as int16 (half the PCIe bytes of fp32) and are normalised and
+pre-emphasised there by `segan_pcm16_prep`, bit-exactly as the reference does on the host.
 """
+import json
+import os
+
 import numpy as np
 import torch
 from torch.utils.data import Dataset
@@ -131,3 +137,91 @@ class SEDataset(Dataset):
             s = _r.choice(self.random_scale)
             c, n = c * s, n * s
         return name, c, n, si
+
+
+# ---- pre-sliced int16 shards ---------------------------------------
+SHARD_MAGIC = 'segan-pcm16-shard-v1'
+
+
+def build_pcm_shard(clean_dir, noisy_dir, out_prefix, slice_size=2 ** 14, stride=0.5,
+                    max_samples=None):
+    """Cut every clean/noisy wav pair into `slice_size` windows (same windows as
+    `SEDataset` / se_dataset.py:62-88) and store them as raw int16 PCM:
+
+      <out_prefix>.pcm16   int16 [n_items][2][slice_size+1]   (clean row, noisy row; element
+                           0 = the wav sample preceding the window, needed by pre-emphasis)
+      <out_prefix>.json    {magic, n_items, slice_size, names[], slice_idx[], first[]}
+
+    The reference re-reads and re-normalises both full wav files for every item
+    (se_dataset.py:190-198,309-353); at the HIP step's rate that starves the GPU."""
+    import glob
+    from scipy.io import wavfile
+    clean_names = sorted(glob.glob(os.path.join(clean_dir, '*.wav')))
+    noisy_names = sorted(glob.glob(os.path.join(noisy_dir, '*.wav')))
+    if len(clean_names) != len(noisy_names) or len(clean_names) == 0:
+        raise ValueError('No wav data found! Check your data path please')
+    if max_samples is not None:
+        clean_names, noisy_names = clean_names[:max_samples], noisy_names[:max_samples]
+    rows, names, sidx, first = [], [], [], []
+    for cpath, npath in zip(clean_names, noisy_names):
+        c, n = wavfile.read(cpath)[1], wavfile.read(npath)[1]
+        if c.dtype != np.int16 or n.dtype != np.int16:
+            raise ValueError('pcm shards hold 16-bit PCM; {} is {}'.format(cpath, c.dtype))
+        name = os.path.splitext(os.path.basename(cpath))[0]
+        for si, (beg, end) in enumerate(slice_signal_index(min(len(c), len(n)), slice_size, stride)):
+            item = np.empty((2, slice_size + 1), dtype=np.int16)
+            for k, w in enumerate((c, n)):
+                item[k, 1:] = w[beg:end]
+                item[k, 0] = w[beg - 1] if beg > 0 else 0
+            rows.append(item)
+            names.append(name)
+            sidx.append(si)
+            first.append(1 if beg == 0 else 0)
+    data = np.stack(rows) if rows else np.zeros((0, 2, slice_size + 1), np.int16)
+    data.tofile(out_prefix + '.pcm16')
+    with open(out_prefix + '.json', 'w') as f:
+        json.dump({'magic': SHARD_MAGIC, 'n_items': len(rows), 'slice_size': slice_size,
+                   'names': names, 'slice_idx': sidx, 'first': first}, f)
+    return len(rows)
+
+
+class PCMShardDataset(Dataset):
+    """Items of a pcm16 shard: (uttname, int16 [2, T+1], first flag, slice_idx).  Use with
+    `PCMShardCollate`, which turns a batch into the loader's [uttnames, clean, noisy,
+    slice_idx] format with clean/noisy already on the GPU as fp32."""
+
+    def __init__(self, prefix):
+        with open(prefix + '.json') as f:
+            self.meta = json.load(f)
+        if self.meta.get('magic') != SHARD_MAGIC:
+            raise ValueError('{}.json is not a {} index'.format(prefix, SHARD_MAGIC))
+        T = self.meta['slice_size']
+        self.slice_size = T
+        self.data = np.memmap(prefix + '.pcm16', dtype=np.int16, mode='r',
+                              shape=(self.meta['n_items'], 2, T + 1))
+
+    def __len__(self):
+        return self.meta['n_items']
+
+    def __getitem__(self, i):
+        return (self.meta['names'][i], torch.from_numpy(np.array(self.data[i])),
+                self.meta['first'][i], self.meta['slice_idx'][i])
+
+
+class PCMShardCollate(object):
+    """collate_fn for `PCMShardDataset`: one pinned int16 staging copy, one H2D transfer,
+    then normalisation + pre-emphasis on the device (`ops.pcm16_prep`)."""
+
+    def __init__(self, preemph, device='cuda'):
+        self.preemph = float(preemph)
+        self.device = torch.device(device)
+
+    def __call__(self, batch):
+        from . import ops
+        names = [b[0] for b in batch]
+        pcm = torch.stack([b[1] for b in batch]).pin_memory()
+        first = torch.tensor([b[2] for b in batch], dtype=torch.uint8).pin_memory()
+        idx = torch.as_tensor([int(b[3]) for b in batch])
+        clean, noisy = ops.pcm16_prep(pcm.to(self.device, non_blocking=True),
+                                      first.to(self.device, non_blocking=True), self.preemph)
+        return [names, clean, noisy, idx]

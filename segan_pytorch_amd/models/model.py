@@ -111,28 +111,43 @@ class SEGAN(Model):
         self.D.apply(weights_init)
 
     # ---- inference --------------------------------------------------------------------
-    def generate(self, inwav, z=None, device='cpu'):
-        """Chunked enhancement of a whole utterance (model.py:116-157)."""
+    def generate(self, inwav, z=None, device='cpu', max_batch=64):
+        """Chunked enhancement of a whole utterance (model.py:116-157): 16384-sample chunks,
+        the last one zero padded, one z for all chunks, de-emphasis at the end.  The chunks
+        are independent (G has no cross-sample coupling in eval mode), so they run as ONE
+        batched forward per `max_batch` chunks instead of the reference's batch-1 loop; when
+        z is None the first chunk runs alone so that G draws z for a single chunk exactly as
+        the reference does, and that z is re-used for the rest (model.py:144-146)."""
         self.G.eval()
         N = 16384
-        c_res = None
-        g_c = None
         T = inwav.shape[2]
+        nch = (T + N - 1) // N
+        x = torch.zeros(nch, 1, N, device=device, dtype=torch.float32)
+        x.view(-1)[:T] = torch.as_tensor(inwav[0, 0]).to(device=device, dtype=torch.float32)
+        outs, hall, beg = [], None, 0
         with torch.no_grad():
-            for beg_i in range(0, T, N):
-                length = min(N, T - beg_i)
-                pad = N - length
-                x = torch.zeros(1, 1, N, device=device, dtype=torch.float32)
-                x[0, 0, :length] = torch.as_tensor(inwav[0, 0, beg_i:beg_i + length]).to(device)
-                canvas_w, hall = self.infer_G(x, z=z, ret_hid=True)
-                nums = [int(k.split('_')[1]) for k in hall.keys() if 'enc' in k and 'zc' not in k]
-                g_c = hall['enc_{}'.format(max(nums))]
-                if z is None and hasattr(self.G, 'z'):
-                    z = self.G.z            # z of the first chunk is re-used (model.py:144-146)
-                if pad > 0:
-                    canvas_w = canvas_w[0, 0, :-pad]
-                canvas_w = canvas_w.data.cpu().numpy().squeeze()
-                c_res = canvas_w if c_res is None else np.concatenate((c_res, canvas_w))
+            if z is None:
+                y, hall = self.infer_G(x[:1].contiguous(), z=None, ret_hid=True)
+                if hasattr(self.G, 'z'):
+                    z = self.G.z
+                outs.append(y)
+                beg = 1
+            while beg < nch:
+                end = min(nch, beg + max_batch)
+                zb = None
+                if z is not None:
+                    if z.size(0) != 1:
+                        # the reference would feed this z to its batch-1 chunks and fail in cat
+                        raise ValueError('generate: z must have batch size 1, got {} (G.z is set '
+                                         'by the first forward of the module, generator.py:203)'
+                                         .format(z.size(0)))
+                    zb = z.to(device).expand(end - beg, -1, -1).contiguous()
+                y, hall = self.infer_G(x[beg:end].contiguous(), z=zb, ret_hid=True)
+                outs.append(y)
+                beg = end
+        nums = [int(k.split('_')[1]) for k in hall.keys() if 'enc' in k and 'zc' not in k]
+        g_c = hall['enc_{}'.format(max(nums))][-1:]
+        c_res = torch.cat(outs, 0).reshape(-1)[:T].cpu().numpy()
         c_res = de_emphasize(c_res, self.preemph)
         return c_res, g_c
 

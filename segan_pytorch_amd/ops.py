@@ -584,6 +584,22 @@ def stft_overlap_add(dframes, B, T, n_fft, hop, win):
     return dx
 
 
+def pcm16_prep(pcm, first, coef):
+    """int16 slices [B, 2, T+1] (+ first[B] uint8) -> (clean, noisy) fp32 [B, T]: min-max
+    normalisation and pre-emphasis of se_dataset.py:108-117 on the GPU, bit-exact."""
+    if pcm.dtype != torch.int16 or first.dtype != torch.uint8 or not pcm.is_cuda or not first.is_cuda:
+        raise TypeError('pcm16_prep: pcm must be a CUDA int16 tensor and first a CUDA uint8 tensor')
+    if pcm.dim() != 3 or pcm.shape[1] != 2 or not pcm.is_contiguous() or first.numel() != pcm.shape[0]:
+        raise ValueError('pcm16_prep: pcm must be contiguous [B, 2, T+1], first [B]')
+    B, T = pcm.shape[0], pcm.shape[2] - 1
+    clean = torch.empty((B, T), device=pcm.device, dtype=torch.float32)
+    noisy = torch.empty((B, T), device=pcm.device, dtype=torch.float32)
+    check(_lib.load().segan_pcm16_prep(ctypes.c_void_p(pcm.data_ptr()),
+                                       ctypes.c_void_p(first.data_ptr()), _ptr(clean), _ptr(noisy),
+                                       B, T, float(coef), _stream()), 'pcm16_prep')
+    return clean, noisy
+
+
 def rmsprop_step(p, g, sq, lr, alpha, eps):
     check(_lib.load().segan_rmsprop_step(_ptr(p), _ptr(g), _ptr(sq), lr, alpha, eps, p.numel(),
                                          _stream()), 'rmsprop_step')

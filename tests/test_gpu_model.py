@@ -399,3 +399,41 @@ def test_precision_modes_on_the_default_net(segan_plus_b2, prec, out_tol, grad_t
             g = dn[k].grad.detach().cpu().double().flatten()
             cos = torch.dot(g, v.double().flatten()) / (g.norm() * v.double().norm() + 1e-30)
             assert cos > 0.95, (k, cos.item())
+
+
+def test_generate_batched_chunks_equal_the_chunk_loop(tiny_step):
+    """SEGAN.generate runs all 16384-sample chunks of an utterance in one batched forward;
+    the result must equal the reference's batch-1 chunk loop (model.py:116-157) run on our G."""
+    from segan_pytorch_amd.datasets import de_emphasize
+    fx = tiny_step
+    m = build(fx)
+    T = 2 * 16384 + 5000
+    g = torch.Generator().manual_seed(3)
+    wav = (torch.rand(1, 1, T, generator=g) * 2 - 1)
+    z_len = 16384
+    for s in fx['opts']['genc_poolings']:
+        z_len //= s
+    z = torch.randn(1, fx['opts']['z_dim'], z_len, generator=g).to(DEV)
+    got, g_c = m.generate(wav, z=z, device=DEV)
+    m.G.eval()
+    chunks = []
+    with torch.no_grad():
+        for beg in range(0, T, 16384):
+            x = torch.zeros(1, 1, 16384, device=DEV)
+            n = min(16384, T - beg)
+            x[0, 0, :n] = wav[0, 0, beg:beg + n].to(DEV)
+            y, hall = m.G(x, z=z, ret_hid=True)
+            chunks.append(y[0, 0, :n].cpu())
+    want = de_emphasize(torch.cat(chunks).numpy(), m.preemph)
+    assert got.shape == want.shape == (T,)
+    assert np.abs(got - want).max() < 1e-5
+    last = max(int(k.split('_')[1]) for k in hall if 'enc' in k and 'zc' not in k)
+    assert max_rel(g_c, hall['enc_{}'.format(last)]) < 1e-6
+    # z drawn inside a fresh G for the first chunk is re-used for the others
+    m2 = build(fx)
+    torch.manual_seed(9)
+    got2, _ = m2.generate(wav, device=DEV)
+    torch.manual_seed(9)
+    z2 = torch.randn(1, fx['opts']['z_dim'], z_len)
+    got3, _ = m2.generate(wav, z=z2.to(DEV), device=DEV)
+    assert np.abs(got2 - got3).max() < 1e-5

@@ -1,0 +1,66 @@
+"""Pre-sliced int16 shards: the shard holds exactly the windows the
+wav-directory dataset produces, and the GPU normalise + pre-emphasis kernel reproduces the
+reference's host pipeline (se_dataset.py:108-117,196-197) bit for bit."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from segan_pytorch_amd.datasets import (PCMShardCollate, PCMShardDataset, SEDataset, build_pcm_shard,
+                                        normalize_wave_minmax, pre_emphasize)
+
+
+def _write_wavs(tmp_path, lens=(40000, 16384, 52011)):
+    from scipy.io import wavfile
+    rng = np.random.RandomState(0)
+    cd, nd = tmp_path / 'clean', tmp_path / 'noisy'
+    cd.mkdir()
+    nd.mkdir()
+    for i, n in enumerate(lens):
+        c = rng.randint(-32768, 32768, size=n).astype(np.int16)
+        c[0] = -32768 if i == 0 else c[0]           # extremes of the int16 range
+        c[1] = 32767
+        z = np.clip(c.astype(np.int32) + rng.randint(-3000, 3000, size=n), -32768, 32767).astype(np.int16)
+        wavfile.write(str(cd / 'utt{}.wav'.format(i)), 16000, c)
+        wavfile.write(str(nd / 'utt{}.wav'.format(i)), 16000, z)
+    return str(cd), str(nd)
+
+
+def test_shard_holds_the_dataset_windows(tmp_path):
+    cd, nd = _write_wavs(tmp_path)
+    n = build_pcm_shard(cd, nd, str(tmp_path / 'sh'), slice_size=16384, stride=0.5)
+    ref = SEDataset(cd, nd, preemph=0.95, slice_size=16384, stride=0.5)
+    ds = PCMShardDataset(str(tmp_path / 'sh'))
+    assert n == len(ds) == len(ref) > 4
+    for i in range(len(ds)):
+        name, pcm, first, si = ds[i]
+        rname, rc, rn, rsi = ref[i]
+        assert (name, si) == (rname, rsi)
+        assert pcm.dtype == torch.int16 and tuple(pcm.shape) == (2, 16385)
+        # host restatement of the device kernel on the stored row == the dataset's item
+        for row, want in ((pcm[0], rc), (pcm[1], rn)):
+            x = normalize_wave_minmax(row.numpy())
+            y = x[1:] - 0.95 * x[:-1]
+            if first:
+                y[0] = x[1]
+            assert np.array_equal(y.astype(np.float32), want.numpy())
+    with pytest.raises(ValueError):
+        open(str(tmp_path / 'bad.json'), 'w').write('{"magic": "x"}')
+        PCMShardDataset(str(tmp_path / 'bad'))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('preemph', [0.95, 0.0])
+def test_gpu_prep_is_bit_exact(tmp_path, preemph):
+    cd, nd = _write_wavs(tmp_path)
+    build_pcm_shard(cd, nd, str(tmp_path / 'sh'), slice_size=16384, stride=0.5)
+    ref = SEDataset(cd, nd, preemph=preemph, slice_size=16384, stride=0.5)
+    ds = PCMShardDataset(str(tmp_path / 'sh'))
+    names, clean, noisy, idx = PCMShardCollate(preemph, 'cuda')([ds[i] for i in range(len(ds))])
+    assert clean.is_cuda and clean.dtype == torch.float32 and tuple(clean.shape) == (len(ds), 16384)
+    for i in range(len(ds)):
+        rname, rc, rn, rsi = ref[i]
+        assert names[i] == rname and int(idx[i]) == rsi
+        assert torch.equal(clean[i].cpu(), rc)
+        assert torch.equal(noisy[i].cpu(), rn)

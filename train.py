@@ -7,8 +7,9 @@ same defaults, same `train.opts` dump) driving the HIP engine in `segan_pytorch_
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 train.py ...
 
 Additions over the reference: `--synthetic N` trains on N fixed-seed synthetic chunk
-pairs (no dataset needed), and under torch.distributed.run every rank trains on its
-shard of each epoch with RCCL gradient averaging.
+pairs (no dataset needed), `--pcm_shard PREFIX` trains from a pre-sliced int16 shard whose
+batches are normalised / pre-emphasised on the GPU, and under torch.distributed.run every
+rank trains on its shard of each epoch with RCCL gradient averaging.
 """
 import argparse
 import json
@@ -21,7 +22,8 @@ from torch.utils.data import DataLoader
 
 from segan_pytorch_amd import distributed as sdist
 from segan_pytorch_amd import losses
-from segan_pytorch_amd.datasets import SEDataset, SyntheticSEDataset, collate_fn
+from segan_pytorch_amd.datasets import (PCMShardCollate, PCMShardDataset, SEDataset,
+                                        SyntheticSEDataset, collate_fn)
 from segan_pytorch_amd.models import SEGAN, WSEGAN
 
 _FMAPS = [64, 128, 256, 512, 1024]
@@ -95,6 +97,9 @@ FLAGS = [
     # ---- additions ----
     ('--synthetic', dict(type=int, default=0,
                          help='train on this many fixed-seed synthetic chunk pairs')),
+    ('--pcm_shard', dict(type=str, default=None,
+                         help='prefix of a pre-sliced int16 shard (scripts/make_pcm_shard.py): batches '
+                              'are normalised and pre-emphasised on the GPU')),
 ]
 
 
@@ -131,8 +136,16 @@ def main(opts):
         segan.D.load_pretrained(opts.d_pretrained_ckpt, True)
     if opts.h5:
         raise NotImplementedError('--h5 datasets are not implemented')
+    collate, workers, pin = collate_fn, opts.num_workers, True
     if opts.synthetic > 0:
         dset = SyntheticSEDataset(opts.synthetic, opts.slice_size, seed=opts.seed)
+    elif opts.pcm_shard is not None:
+        if opts.preemph_norm or list(opts.random_scale) != [1]:
+            raise NotImplementedError('--pcm_shard supports the default pipeline only '
+                                      '(no --preemph_norm, no --random_scale)')
+        dset = PCMShardDataset(opts.pcm_shard)
+        # the collate launches the GPU normalise/pre-emphasis kernel: main process only
+        collate, workers, pin = PCMShardCollate(opts.preemph, device), 0, False
     else:
         dset = SEDataset(opts.clean_trainset, opts.noisy_trainset, opts.preemph,
                          cache_dir=opts.cache_dir, split='train', stride=opts.data_stride,
@@ -144,8 +157,8 @@ def main(opts):
         sampler = DistributedSampler(dset, num_replicas=world, rank=rank, shuffle=True,
                                      seed=opts.seed, drop_last=True)
     dloader = DataLoader(dset, batch_size=opts.batch_size, shuffle=(sampler is None),
-                         sampler=sampler, num_workers=opts.num_workers, pin_memory=True,
-                         collate_fn=collate_fn, drop_last=(world > 1))
+                         sampler=sampler, num_workers=workers, pin_memory=pin,
+                         collate_fn=collate, drop_last=(world > 1))
     if opts.clean_valset is not None:
         raise NotImplementedError('validation (CompositeEval / PESQ binary) is outside the '
                                   'accelerated path')
