@@ -31,6 +31,13 @@ __device__ __forceinline__ void split3(float x, __bf16& p1, __bf16& p2, __bf16& 
   p3 = (__bf16)r2;
 }
 
+// base[elem_off] with a 32-bit byte offset (tensors < 2^30 elements, checked by the launcher):
+// a wave-uniform base then stays in SGPRs and the lane offset is one VGPR
+__device__ __forceinline__ float ld_f32(const float* base, unsigned elem_off) {
+  return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) +
+                                         (size_t)(unsigned)(elem_off << 2));
+}
+
 struct BfExtra {
   const __bf16* wp3;    // packed planes
   long plane_stride;    // elements between planes
@@ -38,7 +45,7 @@ struct BfExtra {
 };
 
 template <int MB, int NB, int WM, int U, bool IN_HI, bool OUT_HI, int SHIFTMASK, int NPL, int TU>
-__global__ __launch_bounds__(256, 2) void corr_bf_kernel(const CorrArgs a, const BfExtra x) {
+__global__ __launch_bounds__(256, NPL == 1 ? 3 : 2) void corr_bf_kernel(const CorrArgs a, const BfExtra x) {
   constexpr int S = 32 / U;
   constexpr int SI = IN_HI ? S : 1;
   constexpr int WN = 4 / WM;
@@ -93,39 +100,53 @@ __global__ __launch_bounds__(256, 2) void corr_bf_kernel(const CorrArgs a, const
   const ColTile ct = make_coltile(coltile * NB, a.Tcols, NB);
 
   // ---- activation staging tasks: task t = (half g, position j), 8 channels each ----
-  int tk_off[MAXT][SI];
+  // tk_base*[k][r]: element offset of (sample, phase-r position) inside segment 0 / 1, so an
+  // element's address is base + channel*Lin (one 24-bit mad); tk_ok: per-phase validity bits
+  unsigned tk_base0[MAXT][SI];
+  int tk_d[MAXT];          // segment 1: sample offset minus segment 0's
   unsigned tk_ok[MAXT];
-  int tk_bo0[MAXT], tk_bo1[MAXT];
+  int tk_g[MAXT], tk_j[MAXT];
+  const bool dual = a.in.C1 > 0;
+  const long pdelta = dual ? reinterpret_cast<const char*>(a.in.p1) - reinterpret_cast<const char*>(a.in.p0) : 0L;
 #pragma unroll
   for (int k = 0; k < MAXT; ++k) {
     const int t = tid + 256 * k;
-    const int j = t % RLs;
+    const int g = t >= RLs ? 1 : 0;
+    const int j = t - g * RLs;
+    tk_g[k] = g;
+    tk_j[k] = j;
     tk_ok[k] = 0u;
-    tk_bo0[k] = 0;
-    tk_bo1[k] = 0;
 #pragma unroll
-    for (int r = 0; r < SI; ++r) tk_off[k][r] = 0;
+    for (int r = 0; r < SI; ++r) tk_base0[k][r] = 0u;
+    tk_d[k] = 0;
     if (t < 2 * RLs) {
       int s, tau;
       lds_pos_decode(ct, j, a.Tcols, a.H, s, tau);
       const int b = ct.b0 + s;
       if (b < a.B) {
-        tk_bo0[k] = b * a.in.C0 * a.Lin;
-        tk_bo1[k] = b * a.in.C1 * a.Lin;
+        const unsigned bo0 = (unsigned)(b * a.in.C0) * (unsigned)a.Lin;
+        tk_d[k] = b * (a.in.C1 - a.in.C0) * a.Lin;
         const int wq = tau + a.win_start;
         if (IN_HI) {
 #pragma unroll
           for (int r = 0; r < SI; ++r) {
             const int idx = segan_hi_index(S * wq + r, a.Lin, a.padL, a.mode, a.roll);
-            if (idx >= 0) { tk_off[k][r] = idx; tk_ok[k] |= 1u << r; }
+            if (idx >= 0) {
+              tk_base0[k][r] = bo0 + idx;
+              tk_ok[k] |= 1u << r;
+            }
           }
         } else if (wq >= 0 && wq < a.Lin) {
-          tk_off[k][0] = wq;
+          tk_base0[k][0] = bo0 + wq;
           tk_ok[k] = 1u;
         }
       }
     }
   }
+  const int Nreal = IN_HI ? a.Cv / S : a.Cv;     // real input channels
+  constexpr int EPC = IN_HI ? S : 1;             // tile elements per real channel
+  constexpr int NRC = 8 / EPC;                   // real channels per task
+  constexpr bool XF_EARLY = NRC <= 4;            // prefetch the transforms with the data
 
   // ---- per-lane operand offsets (in 16-B pieces) ----
   int arow[NI], boff[NJ];
@@ -159,68 +180,91 @@ __global__ __launch_bounds__(256, 2) void corr_bf_kernel(const CorrArgs a, const
   // ---- staging registers ----
   u32x4 wreg[NPL][TU];
   float ireg[MAXT][8];
-  // weight piece of this thread: half g = tid / 128, row = tid % 128
+  ChanXf ixf[MAXT][XF_EARLY ? NRC : 1];
+  // weight piece of this thread: half g = tid / 128, row = tid % 128.  Byte offset inside a
+  // stage = ((tu*2 + wg)*RP + wgrow)*16; the stage base is wave-uniform.
   const int wg = tid >> 7, wr = tid & 127;
   const int wgrow = OUT_HI ? (wr / NPT) * a.NP + n0 + wr % NPT : m0 + wr;
+  const unsigned w_thr = (unsigned)(wg * a.RP + wgrow) * 16u;
+  const unsigned w_tap = (unsigned)a.RP * 32u;                      // bytes between taps
+  const size_t w_stage = (size_t)a.RP * (size_t)(TU * 32);          // bytes between stages
+  const size_t w_plane = (size_t)x.plane_stride * sizeof(__bf16);
 
-  auto load_w = [&](int st) {
-    const int cg = st / TCH, tc = st - cg * TCH;
+  auto load_w = [&](int st) __attribute__((always_inline)) {
+    const char* wst = reinterpret_cast<const char*>(x.wp3) + (size_t)st * w_stage;
 #pragma unroll
     for (int p = 0; p < NPL; ++p)
 #pragma unroll
-      for (int tu = 0; tu < TU; ++tu) {
-        const long piece = ((long)(cg * U + tc * TU + tu) * 2 + wg) * a.RP + wgrow;
-        wreg[p][tu] = *reinterpret_cast<const u32x4*>(x.wp3 + p * x.plane_stride + piece * 8);
-      }
+      for (int tu = 0; tu < TU; ++tu)
+        wreg[p][tu] = *reinterpret_cast<const u32x4*>(wst + p * w_plane + (w_thr + tu * w_tap));
   };
-  auto store_w = [&](int buf) {
+  auto store_w = [&](int buf) __attribute__((always_inline)) {
     u32x4* Wl = Wl0 + buf * (NPL * TU * 2 * MB);
 #pragma unroll
     for (int p = 0; p < NPL; ++p)
 #pragma unroll
       for (int tu = 0; tu < TU; ++tu) Wl[((p * TU + tu) * 2 + wg) * MB + wr] = wreg[p][tu];
   };
-  auto load_in = [&](int cg) {
+  // channel of element e of a task in group cg: nb + e/EPC with nb = (16cg + 8g)/EPC
+  auto load_in = [&](int cg) __attribute__((always_inline)) {
 #pragma unroll
     for (int k = 0; k < MAXT; ++k) {
-      const int t = tid + 256 * k;
-      const int g = t >= RLs ? 1 : 0;     // t < 2*RLs checked at store time
+      const int nb = (16 * cg + 8 * tk_g[k]) / EPC;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        int cv = 16 * cg + 8 * g + e;
-        cv = cv < a.Cv ? cv : 0;
-        const int n = IN_HI ? cv / S : cv;
-        const int r = IN_HI ? e % S : 0;
-        const bool seg1 = n >= a.in.C0;
-        const float* rowp = seg1 ? a.in.p1 + (size_t)(n - a.in.C0) * a.Lin
-                                 : a.in.p0 + (size_t)n * a.Lin;
-        ireg[k][e] = rowp[(seg1 ? tk_bo1[k] : tk_bo0[k]) + tk_off[k][r]];
+      for (int c = 0; c < NRC; ++c) {
+        const int n = min(nb + c, Nreal - 1);
+        if (XF_EARLY && !a.in_identity) ixf[k][XF_EARLY ? c : 0] = segan_chan_xf(a.in, n);
+        if (!dual) {
+          const unsigned ro = __umul24((unsigned)n, (unsigned)a.Lin);
+#pragma unroll
+          for (int r = 0; r < EPC; ++r) ireg[k][c * EPC + r] = ld_f32(a.in.p0, ro + tk_base0[k][IN_HI ? r : 0]);
+        } else {
+          // segment 1 as a byte adjustment of the segment-0 address (arithmetic, so that the
+          // compiler keeps both bases in registers instead of indexing a stack array)
+          const bool seg1 = n >= a.in.C0;
+          const unsigned ro = __umul24((unsigned)(n - (seg1 ? a.in.C0 : 0)), (unsigned)a.Lin);
+          const long adj = seg1 ? pdelta + 4L * tk_d[k] : 0L;
+          const char* bp = reinterpret_cast<const char*>(a.in.p0) + adj;
+#pragma unroll
+          for (int r = 0; r < EPC; ++r)
+            ireg[k][c * EPC + r] = *reinterpret_cast<const float*>(
+                bp + (size_t)(unsigned)((ro + tk_base0[k][IN_HI ? r : 0]) << 2));
+        }
       }
     }
   };
-  auto store_in = [&](int cg) {
+  auto store_in = [&](int cg) __attribute__((always_inline)) {
 #pragma unroll
     for (int k = 0; k < MAXT; ++k) {
-      const int t = tid + 256 * k;
-      if (t >= 2 * RLs) continue;
-      const int g = t >= RLs ? 1 : 0;
-      const int j = t - g * RLs;
+      if (tid + 256 * k >= 2 * RLs) continue;
+      const int nb = (16 * cg + 8 * tk_g[k]) / EPC;
+      const int nval = Nreal - nb;            // channels c < nval exist
       bf16x8 pl[3];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int cv = 16 * cg + 8 * g + e;
-        const bool cvalid = cv < a.Cv;
-        const int n = IN_HI ? cv / S : cv;
-        const int r = IN_HI ? e % S : 0;
-        const ChanXf xf = segan_chan_xf(a.in, cvalid ? n : 0);
-        const bool ok = cvalid && ((tk_ok[k] >> r) & 1u);
-        const float v = ok ? segan_apply_xf(xf, ireg[k][e]) : 0.0f;
-        __bf16 p1, p2, p3;
-        split3(v, p1, p2, p3);
-        pl[0][e] = p1; pl[1][e] = p2; pl[2][e] = p3;
+      for (int c = 0; c < NRC; ++c) {
+        ChanXf xf;
+        if (!a.in_identity) {
+          if (XF_EARLY) xf = ixf[k][XF_EARLY ? c : 0];
+          else xf = segan_chan_xf(a.in, min(nb + c, Nreal - 1));
+        }
+#pragma unroll
+        for (int r = 0; r < EPC; ++r) {
+          const int e = c * EPC + r;
+          float v = ireg[k][e];
+          if (!a.in_identity) {
+            v = fmaf(v, xf.sc, xf.sh);
+            v = fmaf(xf.sl, fminf(v, 0.0f), fmaxf(v, 0.0f));
+          }
+          const bool ok = (c < nval) && ((tk_ok[k] >> (IN_HI ? r : 0)) & 1u);
+          v = ok ? v : 0.0f;
+          __bf16 p1, p2, p3;
+          split3(v, p1, p2, p3);
+          pl[0][e] = p1; pl[1][e] = p2; pl[2][e] = p3;
+        }
       }
 #pragma unroll
-      for (int p = 0; p < NPL; ++p) Il[(p * 2 + g) * RLs + j] = __builtin_bit_cast(u32x4, pl[p]);
+      for (int p = 0; p < NPL; ++p)
+        Il[(p * 2 + tk_g[k]) * RLs + tk_j[k]] = __builtin_bit_cast(u32x4, pl[p]);
     }
   };
 
@@ -530,9 +574,11 @@ static int prep(CorrArgs& a, hipStream_t st) {
   a.ncoltiles = ceil_div(a.Ctot, NB);
   a.RLs = NB + samples_per_tile(a.Tcols, NB) * a.H;
   a.prio_mode = 0;
+  a.in_identity = (!a.in.scale && !a.in.shift && !a.in.slope) ? 1 : 0;
   if (int e = segan_src_defaults(&a.in, st, "corr_bf")) return e;
-  if ((long)a.B * (a.in.C0 + a.in.C1) * a.Lin >= (1L << 31)) {
-    segan_set_error("corr_bf: input exceeds the 2^31 element indexing limit");
+  if ((long)a.B * (a.in.C0 + a.in.C1) * a.Lin >= (1L << 30) || a.Lin >= (1 << 24) ||
+      a.in.C0 + a.in.C1 >= (1 << 24)) {
+    segan_set_error("corr_bf: input exceeds the 2^30 element / 2^24 row indexing limits");
     return SEGAN_EUNSUPPORTED;
   }
   return SEGAN_OK;

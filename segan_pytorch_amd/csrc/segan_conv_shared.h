@@ -60,6 +60,7 @@ struct CorrArgs {
   int OC0, OC1, Lout, act;
   int o_padL, o_roll, o_padR;  // HI store (conv dgrad: reflect halo)
   int prio_mode;               // 0: none, 1: hashed static wave priority per workgroup
+  int in_identity;             // bf16 kernels: the input has no per-channel transform
   int sk_nfull;                // tiles processed whole (strided over the grid)
   int sk_units;                // stream-K part: (tile, chunk) units per workgroup
   long sk_total;               // stream-K part: total units of the remaining tiles

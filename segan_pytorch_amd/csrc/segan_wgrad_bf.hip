@@ -32,7 +32,8 @@ __host__ __device__ constexpr int wbf_pitch(int U, int PW) {
   return U == 8 ? ((PW + 7) / 16) * 16 + 8 : (U == 16 ? ((PW + 15) / 16) * 16 : PW + (PW & 1));
 }
 
-template <int U, int NPL, int TQ>
+// LO_ID / HI_ID: that operand has the identity transform (the gradient operand always has).
+template <int U, int NPL, int TQ, bool LO_ID, bool HI_ID>
 __global__ __launch_bounds__(256, 2) void wgrad_bf_kernel(const WgradArgs a) {
   constexpr int S = 32 / U;
   constexpr int MB = 128;
@@ -82,11 +83,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf_kernel(const WgradArgs a) {
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
   // ---- lo staging units: (row m, float4 f) -> 8 samples x 4 time positions ----
-  const float* a_ptr[NAU];
-  int a_cs[NAU];            // sample stride of the segment the row lives in
+  // addresses are segment-0 base (wave-uniform, SGPRs) + a 32-bit byte offset; rows of
+  // segment 1 carry the byte distance to it in a_adj (arithmetic select, no pointer array)
+  unsigned a_ro[NAU];       // row offset (elements) inside its segment
+  unsigned a_cs[NAU];       // sample stride of that segment
+  long a_adj[NAU];
   bool a_rok[NAU];
   ChanXf a_xf[NAU];
   int a_f[NAU], a_m[NAU];
+  const long lo_delta = a.lo.C1 > 0 ? reinterpret_cast<const char*>(a.lo.p1) -
+                                          reinterpret_cast<const char*>(a.lo.p0) : 0L;
+  const long hi_delta = a.hi.C1 > 0 ? reinterpret_cast<const char*>(a.hi.p1) -
+                                          reinterpret_cast<const char*>(a.hi.p0) : 0L;
 #pragma unroll
   for (int k = 0; k < NAU; ++k) {
     const int id = tid + 256 * k;
@@ -96,13 +104,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf_kernel(const WgradArgs a) {
     a_rok[k] = m < a.M;
     m = a_rok[k] ? m : 0;
     const bool s1 = m >= a.lo.C0;
-    a_ptr[k] = s1 ? a.lo.p1 + (size_t)(m - a.lo.C0) * Ls : a.lo.p0 + (size_t)m * Ls;
-    a_cs[k] = (s1 ? a.lo.C1 : a.lo.C0) * Ls;
+    a_ro[k] = (unsigned)(s1 ? m - a.lo.C0 : m) * (unsigned)Ls;
+    a_cs[k] = (unsigned)(s1 ? a.lo.C1 : a.lo.C0) * (unsigned)Ls;
+    a_adj[k] = s1 ? lo_delta : 0L;
     a_xf[k] = segan_chan_xf(a.lo, m);
   }
   // ---- hi staging units: (virtual channel, position) -> 8 samples ----
-  const float* b_ptr[NBU];
-  int b_cs[NBU], b_pos[NBU], b_r[NBU], b_cvl[NBU];
+  unsigned b_ro[NBU], b_cs[NBU];
+  long b_adj[NBU];
+  int b_pos[NBU], b_r[NBU], b_cvl[NBU];
   bool b_cok[NBU];
   ChanXf b_xf[NBU];
 #pragma unroll
@@ -118,8 +128,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf_kernel(const WgradArgs a) {
     b_cok[k] = uok && n < a.N;
     n = b_cok[k] ? n : 0;
     const bool s1 = n >= a.hi.C0;
-    b_ptr[k] = s1 ? a.hi.p1 + (size_t)(n - a.hi.C0) * a.Lhi : a.hi.p0 + (size_t)n * a.Lhi;
-    b_cs[k] = (s1 ? a.hi.C1 : a.hi.C0) * a.Lhi;
+    b_ro[k] = (unsigned)(s1 ? n - a.hi.C0 : n) * (unsigned)a.Lhi;
+    b_cs[k] = (unsigned)(s1 ? a.hi.C1 : a.hi.C0) * (unsigned)a.Lhi;
+    b_adj[k] = s1 ? hi_delta : 0L;
     b_xf[k] = segan_chan_xf(a.hi, n);
     if (!uok) { b_pos[k] = 0; b_cvl[k] = 0; }
   }
@@ -130,72 +141,114 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf_kernel(const WgradArgs a) {
   bool b_iok[NBU];
   int cur_b0 = 0;
 
-  auto load_chunk = [&](int c) {
+  // A chunk whose 8 samples all exist (every chunk but those of the last sample group) takes
+  // the fast path: no per-sample clamps or masks.  `full` is wave-uniform.
+  bool cur_full = true;
+  auto load_chunk = [&](int c) __attribute__((always_inline)) {
     const int sg = c / a.bf_qc;
     const int q0 = (c - sg * a.bf_qc) * TQ;
     const int b0 = 8 * sg;
     cur_b0 = b0;
+    cur_full = b0 + 8 <= a.B;
 #pragma unroll
     for (int k = 0; k < NAU; ++k) {
       const int q = q0 + 4 * a_f[k];
       a_qok[k] = q < Ls;
-      const int qq = a_qok[k] ? q : 0;
+      const unsigned o0 = a_ro[k] + (a_qok[k] ? q : 0) + (unsigned)b0 * a_cs[k];
+      const char* bp = reinterpret_cast<const char*>(a.lo.p0) + a_adj[k] + (size_t)(unsigned)(o0 << 2);
+      const size_t st = (size_t)a_cs[k] << 2;
+      if (cur_full) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int b = (b0 + e < a.B) ? b0 + e : 0;
-        areg[k][e] = *reinterpret_cast<const f32x4*>(a_ptr[k] + b * a_cs[k] + qq);
+        for (int e = 0; e < 8; ++e) areg[k][e] = *reinterpret_cast<const f32x4*>(bp + e * st);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          areg[k][e] = *reinterpret_cast<const f32x4*>(bp + ((b0 + e < a.B) ? e * st : 0));
       }
     }
 #pragma unroll
     for (int k = 0; k < NBU; ++k) {
       const int idx = segan_hi_index(S * (q0 + b_pos[k]) + b_r[k], a.Lhi, a.padL, a.mode, a.roll);
       b_iok[k] = idx >= 0;
-      const int ii = b_iok[k] ? idx : 0;
+      const unsigned o0 = b_ro[k] + (b_iok[k] ? idx : 0) + (unsigned)b0 * b_cs[k];
+      const char* bp = reinterpret_cast<const char*>(a.hi.p0) + b_adj[k] + (size_t)(unsigned)(o0 << 2);
+      const size_t st = (size_t)b_cs[k] << 2;
+      if (cur_full) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int b = (b0 + e < a.B) ? b0 + e : 0;
-        breg[k][e] = b_ptr[k][b * b_cs[k] + ii];
+        for (int e = 0; e < 8; ++e) breg[k][e] = *reinterpret_cast<const float*>(bp + e * st);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          breg[k][e] = *reinterpret_cast<const float*>(bp + ((b0 + e < a.B) ? e * st : 0));
       }
     }
   };
-  auto store_chunk = [&]() {
+  // 8 values -> NPL bf16 planes, ANDed with a lane mask (0 / ~0) so invalid rows / positions
+  // become zeros at 4 dword ops per piece instead of one select per element
+  auto to_planes = [&](const float (&v)[8], unsigned lm, u32x4 (&out)[3]) __attribute__((always_inline)) {
+    bf16x8 pl[3];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      __bf16 p1, p2, p3;
+      wsplit3(v[e], p1, p2, p3);
+      pl[0][e] = p1; pl[1][e] = p2; pl[2][e] = p3;
+    }
+#pragma unroll
+    for (int p = 0; p < NPL; ++p) {
+      out[p] = __builtin_bit_cast(u32x4, pl[p]);
+#pragma unroll
+      for (int d = 0; d < 4; ++d) out[p][d] &= lm;
+    }
+  };
+  auto store_chunk = [&]() __attribute__((always_inline)) {
     const int nvalid = a.B - cur_b0;   // samples e < nvalid exist
 #pragma unroll
     for (int k = 0; k < NAU; ++k) {
-      const bool ok = a_rok[k] && a_qok[k];
+      const unsigned lm = (a_rok[k] && a_qok[k]) ? 0xFFFFFFFFu : 0u;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        bf16x8 pl[3];
+        float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          float v = segan_apply_xf(a_xf[k], areg[k][e][i]);
-          v = (ok && e < nvalid) ? v : 0.0f;
-          __bf16 p1, p2, p3;
-          wsplit3(v, p1, p2, p3);
-          pl[0][e] = p1; pl[1][e] = p2; pl[2][e] = p3;
+          v[e] = areg[k][e][i];
+          if (!LO_ID) {
+            v[e] = fmaf(v[e], a_xf[k].sc, a_xf[k].sh);
+            v[e] = fmaf(a_xf[k].sl, fminf(v[e], 0.0f), fmaxf(v[e], 0.0f));
+          }
         }
+        if (!cur_full) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = e < nvalid ? v[e] : 0.0f;
+        }
+        u32x4 out[3];
+        to_planes(v, lm, out);
         const int q = 4 * a_f[k] + i;
         const int mm = a_m[k] ^ (a_f[k] * SWM);
 #pragma unroll
-        for (int p = 0; p < NPL; ++p) Al[(p * TQ + q) * MB + mm] = __builtin_bit_cast(u32x4, pl[p]);
+        for (int p = 0; p < NPL; ++p) Al[(p * TQ + q) * MB + mm] = out[p];
       }
     }
 #pragma unroll
     for (int k = 0; k < NBU; ++k) {
       if (tid + 256 * k >= CVW * PW) continue;
-      const bool ok = b_cok[k] && b_iok[k];
-      bf16x8 pl[3];
+      const unsigned lm = (b_cok[k] && b_iok[k]) ? 0xFFFFFFFFu : 0u;
+      float v[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        float v = segan_apply_xf(b_xf[k], breg[k][e]);
-        v = (ok && e < nvalid) ? v : 0.0f;
-        __bf16 p1, p2, p3;
-        wsplit3(v, p1, p2, p3);
-        pl[0][e] = p1; pl[1][e] = p2; pl[2][e] = p3;
+        v[e] = breg[k][e];
+        if (!HI_ID) {
+          v[e] = fmaf(v[e], b_xf[k].sc, b_xf[k].sh);
+          v[e] = fmaf(b_xf[k].sl, fminf(v[e], 0.0f), fmaxf(v[e], 0.0f));
+        }
       }
+      if (!cur_full) {
 #pragma unroll
-      for (int p = 0; p < NPL; ++p)
-        Bl[(p * CVW + b_cvl[k]) * QW + b_pos[k]] = __builtin_bit_cast(u32x4, pl[p]);
+        for (int e = 0; e < 8; ++e) v[e] = e < nvalid ? v[e] : 0.0f;
+      }
+      u32x4 out[3];
+      to_planes(v, lm, out);
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) Bl[(p * CVW + b_cvl[k]) * QW + b_pos[k]] = out[p];
     }
   };
 
@@ -263,8 +316,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf_kernel(const WgradArgs a) {
   }
 }
 
-template <int U, int NPL>
-static int launch_wgrad_bf(WgradArgs& a, hipStream_t st) {
+template <int U, int NPL, bool LO_ID, bool HI_ID>
+static int launch_wgrad_bf_x(WgradArgs& a, hipStream_t st) {
   constexpr int TQ = NPL == 3 ? 8 : 16;
   constexpr int CVW = 128 / U;
   constexpr int QW = wbf_pitch(U, TQ + U - 1);
@@ -272,8 +325,8 @@ static int launch_wgrad_bf(WgradArgs& a, hipStream_t st) {
     segan_set_error("wgrad_bf: low-rate length %d stays on the fp32 kernel", a.Ls);
     return SEGAN_EUNSUPPORTED;
   }
-  if ((long)a.B * a.M * a.Ls >= (1L << 31) || (long)a.B * a.N * a.Lhi >= (1L << 31)) {
-    segan_set_error("wgrad_bf: operand exceeds the 2^31 element indexing limit");
+  if ((long)a.B * a.M * a.Ls >= (1L << 30) || (long)a.B * a.N * a.Lhi >= (1L << 30)) {
+    segan_set_error("wgrad_bf: operand exceeds the 2^30 element indexing limit");
     return SEGAN_EUNSUPPORTED;
   }
   if (int e = segan_src_defaults(&a.lo, st, "wgrad(lo)")) return e;
@@ -290,7 +343,7 @@ static int launch_wgrad_bf(WgradArgs& a, hipStream_t st) {
   a.bf_cps = ceil_div(chunks, nsplit);
   nsplit = ceil_div(chunks, a.bf_cps);
   const size_t lds = (size_t)(NPL * TQ * 128 + NPL * CVW * QW) * 16;
-  auto kern = wgrad_bf_kernel<U, NPL, TQ>;
+  auto kern = wgrad_bf_kernel<U, NPL, TQ, LO_ID, HI_ID>;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -299,6 +352,16 @@ static int launch_wgrad_bf(WgradArgs& a, hipStream_t st) {
   }
   hipLaunchKernelGGL(kern, dim3(ncol, nrow, nsplit), dim3(256), lds, st, a);
   return segan_check_launch("wgrad_bf_kernel");
+}
+
+template <int U, int NPL>
+static int launch_wgrad_bf(WgradArgs& a, hipStream_t st) {
+  const bool lo_id = !a.lo.scale && !a.lo.shift && !a.lo.slope;
+  const bool hi_id = !a.hi.scale && !a.hi.shift && !a.hi.slope;
+  if (lo_id && hi_id) return launch_wgrad_bf_x<U, NPL, true, true>(a, st);
+  if (lo_id) return launch_wgrad_bf_x<U, NPL, true, false>(a, st);
+  if (hi_id) return launch_wgrad_bf_x<U, NPL, false, true>(a, st);
+  return launch_wgrad_bf_x<U, NPL, false, false>(a, st);
 }
 
 int segan_wgrad_bf(WgradArgs& a, int U, int planes, hipStream_t st) {
