@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SEGAN_ABI_VERSION 3
+#define SEGAN_ABI_VERSION 4
 
 #define SEGAN_PAD_REFLECT 0
 #define SEGAN_PAD_ZERO 1
@@ -110,9 +110,14 @@ int segan_conv1d_dgrad(const float* da, const void* wt, const float* w, float* d
  * deconv: lo = layer input x (with its transform), hi = dy, zero padding.
  * Accumulates (atomically) into dw, which is how torch accumulates .grad.
  * `precision`: SEGAN_PREC_*; the bf16 modes contract 8 samples per MFMA operand and return
- * -3 (SEGAN_EUNSUPPORTED) for Ls % 4 != 0 or very short rows: the caller falls back to fp32. */
+ * -3 (SEGAN_EUNSUPPORTED) for Ls % 4 != 0 or very short rows: the caller falls back to fp32.
+ * `scratch` (bf16 modes; may be NULL): segan_wgrad_scratch_bytes(...) bytes in which the lo
+ * operand is converted ONCE into bf16 planes laid out for the kernel (every column tile of dw
+ * re-reads it); without it the conversion happens inside the kernel. */
+size_t segan_wgrad_scratch_bytes(int B, int M, int Ls, int precision);
 int segan_wgrad(const segan_src* lo, const segan_src* hi, float* dw, int B, int M, int N, int Ls,
-                int K, int S, int padL, int mode, int roll, int precision, void* stream);
+                int K, int S, int padL, int mode, int roll, int precision, void* scratch,
+                void* stream);
 
 /* GDeconv1DBlock forward (modules.py:135-141): ConvTranspose1d(stride S, padding
  * `pad`) trimmed to S*Ls samples, + bias, optional tanh (last generator layer).

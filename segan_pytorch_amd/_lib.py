@@ -14,7 +14,7 @@ PAD_REFLECT = 0
 PAD_ZERO = 1
 ACT_NONE = 0
 ACT_TANH = 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class SeganSrc(Structure):
@@ -40,7 +40,8 @@ SIGNATURES = {
     'segan_conv1d_dgrad': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                    c_int, c_int, _P]),
     'segan_wgrad': (c_int, [_SRC, _SRC, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-                            c_int, c_int, _P]),
+                            c_int, c_int, _P, _P]),
+    'segan_wgrad_scratch_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
     'segan_deconv1d_fwd': (c_int, [_SRC, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                    c_int, c_int, _P]),
     'segan_deconv1d_dgrad': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,

@@ -1258,9 +1258,14 @@ extern "C" int segan_conv1d_dgrad(const float* da, const void* wt, const float* 
   return SEGAN_OK;
 }
 
+extern "C" size_t segan_wgrad_scratch_bytes(int B, int M, int Ls, int precision) {
+  if (precision == SEGAN_PREC_FP32 || B <= 0 || M <= 0 || Ls <= 0) return 0;
+  return segan_wgrad_bf_scratch_bytes(B, M, Ls, precision == SEGAN_PREC_BF16 ? 1 : 3);
+}
+
 extern "C" int segan_wgrad(const segan_src* lo, const segan_src* hi, float* dw, int B, int M, int N,
                            int Ls, int K, int S, int padL, int mode, int roll, int precision,
-                           void* stream) {
+                           void* scratch, void* stream) {
   SEGAN_REQUIRE(precision_ok(precision), "wgrad: bad precision %d", precision);
   SEGAN_REQUIRE(stride_ok(S), "wgrad: stride %d not in {1,2,4}", S);
   SEGAN_REQUIRE(K >= 1 && K <= 32, "wgrad: kernel width %d not in [1,32]", K);
@@ -1277,8 +1282,10 @@ extern "C" int segan_wgrad(const segan_src* lo, const segan_src* hi, float* dw, 
   a.Cv = N * S; a.padL = padL; a.mode = mode; a.roll = roll;
   a.Ctot = B * Ls;
   hipStream_t st = (hipStream_t)stream;
-  if (precision != SEGAN_PREC_FP32)
+  if (precision != SEGAN_PREC_FP32) {
+    a.lo_pk = scratch;
     return segan_wgrad_bf(a, 32 / S, precision == SEGAN_PREC_BF16 ? 1 : 3, st);
+  }
   switch (S) {
     case 4: return launch_wgrad_t<8>(a, st);
     case 2: return launch_wgrad_t<16>(a, st);

@@ -95,6 +95,9 @@ struct WgradArgs {
   int prio_mode;
   int bf_qc;              // bf16 kernel: time chunks per sample group
   int bf_cps;             // bf16 kernel: chunks per workgroup (split of the contraction)
+  void* lo_pk;            // bf16 kernel: scratch for the pre-packed lo operand (or NULL)
+  size_t lo_pk_plane;     // bytes between its planes
+  int Mp;                 // its row pitch (M rounded up to 128)
 };
 
 // split-bf16 entry points (segan_conv_bf.hip); `a` is filled exactly as for the fp32 kernels
@@ -102,3 +105,4 @@ int segan_corr_bf_f(CorrArgs& a, int U, const void* wp3, int planes, hipStream_t
 int segan_corr_bf_t(CorrArgs& a, int U, const void* wp3, int planes, hipStream_t st);
 // wgrad on the bf16 matrix cores (segan_wgrad_bf.hip); planes = 1 (bf16) or 3 (bf16x3)
 int segan_wgrad_bf(WgradArgs& a, int U, int planes, hipStream_t st);
+size_t segan_wgrad_bf_scratch_bytes(int B, int M, int Ls, int planes);

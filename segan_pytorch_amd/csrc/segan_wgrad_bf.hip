@@ -32,8 +32,10 @@ __host__ __device__ constexpr int wbf_pitch(int U, int PW) {
   return U == 8 ? ((PW + 7) / 16) * 16 + 8 : (U == 16 ? ((PW + 15) / 16) * 16 : PW + (PW & 1));
 }
 
-// LO_ID / HI_ID: that operand has the identity transform (the gradient operand always has).
-template <int U, int NPL, int TQ, bool LO_ID, bool HI_ID>
+// LO_MODE: 0 = lo converted in the kernel with its transform, 1 = same, identity transform,
+// 2 = lo pre-packed by wgrad_pack_lo_kernel (bf16 planes, [sample group][time][row][8]).
+// HI_ID: hi has the identity transform (the gradient operand always has).
+template <int U, int NPL, int TQ, int LO_MODE, bool HI_ID>
 __global__ __launch_bounds__(256, 2) void wgrad_bf_kernel(const WgradArgs a) {
   constexpr int S = 32 / U;
   constexpr int MB = 128;
@@ -43,7 +45,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf_kernel(const WgradArgs a) {
   constexpr int F4 = TQ / 4;           // float4 loads per lo row and chunk
   constexpr int NAU = (MB * F4) / 256; // lo units per thread
   constexpr int NBU = (CVW * PW + 255) / 256;
-  constexpr int SWM = 8 / F4;          // swizzle step
+  constexpr int SWM = LO_MODE == 2 ? 0 : 8 / F4;   // swizzle step (packed lo is written row-linear)
+  constexpr bool LO_ID = LO_MODE == 1;
+  constexpr bool LO_PK = LO_MODE == 2;
+  constexpr int NPP = (TQ * MB) / 256;  // packed lo: 16-B pieces per thread and plane
   static_assert(QW >= PW, "pitch");
   static_assert(NAU >= 1, "TQ >= 8");
 
@@ -135,7 +140,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf_kernel(const WgradArgs a) {
     if (!uok) { b_pos[k] = 0; b_cvl[k] = 0; }
   }
 
-  f32x4 areg[NAU][8];
+  f32x4 areg[LO_PK ? 1 : NAU][LO_PK ? 1 : 8];
+  u32x4 apk[LO_PK ? NPL : 1][LO_PK ? NPP : 1];
+  unsigned apk_ok = 0u;
   float breg[NBU][8];
   bool a_qok[NAU];
   bool b_iok[NBU];
@@ -150,8 +157,27 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf_kernel(const WgradArgs a) {
     const int b0 = 8 * sg;
     cur_b0 = b0;
     cur_full = b0 + 8 <= a.B;
+    if (LO_PK) {
+      // piece id = tid + 256*i -> (time q = id / MB, row m = id % MB): 64 consecutive rows per
+      // wave instruction = 1 KB contiguous
+      const char* base = reinterpret_cast<const char*>(a.lo_pk) +
+                         ((size_t)sg * Ls * a.Mp + m0) * 16;
+      apk_ok = 0u;
 #pragma unroll
-    for (int k = 0; k < NAU; ++k) {
+      for (int i = 0; i < NPP; ++i) {
+        const int id = tid + 256 * i;
+        const int q = q0 + id / MB;
+        const bool ok = q < Ls;
+        if (ok) apk_ok |= 1u << i;
+        const size_t off = ((size_t)(ok ? q : 0) * a.Mp + id % MB) * 16;
+#pragma unroll
+        for (int p = 0; p < NPL; ++p)
+          apk[LO_PK ? p : 0][LO_PK ? i : 0] =
+              *reinterpret_cast<const u32x4*>(base + p * a.lo_pk_plane + off);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < (LO_PK ? 0 : NAU); ++k) {
       const int q = q0 + 4 * a_f[k];
       a_qok[k] = q < Ls;
       const unsigned o0 = a_ro[k] + (a_qok[k] ? q : 0) + (unsigned)b0 * a_cs[k];
@@ -202,8 +228,22 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf_kernel(const WgradArgs a) {
   };
   auto store_chunk = [&]() __attribute__((always_inline)) {
     const int nvalid = a.B - cur_b0;   // samples e < nvalid exist
+    if (LO_PK) {
 #pragma unroll
-    for (int k = 0; k < NAU; ++k) {
+      for (int i = 0; i < NPP; ++i) {
+        const int id = tid + 256 * i;
+        const unsigned lm = ((apk_ok >> i) & 1u) ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) {
+          u32x4 v = apk[LO_PK ? p : 0][LO_PK ? i : 0];
+#pragma unroll
+          for (int d = 0; d < 4; ++d) v[d] &= lm;
+          Al[(p * TQ + id / MB) * MB + id % MB] = v;
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < (LO_PK ? 0 : NAU); ++k) {
       const unsigned lm = (a_rok[k] && a_qok[k]) ? 0xFFFFFFFFu : 0u;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -262,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf_kernel(const WgradArgs a) {
     for (int kk = 0; kk < TQ / 2; ++kk) {
       // lane half h contracts time position q = kk + h*TQ/2; its rows sit at m ^ swz(q)
       const int qa = kk + h * (TQ / 2);
-      const int sw = ((qa >> 2) % F4) * SWM;
+      const int sw = LO_PK ? 0 : ((qa >> 2) % F4) * SWM;
       bf16x8 af[2][NPL], bf[2][NPL];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -316,7 +356,70 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf_kernel(const WgradArgs a) {
   }
 }
 
-template <int U, int NPL, bool LO_ID, bool HI_ID>
+
+// ====================================================================================
+// lo pre-pack: fp32 lo[b][m][t] (with its transform) -> bf16 planes [p][sg][t][Mp][8 samples].
+// Every column tile of the weight gradient re-reads the lo operand (N*S*U/128 = 32..256
+// times), so it is converted ONCE here: the hot kernel then streams 16-byte pieces in full
+// lines (2 B/element instead of 4) and spends no VALU on it.  Tile 64 time steps x 16 rows
+// through LDS so that both the reads (256 B per row run) and the writes (256 B per time step)
+// are coalesced.
+// ====================================================================================
+template <int NPL>
+__global__ __launch_bounds__(256) void wgrad_pack_lo_kernel(const segan_src lo, __bf16* __restrict__ out,
+                                                            size_t plane_elems, int B, int M, int Mp,
+                                                            int Ls, int identity) {
+  __shared__ u32x4 tile[NPL][16][65];
+  const int tid = threadIdx.x;
+  const int q0 = blockIdx.x * 64, m0 = blockIdx.y * 16, sg = blockIdx.z;
+  {
+    const int ql = tid & 63;
+    const int q = q0 + ql;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const int ml = (tid >> 6) + 4 * pass;
+      const int m = m0 + ml;
+      const bool ok = m < M && q < Ls;
+      const int mc = ok ? m : 0;
+      const bool s1 = mc >= lo.C0;
+      const float* row = s1 ? lo.p1 + (size_t)(mc - lo.C0) * Ls : lo.p0 + (size_t)mc * Ls;
+      const size_t cs = (size_t)(s1 ? lo.C1 : lo.C0) * Ls;
+      const ChanXf xf = segan_chan_xf(lo, mc);
+      bf16x8 pl[3];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int b = 8 * sg + e;
+        float v = row[(size_t)(b < B ? b : 0) * cs + (ok ? q : 0)];
+        if (!identity) {
+          v = fmaf(v, xf.sc, xf.sh);
+          v = fmaf(xf.sl, fminf(v, 0.0f), fmaxf(v, 0.0f));
+        }
+        v = (ok && b < B) ? v : 0.0f;
+        __bf16 p1, p2, p3;
+        wsplit3(v, p1, p2, p3);
+        pl[0][e] = p1; pl[1][e] = p2; pl[2][e] = p3;
+      }
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) tile[p][ml][ql] = __builtin_bit_cast(u32x4, pl[p]);
+    }
+  }
+  __syncthreads();
+  {
+    const int mw = tid & 15;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const int qw = (tid >> 4) + 16 * pass;
+      const int q = q0 + qw;
+      if (q >= Ls) continue;
+      const size_t piece = ((size_t)sg * Ls + q) * Mp + m0 + mw;
+#pragma unroll
+      for (int p = 0; p < NPL; ++p)
+        *reinterpret_cast<u32x4*>(out + p * plane_elems + piece * 8) = tile[p][mw][qw];
+    }
+  }
+}
+
+template <int U, int NPL, int LO_MODE, bool HI_ID>
 static int launch_wgrad_bf_x(WgradArgs& a, hipStream_t st) {
   constexpr int TQ = NPL == 3 ? 8 : 16;
   constexpr int CVW = 128 / U;
@@ -329,8 +432,19 @@ static int launch_wgrad_bf_x(WgradArgs& a, hipStream_t st) {
     segan_set_error("wgrad_bf: operand exceeds the 2^30 element indexing limit");
     return SEGAN_EUNSUPPORTED;
   }
+  const bool lo_identity = !a.lo.scale && !a.lo.shift && !a.lo.slope;
   if (int e = segan_src_defaults(&a.lo, st, "wgrad(lo)")) return e;
   if (int e = segan_src_defaults(&a.hi, st, "wgrad(hi)")) return e;
+  if (LO_MODE == 2) {
+    a.Mp = round_up(a.M, 128);
+    const int SG = ceil_div(a.B, 8);
+    const size_t plane_elems = (size_t)SG * a.Ls * a.Mp * 8;
+    a.lo_pk_plane = plane_elems * sizeof(__bf16);
+    hipLaunchKernelGGL((wgrad_pack_lo_kernel<NPL>), dim3(ceil_div(a.Ls, 64), a.Mp / 16, SG), dim3(256),
+                       0, st, a.lo, reinterpret_cast<__bf16*>(a.lo_pk), plane_elems, a.B, a.M, a.Mp,
+                       a.Ls, lo_identity ? 1 : 0);
+    if (int e = segan_check_launch("wgrad_pack_lo_kernel")) return e;
+  }
   a.bf_qc = ceil_div(a.Ls, TQ);
   const int chunks = ceil_div(a.B, 8) * a.bf_qc;
   const int ncol = ceil_div(a.Cv, CVW);
@@ -343,7 +457,7 @@ static int launch_wgrad_bf_x(WgradArgs& a, hipStream_t st) {
   a.bf_cps = ceil_div(chunks, nsplit);
   nsplit = ceil_div(chunks, a.bf_cps);
   const size_t lds = (size_t)(NPL * TQ * 128 + NPL * CVW * QW) * 16;
-  auto kern = wgrad_bf_kernel<U, NPL, TQ, LO_ID, HI_ID>;
+  auto kern = wgrad_bf_kernel<U, NPL, TQ, LO_MODE, HI_ID>;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -358,10 +472,16 @@ template <int U, int NPL>
 static int launch_wgrad_bf(WgradArgs& a, hipStream_t st) {
   const bool lo_id = !a.lo.scale && !a.lo.shift && !a.lo.slope;
   const bool hi_id = !a.hi.scale && !a.hi.shift && !a.hi.slope;
-  if (lo_id && hi_id) return launch_wgrad_bf_x<U, NPL, true, true>(a, st);
-  if (lo_id) return launch_wgrad_bf_x<U, NPL, true, false>(a, st);
-  if (hi_id) return launch_wgrad_bf_x<U, NPL, false, true>(a, st);
-  return launch_wgrad_bf_x<U, NPL, false, false>(a, st);
+  if (a.lo_pk != nullptr)
+    return hi_id ? launch_wgrad_bf_x<U, NPL, 2, true>(a, st) : launch_wgrad_bf_x<U, NPL, 2, false>(a, st);
+  if (lo_id && hi_id) return launch_wgrad_bf_x<U, NPL, 1, true>(a, st);
+  if (lo_id) return launch_wgrad_bf_x<U, NPL, 1, false>(a, st);
+  if (hi_id) return launch_wgrad_bf_x<U, NPL, 0, true>(a, st);
+  return launch_wgrad_bf_x<U, NPL, 0, false>(a, st);
+}
+
+size_t segan_wgrad_bf_scratch_bytes(int B, int M, int Ls, int planes) {
+  return (size_t)planes * ceil_div(B, 8) * Ls * round_up(M, 128) * 8 * sizeof(__bf16);
 }
 
 int segan_wgrad_bf(WgradArgs& a, int U, int planes, hipStream_t st) {

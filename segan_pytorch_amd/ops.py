@@ -20,6 +20,9 @@ PREC_FP32, PREC_BF16, PREC_BF16X3 = 0, 1, 3
 _PREC_NAMES = {'fp32': PREC_FP32, 'bf16': PREC_BF16, 'bf16x3': PREC_BF16X3}
 _precision = _PREC_NAMES[_os.environ.get('SEGAN_PRECISION', 'fp32')]
 _EUNSUPPORTED = -3
+# bf16 modes: convert the lo operand of the weight gradients once per call into a scratch
+# buffer (SEGAN_WGRAD_PACK=0 keeps the conversion inside the kernel; for A/B measurements)
+_WGRAD_PACK = _os.environ.get('SEGAN_WGRAD_PACK', '1') != '0'
 
 
 def set_precision(mode):
@@ -261,13 +264,17 @@ def wgrad(lo, hi, dw, K, S, padL, pad_mode, roll=0):
     cl, ch = lo.c_struct(), hi.c_struct()
     lib = _lib.load()
     if _precision != PREC_FP32:
+        nbytes = lib.segan_wgrad_scratch_bytes(lo.B, M, lo.L, _precision)
+        scratch = torch.empty(nbytes, device=dw.device, dtype=torch.uint8) if _WGRAD_PACK else None
         rc = lib.segan_wgrad(ctypes.byref(cl), ctypes.byref(ch), _ptr(dw), lo.B, M, N, lo.L, K, S,
-                             padL, pad_mode, roll, _precision, _stream())
+                             padL, pad_mode, roll, _precision,
+                             ctypes.c_void_p(scratch.data_ptr()) if scratch is not None else None,
+                             _stream())
         if rc != -3:
             check(rc, 'wgrad')
             return
     check(lib.segan_wgrad(ctypes.byref(cl), ctypes.byref(ch), _ptr(dw), lo.B, M, N, lo.L, K, S, padL,
-                          pad_mode, roll, PREC_FP32, _stream()), 'wgrad')
+                          pad_mode, roll, PREC_FP32, None, _stream()), 'wgrad')
 
 
 def deconv1d_fwd(src, w, bias, S, act=ACT_NONE, pack=None):
