@@ -13,6 +13,23 @@ import torch
 import torch.nn as nn
 
 
+def convert_legacy_generator_keys(state_dict):
+    """Old SEGAN-G checkpoints name the blocks gen_enc.i.conv.* / gen_dec.i.conv.*; the
+    reference ships weightG_fmt_converter.py:18-44 to rewrite them offline.  Done on the fly
+    here so such a checkpoint loads directly: gen_enc -> enc_blocks, gen_dec -> dec_blocks
+    with conv -> deconv.  Current-format dicts pass through unchanged."""
+    if not any(('gen_enc' in k or 'gen_dec' in k) for k in state_dict):
+        return state_dict
+    out = type(state_dict)()
+    for k, v in state_dict.items():
+        if 'gen_enc' in k:
+            k = k.replace('gen_enc', 'enc_blocks')
+        elif 'gen_dec' in k:
+            k = k.replace('gen_dec', 'dec_blocks').replace('conv', 'deconv')
+        out[k] = v
+    return out
+
+
 class Saver(object):
 
     def __init__(self, model, save_path, max_ckpts=5, optimizer=None, prefix=''):
@@ -82,6 +99,7 @@ class Saver(object):
         model_dict = self.model.state_dict()
         st = torch.load(ckpt_file, map_location='cpu')
         pt_dict = st['state_dict'] if 'state_dict' in st else st
+        pt_dict = convert_legacy_generator_keys(pt_dict)
         keys = list(pt_dict.keys())
         allowed = keys[:] if load_last else keys[:-2]     # core.py:131-135
         pt_dict = {k: v for k, v in pt_dict.items()

@@ -245,3 +245,25 @@ def test_bce_cost():
     lr = F.binary_cross_entropy_with_logits(dd.view(-1), torch.ones(7, dtype=torch.float64))
     (0.5 * lr).backward()
     assert abs(l.item() - lr.item()) < 1e-6 and max_rel(d.grad, dd.grad) < 1e-5
+
+
+def test_legacy_generator_checkpoint_loads(tiny_step, tmp_path):
+    """A checkpoint with the old gen_enc / gen_dec key names (what weightG_fmt_converter.py
+    rewrites offline in the reference) loads directly through load_pretrained."""
+    from segan_pytorch_amd.models.core import convert_legacy_generator_keys
+    fx = tiny_step
+    m = build(fx)
+    legacy = {}
+    for k, v in fx['G0'].items():
+        if k.startswith('enc_blocks'):
+            k = k.replace('enc_blocks', 'gen_enc')
+        elif k.startswith('dec_blocks'):
+            k = k.replace('dec_blocks', 'gen_dec').replace('deconv', 'conv')
+        legacy[k] = v + 0.5
+    assert any('gen_dec' in k for k in legacy)
+    assert set(convert_legacy_generator_keys(legacy).keys()) == set(fx['G0'].keys())
+    path = str(tmp_path / 'old_G.ckpt')
+    torch.save({'state_dict': legacy}, path)
+    m.G.load_pretrained(path, load_last=True)
+    for k, v in m.G.state_dict().items():
+        assert torch.equal(v.cpu(), fx['G0'][k] + 0.5), k
