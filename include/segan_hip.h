@@ -213,6 +213,21 @@ int segan_l1_mean(const float* x, const float* y, float* loss, float* ws, int64_
 int segan_l1_bwd(const float* x, const float* y, const float* gout, float gscale, float* grad,
                  int64_t n, void* stream);
 
+/* ---- spectral normalisation ('snorm', modules.py:12-14, discriminator.py:118-121) -------
+ * torch.nn.utils.spectral_norm with its defaults (one power iteration in training mode,
+ * eps 1e-12) on a weight [A][Bd][K] viewed as a matrix with rows = dim 0 (Conv1d, Linear,
+ * PReLU) or dim 1 (ConvTranspose1d):
+ *   power_iteration != 0:  v <- normalize(W^T u), u <- normalize(W v)   (u, v updated in place)
+ *   sigma[0] = u . (W v);  w_sn = w / sigma
+ * ws: scratch of segan_snorm_ws_floats(...) floats (shared by fwd and bwd). */
+size_t segan_snorm_ws_floats(int A, int Bd, int K, int dim);
+int segan_snorm_fwd(const float* w, float* u, float* v, float* w_sn, float* sigma, float* ws, int A,
+                    int Bd, int K, int dim, int power_iteration, float eps, void* stream);
+/* dw += dw_sn/sigma - (<dw_sn, w>/sigma^2) u v^T   (u, v: the vectors the forward used) */
+int segan_snorm_bwd(const float* dw_sn, const float* w, const float* u, const float* v,
+                    const float* sigma, float* dw, float* ws, int A, int Bd, int K, int dim,
+                    void* stream);
+
 /* ---- STFT power loss of the WSEGAN step (model.py:640-653) ------------------------------
  * torch.stft(x, n_fft, hop_length=hop, win_length=win, normalized=True) with window=None:
  * a rectangular window zero-padded to n_fft, centre (reflect) padding of n_fft/2.  Only `win`

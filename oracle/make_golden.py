@@ -117,10 +117,47 @@ def checksum(t):
             'n': t.numel(), 'sample_idx': idx, 'sample': t[idx].float().clone()}
 
 
+def make_snorm(ref):
+    """tiny_snorm.pt: (1) one SEGAN step with --dnorm_type snorm (spectral norm on D's convs,
+    on fc[0], fc[2] and — as discriminator.py:118-121 literally does — on the PReLU fc[3]);
+    the three D forwards each run one power iteration, so D_after also pins the u/v buffers.
+    (2) a Generator built with norm_type='snorm' (generator.py:94,126,168; not reachable from
+    train.py, which never forwards --gnorm_type): output and gradients of a linear loss."""
+    o = tiny_opts()
+    o['dnorm_type'] = 'snorm'
+    seed_all(111)
+    segan = ref.SEGAN(SimpleNamespace(**o))
+    clean, noisy = synth(3, 1024, 10)
+    clean, noisy = clean.unsqueeze(1), noisy.unsqueeze(1)
+    z = torch.randn(3, 32, 16, generator=torch.Generator().manual_seed(11))
+    fx = {'opts': o, 'G0': clone_sd(segan.G), 'D0': clone_sd(segan.D), 'clean': clean,
+          'noisy': noisy, 'z': z, 'roll_seed': 13,
+          'rolls': ref_harness.ReplayRandom(13).rolls(3, o['phase_shift'], 3)}
+    fx.update(manual_step(ref, segan, clean, noisy, z, 13))
+    seed_all(5)
+    G = ref.Generator(1, [8, 16, 32], 31, [4, 4, 4], z_dim=32, skip_merge='concat', bias=True,
+                      norm_type='snorm')
+    G.train()
+    g0 = clone_sd(G)
+    gen = torch.Generator().manual_seed(12)
+    x = torch.rand(2, 1, 1024, generator=gen) * 2 - 1
+    zz = torch.randn(2, 32, 16, generator=gen)
+    c = torch.randn(2, 1, 1024, generator=gen)
+    y = G(x, z=zz)
+    (y * c).sum().backward()
+    fx['gsn'] = {'G0': g0, 'x': x, 'z': zz, 'c': c, 'y': y.detach().clone(),
+                 'grads': grads_of(G), 'G_after_fwd': clone_sd(G)}
+    torch.save(fx, os.path.join(OUT, 'tiny_snorm.pt'))
+    print('tiny_snorm.pt done', sorted(k for k in fx['D0'] if 'fc.3' in k or 'enc_blocks.0.conv' in k))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = ref_harness.import_reference()
     torch.set_num_threads(max(1, os.cpu_count() or 1))
+    if len(sys.argv) > 1 and sys.argv[1] == 'snorm':     # only the spectral-norm fixture
+        make_snorm(ref)
+        return
 
     # ---------------- tiny_step ----------------
     o = tiny_opts()
@@ -238,6 +275,7 @@ def main():
     fx4['D_after'] = {k: checksum(v) for k, v in res['D_after'].items()}
     torch.save(fx4, os.path.join(OUT, 'segan_plus_b2.pt'))
     print('segan_plus_b2.pt done', res['Genh'].shape, res['g_l1_loss'])
+    make_snorm(ref)
 
 
 if __name__ == '__main__':

@@ -12,6 +12,8 @@ it can be fed the weights of the reference modules or of the HIP modules alike:
 * ``generator_forward``  segan/models/generator.py:180-230 (+ GSkip.forward 64-78)
 * ``roll``               segan/models/discriminator.py:160-172 (phase shift)
 * ``discriminator_forward`` segan/models/discriminator.py:150-194
+* ``spectral_weight``    torch.nn.utils.spectral_norm as used by modules.py:12-14 and
+                         discriminator.py:118-121 ('snorm')
 * ``gan_step``           segan/models/model.py:292-321 with nn.MSELoss (train.py:94),
                          F.l1_loss (model.py:79) and optim.RMSprop (model.py:221-222)
 
@@ -64,15 +66,46 @@ def gdeconv_block(x, w, b, slope, stride, tanh=False):
     return torch.tanh(h) if tanh else F.prelu(h, slope)
 
 
+def spectral_weight(sd, prefix, dim=0, training=True, eps=1e-12):
+    """The weight torch.nn.utils.spectral_norm hands to the layer ('snorm': modules.py:12-14,
+    discriminator.py:118-121), restated from its documented algorithm (torch is a third-party
+    dependency of the reference): W_mat = weight_orig with `dim` first, flattened to 2-D;
+    in training mode ONE power iteration under no_grad, in place on the u / v buffers,
+        v <- normalize(W_mat^T u),  u <- normalize(W_mat v)      (eps 1e-12)
+    then sigma = u . (W_mat v) with u, v treated as constants, weight = weight_orig / sigma.
+    `sd[prefix + 'weight_u' / 'weight_v']` are updated in place like the module's buffers."""
+    w = sd[prefix + 'weight_orig']
+    u, v = sd[prefix + 'weight_u'], sd[prefix + 'weight_v']
+    wm = w
+    if dim != 0:
+        wm = w.permute(dim, *[d for d in range(w.dim()) if d != dim])
+    wm = wm.reshape(wm.size(0), -1)
+    if training:
+        with torch.no_grad():
+            v.copy_(F.normalize(torch.mv(wm.t(), u), dim=0, eps=eps))
+            u.copy_(F.normalize(torch.mv(wm, v), dim=0, eps=eps))
+    sigma = torch.dot(u.clone(), torch.mv(wm, v.clone()))
+    return w / sigma
+
+
+def _weight(sd, prefix, dim=0, training=True):
+    """`prefix`weight, or its spectrally normalised form when the layer carries
+    weight_orig / weight_u / weight_v."""
+    if prefix + 'weight_orig' in sd:
+        return spectral_weight(sd, prefix, dim, training)
+    return sd[prefix + 'weight']
+
+
 def _count(sd, prefix):
     n = 0
     while '{}.{}.act.weight'.format(prefix, n) in sd or \
-            '{}.{}.deconv.weight'.format(prefix, n) in sd:
+            '{}.{}.deconv.weight'.format(prefix, n) in sd or \
+            '{}.{}.deconv.weight_orig'.format(prefix, n) in sd:
         n += 1
     return n
 
 
-def generator_forward(sd, x, z, strides, dec_strides=None, ret_hid=False):
+def generator_forward(sd, x, z, strides, dec_strides=None, ret_hid=False, training=True):
     """generator.py:180-230 with skip_type alpha, skip_merge concat."""
     n_enc = _count(sd, 'enc_blocks')
     n_dec = _count(sd, 'dec_blocks')
@@ -82,7 +115,7 @@ def generator_forward(sd, x, z, strides, dec_strides=None, ret_hid=False):
     skips = {}
     for l in range(n_enc):
         p = 'enc_blocks.{}.'.format(l)
-        hi, lin = gconv_block(hi, sd[p + 'conv.weight'], sd.get(p + 'conv.bias'),
+        hi, lin = gconv_block(hi, _weight(sd, p + 'conv.', 0, training), sd.get(p + 'conv.bias'),
                               sd[p + 'act.weight'], strides[l])
         if l < n_enc - 1 and 'alpha_{}.skip_k'.format(l) in sd:
             skips[l] = lin                       # the PRE-activation (generator.py:185,191)
@@ -98,7 +131,7 @@ def generator_forward(sd, x, z, strides, dec_strides=None, ret_hid=False):
             hi = torch.cat((hi, sk), dim=1)      # GSkip concat, generator.py:64-76
         p = 'dec_blocks.{}.'.format(l)
         last = (p + 'act.weight') not in sd
-        hi = gdeconv_block(hi, sd[p + 'deconv.weight'], sd[p + 'deconv.bias'],
+        hi = gdeconv_block(hi, _weight(sd, p + 'deconv.', 1, training), sd[p + 'deconv.bias'],
                            sd.get(p + 'act.weight'), dec_strides[l], tanh=last)
         enc_idx -= 1
         hall['dec_{}'.format(l)] = hi
@@ -119,18 +152,20 @@ def discriminator_forward(sd, x, rolls, strides, training=True, ret_act=False):
             bn = {'weight': sd[p + 'norm.weight'], 'bias': sd[p + 'norm.bias'],
                   'running_mean': sd[p + 'norm.running_mean'],
                   'running_var': sd[p + 'norm.running_var']}
-        h, _ = gconv_block(h, sd[p + 'conv.weight'], sd.get(p + 'conv.bias'),
+        h, _ = gconv_block(h, _weight(sd, p + 'conv.', 0, training), sd.get(p + 'conv.bias'),
                            sd[p + 'act.weight'], strides[l], bn=bn, training=training)
         acts['h_{}'.format(l)] = h
     h = h.view(h.size(0), -1)
-    h = F.prelu(F.linear(h, sd['fc.0.weight'], sd['fc.0.bias']), sd['fc.1.weight'])
-    h = F.prelu(F.linear(h, sd['fc.2.weight'], sd['fc.2.bias']), sd['fc.3.weight'])
-    y = F.linear(h, sd['fc.4.weight'], sd['fc.4.bias'])
+    h = F.prelu(F.linear(h, _weight(sd, 'fc.0.', 0, training), sd['fc.0.bias']),
+                _weight(sd, 'fc.1.', 0, training))
+    h = F.prelu(F.linear(h, _weight(sd, 'fc.2.', 0, training), sd['fc.2.bias']),
+                _weight(sd, 'fc.3.', 0, training))
+    y = F.linear(h, _weight(sd, 'fc.4.', 0, training), sd['fc.4.bias'])
     acts['logit'] = y
     return (y, acts) if ret_act else y
 
 
-_BUFFERS = ('running_mean', 'running_var', 'num_batches_tracked')
+_BUFFERS = ('running_mean', 'running_var', 'num_batches_tracked', 'weight_u', 'weight_v')
 
 
 def _leafs(sd):

@@ -61,6 +61,9 @@ SIGNATURES = {
     'segan_mse_const': (c_int, [_P, c_float, _P, _P, _P, c_float, c_int, _P]),
     'segan_l1_bwd': (c_int, [_P, _P, _P, c_float, _P, c_int64, _P]),
     'segan_l1_mean': (c_int, [_P, _P, _P, _P, c_int64, _P]),
+    'segan_snorm_ws_floats': (c_size_t, [c_int, c_int, c_int, c_int]),
+    'segan_snorm_fwd': (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, _P]),
+    'segan_snorm_bwd': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     'segan_pcm16_prep': (c_int, [_P, _P, _P, _P, c_int, c_int, c_double, _P]),
     'segan_stft_basis': (c_int, [_P, c_int, c_int, _P]),
     'segan_stft_frames': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),

@@ -76,6 +76,65 @@ def _cat(a, b):
 
 
 # =====================================================================================
+# effective weights (spectral normalisation)
+# =====================================================================================
+import itertools as _it
+
+_sn_epoch = _it.count(1 << 40)
+
+
+def _is_sn(mod):
+    return hasattr(mod, 'weight_orig')
+
+
+class _Weights(object):
+    """Effective weights of ONE forward call.  For a plain parameter container (the nn.Conv1d /
+    nn.ConvTranspose1d / nn.Linear / nn.PReLU children) that is its ``.weight``.  For a
+    spectrally-normalised one (``torch.nn.utils.spectral_norm`` registration: ``weight_orig``
+    parameter, ``weight_u`` / ``weight_v`` buffers; modules.py:12-14, discriminator.py:118-121)
+    it is ``weight_orig / sigma``, computed by ``ops.snorm_fwd`` with the power iteration of
+    training mode (u, v updated in place, as torch does under no_grad) and remembered with the
+    (u, v, sigma) it used, so the backward of THIS call differentiates through exactly that
+    normalisation even when D runs several forwards before one backward (model.py:577-631)."""
+
+    def __init__(self):
+        self._sn = {}
+
+    def get(self, mod):
+        if not _is_sn(mod):
+            return mod.weight
+        st = self._sn.get(id(mod))
+        if st is None:
+            dim = 1 if isinstance(mod, torch.nn.ConvTranspose1d) else 0
+            w_sn, sigma = ops.snorm_fwd(mod.weight_orig.detach(), mod.weight_u, mod.weight_v, dim,
+                                        mod.training)
+            w_sn._segan_epoch = next(_sn_epoch)      # never aliases a cached weight pack
+            st = (w_sn, mod.weight_u.clone(), mod.weight_v.clone(), sigma, dim)
+            self._sn[id(mod)] = st
+        return st[0]
+
+    @staticmethod
+    def param(mod):
+        return mod.weight_orig if _is_sn(mod) else mod.weight
+
+    def needs_grad(self, mod):
+        return self.param(mod).requires_grad
+
+    def grad_target(self, mod):
+        """Buffer the weight-gradient kernel accumulates into: the parameter's .grad, or for a
+        normalised weight a zeroed temporary that `finish` folds into weight_orig.grad."""
+        if not _is_sn(mod):
+            return grad_buf(mod.weight)
+        return torch.zeros_like(self._sn[id(mod)][0])
+
+    def finish(self, mod, tmp):
+        if not _is_sn(mod):
+            return
+        w_sn, u, v, sigma, dim = self._sn[id(mod)]
+        ops.snorm_bwd(tmp, mod.weight_orig.detach(), u, v, sigma, dim, grad_buf(mod.weight_orig))
+
+
+# =====================================================================================
 # Generator
 # =====================================================================================
 class GeneratorFn(torch.autograd.Function):
@@ -88,8 +147,9 @@ class GeneratorFn(torch.autograd.Function):
         n_enc = len(enc)
         a_enc, src_enc = [], []
         src = Src(x)
+        W = _Weights()
         for blk in enc:
-            a = ops.conv1d_fwd(src, blk.conv.weight, blk.conv.bias, blk.stride, pack=blk._pack)
+            a = ops.conv1d_fwd(src, W.get(blk.conv), blk.conv.bias, blk.stride, pack=blk._pack)
             src_enc.append(src)
             a_enc.append(a)
             src = Src(a, slope=blk.act.weight)
@@ -120,7 +180,7 @@ class GeneratorFn(torch.autograd.Function):
                 else:
                     src = Src(prev, slope=s_prev)
             act = ACT_TANH if blk.is_tanh else ACT_NONE
-            a = ops.deconv1d_fwd(src, blk.deconv.weight, blk.deconv.bias, blk.stride, act,
+            a = ops.deconv1d_fwd(src, W.get(blk.deconv), blk.deconv.bias, blk.stride, act,
                                  pack=blk._pack)
             src_dec.append(src)
             a_dec.append(a)
@@ -129,7 +189,7 @@ class GeneratorFn(torch.autograd.Function):
         ctx.gen = gen
         ctx.set_materialize_grads(False)
         ctx.x_needs = x.requires_grad
-        ctx.state = (x, z, a_enc, src_enc, a_dec, src_dec)
+        ctx.state = (x, z, a_enc, src_enc, a_dec, src_dec, W)
         hid = None
         if want_hid:
             hid = {}
@@ -148,7 +208,7 @@ class GeneratorFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, *unused):
         gen = ctx.gen
-        x, z, a_enc, src_enc, a_dec, src_dec = ctx.state
+        x, z, a_enc, src_enc, a_dec, src_dec, W = ctx.state
         enc, dec = list(gen.enc_blocks), list(gen.dec_blocks)
         n_enc, n_dec = len(enc), len(dec)
         if dy is None:
@@ -162,7 +222,7 @@ class GeneratorFn(torch.autograd.Function):
         da = None
         for li in range(n_dec - 1, -1, -1):
             blk = dec[li]
-            w = blk.deconv.weight
+            w = W.get(blk.deconv)
             K, S = blk.kwidth, blk.stride
             if blk.is_tanh:
                 da = ops.tanh_bwd(a_dec[li], dy, dbias=_gb(blk.deconv.bias))
@@ -170,10 +230,10 @@ class GeneratorFn(torch.autograd.Function):
                 da = ops.act_bwd(a_dec[li], dh, slope=blk.act.weight,
                                  dslope=_gb(blk.act.weight), dbias=_gb(blk.deconv.bias))
             src = src_dec[li]
-            if w.requires_grad:
-                gw = grad_buf(w)
-                side.run(lambda: ops.wgrad(src, Src(da), gw, K, S, ops.deconv_pad(K, S),
-                                           PAD_ZERO), da)
+            if W.needs_grad(blk.deconv):
+                gw = W.grad_target(blk.deconv)
+                side.run(lambda: (ops.wgrad(src, Src(da), gw, K, S, ops.deconv_pad(K, S), PAD_ZERO),
+                                  W.finish(blk.deconv, gw)), da)
             if li == 0:
                 if gen.no_z:
                     _d0, dh_last_enc = ops.deconv1d_dgrad(da, w, S, 0, pack=blk._pack)
@@ -194,7 +254,7 @@ class GeneratorFn(torch.autograd.Function):
         dx = None
         for l in range(n_enc - 1, -1, -1):
             blk = enc[l]
-            w = blk.conv.weight
+            w = W.get(blk.conv)
             K, S = blk.kwidth, blk.stride
             alpha_p = gen.skips[l]['alpha'].skip_k if (gen.skip and l in gen.skips) else None
             dsk = dskip.get(l)
@@ -204,9 +264,10 @@ class GeneratorFn(torch.autograd.Function):
                              dalpha=_gb(alpha_p, dsk is not None),
                              dbias=_gb(blk.conv.bias))
             padL = ops.conv_pad(K, S)[0]
-            if w.requires_grad:
-                gw = grad_buf(w)
-                side.run(lambda: ops.wgrad(Src(da), src_enc[l], gw, K, S, padL, PAD_REFLECT), da)
+            if W.needs_grad(blk.conv):
+                gw = W.grad_target(blk.conv)
+                side.run(lambda: (ops.wgrad(Src(da), src_enc[l], gw, K, S, padL, PAD_REFLECT),
+                                  W.finish(blk.conv, gw)), da)
             if l > 0:
                 dh = ops.conv1d_dgrad(da, w, src_enc[l].L, S, pack=blk._pack)
             elif ctx.x_needs:
@@ -231,8 +292,9 @@ class DiscriminatorFn(torch.autograd.Function):
         training = disc.training
         src = Src(x) if x1 is None else Src(x, x1.contiguous())
         cs, srcs, bns, xfs = [], [], [], []
+        W = _Weights()
         for l, blk in enumerate(blocks):
-            c = ops.conv1d_fwd(src, blk.conv.weight, blk.conv.bias, blk.stride, roll=rolls[l],
+            c = ops.conv1d_fwd(src, W.get(blk.conv), blk.conv.bias, blk.stride, roll=rolls[l],
                                pack=blk._pack)
             srcs.append(src)
             cs.append(c)
@@ -262,49 +324,57 @@ class DiscriminatorFn(torch.autograd.Function):
         B = h.shape[0]
         hf = h.view(B, -1)
         fc = disc.fc
-        y1 = ops.linear_fwd(hf, fc[0].weight)
-        a1 = ops.bias_prelu_rows(y1, fc[0].bias, fc[1].weight)
-        y2 = ops.linear_fwd(a1, fc[2].weight)
-        a2 = ops.bias_prelu_rows(y2, fc[2].bias, fc[3].weight)
-        y3 = ops.linear_fwd(a2, fc[4].weight)
+        y1 = ops.linear_fwd(hf, W.get(fc[0]))
+        a1 = ops.bias_prelu_rows(y1, fc[0].bias, W.get(fc[1]))
+        y2 = ops.linear_fwd(a1, W.get(fc[2]))
+        a2 = ops.bias_prelu_rows(y2, fc[2].bias, W.get(fc[3]))
+        y3 = ops.linear_fwd(a2, W.get(fc[4]))
         out = ops.bias_prelu_rows(y3, fc[4].bias, None)
         ctx.disc = disc
         ctx.rolls = tuple(rolls)
         ctx.x_needs = x.requires_grad or (x1 is not None and x1.requires_grad)
         ctx.split = None if x1 is None else (x.shape[1], x.requires_grad, x1.requires_grad)
-        ctx.state = (cs, srcs, bns, hf, y1, a1, y2, a2, y3)
+        ctx.state = (cs, srcs, bns, hf, y1, a1, y2, a2, y3, W)
         disc._last_fwd = (cs, xfs)      # for the lazy int_act dict
         return out
 
     @staticmethod
     def backward(ctx, dout):
         disc = ctx.disc
-        cs, srcs, bns, hf, y1, a1, y2, a2, y3 = ctx.state
+        cs, srcs, bns, hf, y1, a1, y2, a2, y3, W = ctx.state
         blocks = list(disc.enc_blocks)
         fc = disc.fc
         dout = dout.contiguous()
         any_param = any(p.requires_grad for p in disc.parameters())
         # ---- dense head ----
+        def lin_wgrad(mod, dy, xin):
+            if W.needs_grad(mod):
+                gw = W.grad_target(mod)
+                ops.linear_wgrad(dy, xin, gw)
+                W.finish(mod, gw)
+
+        def prelu_bwd(y, lin, act, dact):
+            gs = W.grad_target(act) if W.needs_grad(act) else None
+            d = ops.bias_prelu_rows_bwd(y, lin.bias, W.get(act), dact, gs, _gb(lin.bias))
+            if gs is not None:
+                W.finish(act, gs)
+            return d
+
         dy3 = ops.bias_prelu_rows_bwd(y3, fc[4].bias, None, dout, None, _gb(fc[4].bias))
-        if fc[4].weight.requires_grad:
-            ops.linear_wgrad(dy3, a2, grad_buf(fc[4].weight))
-        da2 = ops.linear_dgrad(dy3, fc[4].weight)
-        dy2 = ops.bias_prelu_rows_bwd(y2, fc[2].bias, fc[3].weight, da2, _gb(fc[3].weight),
-                                      _gb(fc[2].bias))
-        if fc[2].weight.requires_grad:
-            ops.linear_wgrad(dy2, a1, grad_buf(fc[2].weight))
-        da1 = ops.linear_dgrad(dy2, fc[2].weight)
-        dy1 = ops.bias_prelu_rows_bwd(y1, fc[0].bias, fc[1].weight, da1, _gb(fc[1].weight),
-                                      _gb(fc[0].bias))
-        if fc[0].weight.requires_grad:
-            ops.linear_wgrad(dy1, hf, grad_buf(fc[0].weight))
-        dh = ops.linear_dgrad(dy1, fc[0].weight).view(cs[-1].shape)
+        lin_wgrad(fc[4], dy3, a2)
+        da2 = ops.linear_dgrad(dy3, W.get(fc[4]))
+        dy2 = prelu_bwd(y2, fc[2], fc[3], da2)
+        lin_wgrad(fc[2], dy2, a1)
+        da1 = ops.linear_dgrad(dy2, W.get(fc[2]))
+        dy1 = prelu_bwd(y1, fc[0], fc[1], da1)
+        lin_wgrad(fc[0], dy1, hf)
+        dh = ops.linear_dgrad(dy1, W.get(fc[0])).view(cs[-1].shape)
         # ---- conv stack ----
         dx = None
         side = _SideStream()
         for l in range(len(blocks) - 1, -1, -1):
             blk = blocks[l]
-            w = blk.conv.weight
+            w = W.get(blk.conv)
             K, S = blk.kwidth, blk.stride
             bn = bns[l]
             if bn == 'eval':
@@ -318,10 +388,10 @@ class DiscriminatorFn(torch.autograd.Function):
                 dc = ops.act_bwd(cs[l], dh, slope=blk.act.weight, dslope=_gb(blk.act.weight),
                                  dbias=_gb(blk.conv.bias))
             padL = ops.conv_pad(K, S)[0]
-            if w.requires_grad:
-                gw, rl = grad_buf(w), ctx.rolls[l]
-                side.run(lambda: ops.wgrad(Src(dc), srcs[l], gw, K, S, padL, PAD_REFLECT, roll=rl),
-                         dc)
+            if W.needs_grad(blk.conv):
+                gw, rl = W.grad_target(blk.conv), ctx.rolls[l]
+                side.run(lambda: (ops.wgrad(Src(dc), srcs[l], gw, K, S, padL, PAD_REFLECT, roll=rl),
+                                  W.finish(blk.conv, gw)), dc)
             if l > 0:
                 dh = ops.conv1d_dgrad(dc, w, srcs[l].L, S, roll=ctx.rolls[l], pack=blk._pack)
             elif ctx.x_needs:
@@ -347,7 +417,8 @@ class ConvBlockFn(torch.autograd.Function):
     def forward(ctx, blk, x, *params):
         x = x.contiguous()
         src = Src(x)
-        c = ops.conv1d_fwd(src, blk.conv.weight, blk.conv.bias, blk.stride, pack=blk._pack)
+        W = _Weights()
+        c = ops.conv1d_fwd(src, W.get(blk.conv), blk.conv.bias, blk.stride, pack=blk._pack)
         bn_saved = None
         scale = shift = None
         if blk.norm is not None:
@@ -369,15 +440,15 @@ class ConvBlockFn(torch.autograd.Function):
         ctx.blk = blk
         ctx.set_materialize_grads(False)
         ctx.x_needs = x.requires_grad
-        ctx.state = (src, c, bn_saved)
+        ctx.state = (src, c, bn_saved, W)
         return h, a
 
     @staticmethod
     def backward(ctx, dh, da_lin):
         blk = ctx.blk
-        src, c, bn = ctx.state
+        src, c, bn, W = ctx.state
         K, S = blk.kwidth, blk.stride
-        w = blk.conv.weight
+        w = W.get(blk.conv)
         if dh is None and da_lin is None:
             return (None,) * len(ctx.needs_input_grad)
         dh = dh.contiguous() if dh is not None else None
@@ -395,8 +466,10 @@ class ConvBlockFn(torch.autograd.Function):
             dc = ops.act_bwd(c, dh, slope=blk.act.weight, bn=bn, dslope=_gb(blk.act.weight),
                              dgamma=_gb(bn[2]), dbeta=_gb(bn[3]), dbias=_gb(blk.conv.bias))
         padL = ops.conv_pad(K, S)[0]
-        if w.requires_grad:
-            ops.wgrad(Src(dc), src, grad_buf(w), K, S, padL, PAD_REFLECT)
+        if W.needs_grad(blk.conv):
+            gw = W.grad_target(blk.conv)
+            ops.wgrad(Src(dc), src, gw, K, S, padL, PAD_REFLECT)
+            W.finish(blk.conv, gw)
         dx = ops.conv1d_dgrad(dc, w, src.L, S, pack=blk._pack) if ctx.x_needs else None
         ctx.state = None
         return (None, dx) + (None,) * (len(ctx.needs_input_grad) - 2)
@@ -410,28 +483,31 @@ class DeconvBlockFn(torch.autograd.Function):
         x = x.contiguous()
         src = Src(x)
         act = ACT_TANH if blk.is_tanh else ACT_NONE
-        a = ops.deconv1d_fwd(src, blk.deconv.weight, blk.deconv.bias, blk.stride, act,
+        W = _Weights()
+        a = ops.deconv1d_fwd(src, W.get(blk.deconv), blk.deconv.bias, blk.stride, act,
                              pack=blk._pack)
         h = a if blk.is_tanh else ops.affine_prelu(a, slope=blk.act.weight)
         ctx.blk = blk
         ctx.x_needs = x.requires_grad
-        ctx.state = (src, a)
+        ctx.state = (src, a, W)
         return h
 
     @staticmethod
     def backward(ctx, dh):
         blk = ctx.blk
-        src, a = ctx.state
+        src, a, W = ctx.state
         K, S = blk.kwidth, blk.stride
-        w = blk.deconv.weight
+        w = W.get(blk.deconv)
         dh = dh.contiguous()
         if blk.is_tanh:
             da = ops.tanh_bwd(a, dh, dbias=_gb(blk.deconv.bias))
         else:
             da = ops.act_bwd(a, dh, slope=blk.act.weight, dslope=_gb(blk.act.weight),
                              dbias=_gb(blk.deconv.bias))
-        if w.requires_grad:
-            ops.wgrad(src, Src(da), grad_buf(w), K, S, ops.deconv_pad(K, S), PAD_ZERO)
+        if W.needs_grad(blk.deconv):
+            gw = W.grad_target(blk.deconv)
+            ops.wgrad(src, Src(da), gw, K, S, ops.deconv_pad(K, S), PAD_ZERO)
+            W.finish(blk.deconv, gw)
         dx = None
         if ctx.x_needs:
             _d0, dx = ops.deconv1d_dgrad(da, w, S, 0, pack=blk._pack)

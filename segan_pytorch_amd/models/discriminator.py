@@ -61,9 +61,8 @@ class Discriminator(Model):
         if sinc_conv:
             raise NotImplementedError('sinc_conv is not implemented in segan_pytorch_amd (and is '
                                       'broken in the reference: discriminator.py:90-95)')
-        if norm_type not in ('bnorm', None):
-            raise NotImplementedError("Discriminator norm_type {!r} is not implemented yet "
-                                      "(only 'bnorm' and None)".format(norm_type))
+        if norm_type not in ('bnorm', 'snorm', None):
+            raise TypeError('Unrecognized norm type: ', norm_type)
         ninp = ninputs
         self.enc_blocks = nn.ModuleList()
         for fmap, pool in zip(fmaps, poolings):
@@ -75,6 +74,12 @@ class Discriminator(Model):
             pool_slen *= fmaps[-1]
             self.fc = nn.Sequential(nn.Linear(pool_slen, 256), nn.PReLU(256),
                                     nn.Linear(256, 128), nn.PReLU(128), nn.Linear(128, 1))
+            if norm_type == 'snorm':
+                # discriminator.py:118-121, literally: the two hidden Linears and fc[3], which
+                # is the second PReLU (its [128] slope vector is normalised as a 128x1 matrix)
+                torch.nn.utils.spectral_norm(self.fc[0])
+                torch.nn.utils.spectral_norm(self.fc[2])
+                torch.nn.utils.spectral_norm(self.fc[3])
         else:
             raise NotImplementedError("Discriminator pool_type {!r} is not implemented (only "
                                       "'none', the SEGAN+/WSEGAN setting)".format(pool_type))

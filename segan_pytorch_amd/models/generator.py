@@ -75,9 +75,10 @@ class Generator(Model):
         if isinstance(kwidth, int):
             kwidth = [kwidth] * len(fmaps)
         assert isinstance(kwidth, list), type(kwidth)
-        if norm_type is not None:
-            raise NotImplementedError('Generator norm layers are not implemented (the reference '
-                                      'training never enables them: model.py:82-96)')
+        if norm_type not in (None, 'snorm'):
+            raise NotImplementedError("only norm_type None / 'snorm' are implemented in the "
+                                      "Generator (the reference's training never passes one: "
+                                      "model.py:82-96)")
         skips = {}
         ninp = ninputs
         for pi, (fmap, pool, kw) in enumerate(zip(fmaps, poolings, kwidth), start=1):

@@ -22,9 +22,12 @@ def build_norm_layer(norm_type, param=None, num_feats=None):
     if norm_type == 'bnorm':
         return nn.BatchNorm1d(num_feats)
     elif norm_type == 'snorm':
-        raise NotImplementedError(
-            "norm_type='snorm' (spectral norm, modules.py:12-14) is not implemented yet in "
-            "segan_pytorch_amd")
+        # registers weight_orig / weight_u / weight_v on the parameter container exactly as the
+        # reference does (same state_dict keys, same RNG draws for u and v); the hook torch
+        # installs never runs because the container's forward is never called — the
+        # normalisation itself is done by ops.snorm_fwd / snorm_bwd (functional._Weights)
+        torch.nn.utils.spectral_norm(param)
+        return None
     elif norm_type is None:
         return None
     else:
@@ -74,14 +77,15 @@ class GDeconv1DBlock(nn.Module):
         _check_geometry(kwidth, stride)
         if stride < 2:
             raise ValueError('GDeconv1DBlock needs stride > 1')
-        if norm_type is not None:
-            raise NotImplementedError('norm layers inside GDeconv1DBlock are not implemented '
-                                      '(the reference never builds G with a norm, model.py:82-96)')
+        if norm_type not in (None, 'snorm'):
+            raise NotImplementedError("only norm_type None / 'snorm' are implemented inside "
+                                      "GDeconv1DBlock (BatchNorm in G is never built by the "
+                                      "reference's recipes)")
         pad = max(0, (stride - kwidth) // -2)
         # NOTE the reference ignores `bias` here: the deconv always has a bias
         # (modules.py:116-119)
         self.deconv = nn.ConvTranspose1d(ninp, fmaps, kwidth, stride=stride, padding=pad)
-        self.norm = None
+        self.norm = build_norm_layer(norm_type, self.deconv, fmaps)
         if act is not None:
             if act != 'Tanh':
                 raise NotImplementedError("only act=None (PReLU) or 'Tanh' are implemented")

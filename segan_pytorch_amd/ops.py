@@ -591,6 +591,47 @@ def stft_overlap_add(dframes, B, T, n_fft, hop, win):
     return dx
 
 
+# ---- spectral normalisation -----------------------------------------------------------------
+def _sn_view(w, dim):
+    """[A, Bd, K] view of a weight for the C ABI: Conv1d / ConvTranspose1d [A, Bd, K], Linear
+    [A, Bd] (K = 1), PReLU [A] (Bd = K = 1)."""
+    shp = tuple(w.shape) + (1,) * (3 - w.dim())
+    if w.dim() > 3 or dim not in (0, 1) or (dim == 1 and w.dim() < 2):
+        raise ValueError('snorm: unsupported weight shape {} / dim {}'.format(tuple(w.shape), dim))
+    return shp
+
+
+def snorm_fwd(w, u, v, dim, power_iteration, eps=1e-12):
+    """(w / sigma, sigma) of torch.nn.utils.spectral_norm; u, v are updated in place when
+    `power_iteration` (training mode)."""
+    _chk(w, 'w')
+    _chk(u, 'u', 1)
+    _chk(v, 'v', 1)
+    A, Bd, K = _sn_view(w, dim)
+    rows, cols = (A, Bd * K) if dim == 0 else (Bd, A * K)
+    if u.numel() != rows or v.numel() != cols:
+        raise ValueError('snorm: u[{}] / v[{}] do not match the {}x{} matrix view'.format(
+            u.numel(), v.numel(), rows, cols))
+    lib = _lib.load()
+    w_sn = torch.empty_like(w)
+    sigma = torch.empty(1, device=w.device, dtype=torch.float32)
+    ws = torch.empty(lib.segan_snorm_ws_floats(A, Bd, K, dim), device=w.device, dtype=torch.float32)
+    check(lib.segan_snorm_fwd(_ptr(w), _ptr(u), _ptr(v), _ptr(w_sn), _ptr(sigma), _ptr(ws), A, Bd, K,
+                              dim, 1 if power_iteration else 0, float(eps), _stream()), 'snorm_fwd')
+    return w_sn, sigma
+
+
+def snorm_bwd(dw_sn, w, u, v, sigma, dim, dw):
+    """dw += d(w/sigma)^T dw_sn with u, v held constant (how torch differentiates it)."""
+    _chk(dw_sn, 'dw_sn')
+    _chk(dw, 'dw')
+    A, Bd, K = _sn_view(w, dim)
+    lib = _lib.load()
+    ws = torch.empty(lib.segan_snorm_ws_floats(A, Bd, K, dim), device=w.device, dtype=torch.float32)
+    check(lib.segan_snorm_bwd(_ptr(dw_sn), _ptr(w), _ptr(u), _ptr(v), _ptr(sigma), _ptr(dw), _ptr(ws),
+                              A, Bd, K, dim, _stream()), 'snorm_bwd')
+
+
 def pcm16_prep(pcm, first, coef):
     """int16 slices [B, 2, T+1] (+ first[B] uint8) -> (clean, noisy) fp32 [B, T]: min-max
     normalisation and pre-emphasis of se_dataset.py:108-117 on the GPU, bit-exact."""

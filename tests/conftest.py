@@ -36,6 +36,11 @@ def tiny_s2():
 
 
 @pytest.fixture(scope='session')
+def tiny_snorm():
+    return load_golden('tiny_snorm.pt')
+
+
+@pytest.fixture(scope='session')
 def tiny_wsegan2():
     return load_golden('tiny_wsegan2.pt')
 

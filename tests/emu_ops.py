@@ -285,6 +285,38 @@ def stft_overlap_add(dframes, B, T, n_fft, hop, win):
     return dx.float()
 
 
+def _sn_mat(w, dim):
+    if dim != 0:
+        w = w.permute(dim, *[d for d in range(w.dim()) if d != dim])
+    return w.reshape(w.size(0), -1)
+
+
+def snorm_fwd(w, u, v, dim, power_iteration, eps=1e-12):
+    import torch.nn.functional as F
+    wm = _sn_mat(w.detach(), dim)
+    with torch.no_grad():
+        if power_iteration:
+            v.copy_(F.normalize(torch.mv(wm.t(), u), dim=0, eps=eps))
+            u.copy_(F.normalize(torch.mv(wm, v), dim=0, eps=eps))
+        sigma = torch.dot(u, torch.mv(wm, v)).reshape(1)
+        return (w.detach() / sigma).contiguous(), sigma
+
+
+def snorm_bwd(dw_sn, w, u, v, sigma, dim, dw):
+    wd = w.detach().double()
+    d = (dw_sn.double() * wd).sum()
+    outer = torch.outer(u.double(), v.double())      # [rows, cols] of the matrix view
+    if dim == 0:
+        outer = outer.reshape(wd.shape)
+    else:
+        perm = [dim] + [i for i in range(wd.dim()) if i != dim]
+        shape = [wd.shape[i] for i in perm]
+        inv = [perm.index(i) for i in range(wd.dim())]
+        outer = outer.reshape(shape).permute(inv)
+    s = sigma.double()
+    dw.add_((dw_sn.double() / s - d / (s * s) * outer).float())
+
+
 def rmsprop_step(p, g, sq, lr, alpha, eps):
     sq.mul_(alpha).addcmul_(g, g, value=1 - alpha)
     p.addcdiv_(g, sq.sqrt().add_(eps), value=-lr)
@@ -318,7 +350,7 @@ _NAMES = ['conv1d_fwd', 'conv1d_dgrad', 'wgrad', 'deconv1d_fwd', 'deconv1d_dgrad
           'affine_prelu', 'sum_skip', 'bce_logits_const', 'bce_logits_const_bwd', 'act_bwd', 'tanh_bwd', 'linear_fwd', 'linear_dgrad', 'linear_wgrad',
           'bias_prelu_rows', 'bias_prelu_rows_bwd', 'mse_const', 'mse_const_bwd', 'l1_mean',
           'l1_bwd', 'stft_basis', 'stft_frames', 'stft_spectrum', 'stft_spectrum_bwd', 'powdb',
-          'powdb_bwd', 'stft_overlap_add', 'rmsprop_step', 'adam_step', 'fill_', 'scale_', '_chk']
+          'powdb_bwd', 'stft_overlap_add', 'snorm_fwd', 'snorm_bwd', 'rmsprop_step', 'adam_step', 'fill_', 'scale_', '_chk']
 
 
 def install():

@@ -108,9 +108,11 @@ def test_argument_validation_mirrors_reference_errors():
         g(torch.zeros(1, 1, 30))             # not divisible by the pooling
     with pytest.raises(ValueError):          # generator.py:200-202
         g(torch.zeros(1, 1, 32), z=torch.zeros(1, 8))
-    for bad in (dict(norm_type='snorm'), dict(sinc_conv=True), dict(pool_type='gmax')):
+    for bad in (dict(sinc_conv=True), dict(pool_type='gmax')):
         with pytest.raises(NotImplementedError):
             Discriminator(2, [8, 16], 31, [4, 4], pool_slen=2, **bad)
+    d = Discriminator(2, [8, 16], 31, [4, 4], pool_slen=2, norm_type='snorm')
+    assert 'enc_blocks.0.conv.weight_orig' in d.state_dict() and 'fc.3.weight_u' in d.state_dict()
 
 
 def test_flat_arena_optimizer_state_dict_format():

@@ -525,3 +525,41 @@ def test_stft_pow_l1_matches_torch_stft(B, T, n_fft):
     loss.backward()
     assert abs(loss.item() - ref.item()) < 1e-5 * abs(ref.item())
     assert max_rel(xg.grad, xd.grad) < 5e-3
+
+
+# ---- spectral normalisation ------------------------------------------------------------------
+@pytest.mark.parametrize('shape,dim', [((40, 24, 31), 0), ((24, 40, 31), 1), ((256, 4000), 0),
+                                       ((128,), 0), ((1024, 512, 31), 0), ((8, 3, 5), 1)])
+@pytest.mark.parametrize('power_iteration', [True, False])
+def test_snorm_fwd_bwd_matches_torch(shape, dim, power_iteration):
+    """ops.snorm_fwd / snorm_bwd against torch.nn.utils.spectral_norm's algorithm in fp64:
+    u, v after the power iteration, sigma, the normalised weight, and the gradient folded
+    back into weight_orig (u, v constants)."""
+    import torch.nn.functional as F
+    ops = _ops()
+    w = rnd(*shape, seed=1, scale=0.3)
+    wm = w.double()
+    if dim != 0:
+        wm = wm.permute(dim, *[d for d in range(w.dim()) if d != dim])
+    wm = wm.reshape(wm.size(0), -1)
+    u0 = F.normalize(rnd(wm.size(0), seed=2).double(), dim=0)
+    v0 = F.normalize(rnd(wm.size(1), seed=3).double(), dim=0)
+    u, v = u0.clone(), v0.clone()
+    if power_iteration:
+        v = F.normalize(torch.mv(wm.t(), u), dim=0, eps=1e-12)
+        u = F.normalize(torch.mv(wm, v), dim=0, eps=1e-12)
+    wd = w.double().requires_grad_(True)
+    wmd = wd if dim == 0 else wd.permute(dim, *[d for d in range(w.dim()) if d != dim])
+    sigma = torch.dot(u, torch.mv(wmd.reshape(wm.shape), v))
+    w_sn_ref = wd / sigma
+    g = rnd(*shape, seed=4)
+    w_sn_ref.backward(g.double())
+
+    ug, vg = u0.float().to(DEV), v0.float().to(DEV)
+    w_sn, sig = ops.snorm_fwd(w.to(DEV), ug, vg, dim, power_iteration)
+    assert max_rel(ug, u) < 2e-5 and max_rel(vg, v) < 2e-5
+    assert abs(sig.item() - sigma.item()) < 2e-5 * abs(sigma.item())
+    assert max_rel(w_sn, w_sn_ref) < 2e-5
+    dw = torch.full(shape, 0.25, device=DEV)          # accumulates
+    ops.snorm_bwd(g.to(DEV), w.to(DEV), ug, vg, sig, dim, dw)
+    assert max_rel(dw - 0.25, wd.grad) < 5e-5
