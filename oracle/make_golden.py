@@ -151,12 +151,54 @@ def make_snorm(ref):
     print('tiny_snorm.pt done', sorted(k for k in fx['D0'] if 'fc.3' in k or 'enc_blocks.0.conv' in k))
 
 
+def make_wsegan_snorm(ref):
+    """tiny_wsegan_snorm.pt: the literal WSEGAN.train in the flavour of run_wsegan_train.sh
+    (--wsegan --dnorm_type snorm --opt adam --misalign_pair), two iterations.  Same harness-only
+    patches as tiny_wsegan2 (legacy torch.stft call, hard .cuda())."""
+    ow = tiny_opts()
+    ow.update(dict(wsegan=True, misalign_pair=True, cuda=False, save_freq=1000, dnorm_type='snorm',
+                   opt='adam'))
+    _stft = torch.stft
+    torch.stft = lambda *a, **k: torch.view_as_real(_stft(*a, return_complex=True, **k))
+    _cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    # model.py:224-225 builds Adam(betas=(0, 0.9)); torch 2.x rejects the int 0 -> floats
+    _Adam = torch.optim.Adam
+
+    class _AdamFloatBetas(_Adam):
+        def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), **kw):
+            super().__init__(params, lr=lr, betas=tuple(float(b) for b in betas), **kw)
+    torch.optim.Adam = _AdamFloatBetas
+    try:
+        seed_all(111)
+        wseg = ref.WSEGAN(SimpleNamespace(**ow))
+        c1, n1 = synth(3, 1024, 14)
+        names = ['utt_additive_0', 'utt_1', 'utt_additive_2']
+        loader = [[names, c1, n1, torch.zeros(3)]]
+        fxw = {'opts': ow, 'G0': clone_sd(wseg.G), 'D0': clone_sd(wseg.D), 'clean': c1,
+               'noisy': n1, 'names': names, 'seed': 37, 'iters': 2}
+        ow2 = dict(ow)
+        ow2['epoch'] = 2
+        seed_all(37)
+        wseg.train(SimpleNamespace(**ow2), loader, None, ow['l1_weight'], ow['l1_dec_step'],
+                   ow['l1_dec_epoch'], 1000, va_dloader=None, device='cpu')
+        fxw['G_final'] = clone_sd(wseg.G)
+        fxw['D_final'] = clone_sd(wseg.D)
+        torch.save(fxw, os.path.join(OUT, 'tiny_wsegan_snorm.pt'))
+        print('tiny_wsegan_snorm.pt done')
+    finally:
+        torch.stft = _stft
+        torch.Tensor.cuda = _cuda
+        torch.optim.Adam = _Adam
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = ref_harness.import_reference()
     torch.set_num_threads(max(1, os.cpu_count() or 1))
-    if len(sys.argv) > 1 and sys.argv[1] == 'snorm':     # only the spectral-norm fixture
+    if len(sys.argv) > 1 and sys.argv[1] == 'snorm':     # only the spectral-norm fixtures
         make_snorm(ref)
+        make_wsegan_snorm(ref)
         return
 
     # ---------------- tiny_step ----------------
@@ -276,6 +318,7 @@ def main():
     torch.save(fx4, os.path.join(OUT, 'segan_plus_b2.pt'))
     print('segan_plus_b2.pt done', res['Genh'].shape, res['g_l1_loss'])
     make_snorm(ref)
+    make_wsegan_snorm(ref)
 
 
 if __name__ == '__main__':

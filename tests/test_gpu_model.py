@@ -347,12 +347,14 @@ def test_blocks_standalone_match_oracle():
     assert max_rel(db.deconv.weight.grad, sd['deconv.weight'].grad) < GRAD_TOL
 
 
-def test_wsegan_literal_train_matches_reference(tmp_path):
+@pytest.mark.parametrize('golden', ['tiny_wsegan2.pt', 'tiny_wsegan_snorm.pt'])
+def test_wsegan_literal_train_matches_reference(golden, tmp_path):
     """WSEGAN.train with --misalign_pair on the GPU against the reference's literal
-    WSEGAN.train (two iterations; same host RNG streams)."""
+    WSEGAN.train (two iterations; same host RNG streams); second fixture: the
+    run_wsegan_train.sh flavour (--dnorm_type snorm --opt adam)."""
     from conftest import load_golden
     from segan_pytorch_amd.models import WSEGAN
-    fx = load_golden('tiny_wsegan2.pt')
+    fx = load_golden(golden)
     o = dict(fx['opts'])
     o['save_path'] = str(tmp_path)
     o['epoch'] = fx['iters']

@@ -167,11 +167,14 @@ def test_blocks_standalone(tiny_step):
     assert max_rel(db.deconv.weight.grad, sd['deconv.weight'].grad) < 1e-4
 
 
-def test_wsegan_literal_train(tiny_wsegan2, tmp_path):
+@pytest.mark.parametrize('golden', ['tiny_wsegan2.pt', 'tiny_wsegan_snorm.pt'])
+def test_wsegan_literal_train(golden, tmp_path):
     """WSEGAN.train (misalign pair, STFT power loss, masked L1) against the reference's
-    literal WSEGAN.train."""
+    literal WSEGAN.train; the second fixture is the run_wsegan_train.sh flavour
+    (--dnorm_type snorm --opt adam)."""
+    from conftest import load_golden
     from segan_pytorch_amd.models import WSEGAN
-    fx = tiny_wsegan2
+    fx = load_golden(golden)
     o = dict(fx['opts'])
     o['save_path'] = str(tmp_path)
     o['epoch'] = fx['iters']
