@@ -691,6 +691,88 @@ static int launch_tsmall(CorrArgs& a, const float* w, int K, int M, int N, int S
   return launch_tsmall_sn<1, 2>(a, w, K, M, pad, st);
 }
 
+
+// ====================================================================================
+// F form for 1-2 input channels (the first conv of G and of D: HBM-bound, and an MFMA tile
+// whose contraction is N*32 <= 64 deep would be mostly the padding to the 64-deep LDS chunk).
+// Direct VALU kernel: a workgroup owns 256 output positions of one sample, stages the padded
+// input window once (reflect / roll / transform applied while staging) and walks the output
+// channels with the taps read as 16-byte LDS broadcasts from a zero-padded [m][n][32] copy of
+// the packed weights.  Stores are coalesced along time.
+// ====================================================================================
+template <int S, int N>
+__global__ __launch_bounds__(256) void fsmall_kernel(const CorrArgs a, int M) {
+  constexpr int U = 32 / S;
+  constexpr int XW = S * 256 + 32;
+  constexpr int WST = N * 32 + 4;          // row stride of the weight copy (16-B aligned)
+  __shared__ __attribute__((aligned(16))) float xs[N][XW];
+  __shared__ __attribute__((aligned(16))) float ws[64 * WST];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y;
+  const int t0 = blockIdx.x * 256;
+  for (int j = tid; j < XW; j += 256) {
+    const int idx = segan_hi_index(S * t0 + j, a.Lin, a.padL, a.mode, a.roll);
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      float v = 0.0f;
+      if (idx >= 0) v = segan_apply_xf(segan_chan_xf(a.in, n), segan_src_row(a.in, b, n, a.Lin)[idx]);
+      xs[n][j] = v;
+    }
+  }
+  const int t = t0 + tid;
+  for (int m0 = 0; m0 < M; m0 += 64) {
+    // packed F layout: w[m][n][S*u + r] = wp[((n*S + r)*U + u) * RP + m]; rows of taps >= K
+    // are zero.  Lanes run along m so the global reads are coalesced.
+    for (int e = tid; e < 64 * N * 32; e += 256) {
+      const int ml = e & 63, nk = e >> 6;
+      const int n = nk >> 5, k = nk & 31;
+      const int row = (n * S + k % S) * U + k / S;
+      const int m = m0 + ml;
+      ws[ml * WST + n * 32 + k] = m < a.RP ? a.wp[(size_t)row * a.RP + m] : 0.0f;
+    }
+    __syncthreads();
+    float xv[N][32];
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      if (S == 4) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(&xs[n][4 * tid + 4 * i]);
+          xv[n][4 * i] = v[0]; xv[n][4 * i + 1] = v[1]; xv[n][4 * i + 2] = v[2]; xv[n][4 * i + 3] = v[3];
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 32; ++k) xv[n][k] = xs[n][S * tid + k];
+      }
+    }
+    const int mcn = min(64, M - m0);
+    for (int ml = 0; ml < mcn; ++ml) {
+      float acc = a.bias ? a.bias[m0 + ml] : 0.0f;
+#pragma unroll
+      for (int n = 0; n < N; ++n) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(&ws[ml * WST + n * 32 + 4 * i]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc = fmaf(wv[e], xv[n][4 * i + e], acc);
+        }
+      }
+      if (t < a.Lout) a.out0[((size_t)b * M + m0 + ml) * a.Lout + t] = acc;
+    }
+    __syncthreads();
+  }
+}
+
+static int launch_fsmall(CorrArgs& a, int M, int N, int S, hipStream_t st) {
+  if (int e = segan_src_defaults(&a.in, st, "fsmall")) return e;
+  dim3 grid(ceil_div(a.Lout, 256), a.B);
+#define FS(SS, NN) hipLaunchKernelGGL((fsmall_kernel<SS, NN>), grid, dim3(256), 0, st, a, M)
+  if (N == 1) { if (S == 4) FS(4, 1); else if (S == 2) FS(2, 1); else FS(1, 1); }
+  else { if (S == 4) FS(4, 2); else if (S == 2) FS(2, 2); else FS(1, 2); }
+#undef FS
+  return segan_check_launch("fsmall_kernel");
+}
+
 // ====================================================================================
 // wgrad kernel
 // ====================================================================================
@@ -1137,6 +1219,8 @@ extern "C" int segan_conv1d_fwd(const segan_src* x, const void* wf, const float*
   a.OC0 = M; a.OC1 = 0; a.Lout = a.Tcols; a.act = SEGAN_ACT_NONE;
   a.out0_elems = (size_t)B * M * a.Tcols;
   if (precision) return segan_corr_bf_f(a, U, wf, precision, (hipStream_t)stream);
+  static const bool fsmall_on = [] { const char* e = getenv("SEGAN_FSMALL"); return !e || atoi(e) != 0; }();
+  if (N <= 2 && fsmall_on) return launch_fsmall(a, M, N, S, (hipStream_t)stream);
   return launch_corr<true, false>(a, U, (hipStream_t)stream);
 }
 

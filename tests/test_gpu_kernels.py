@@ -108,6 +108,22 @@ def test_conv1d_fwd_dual_source_and_transform():
     assert max_rel(dw, wd.grad) < TOL
 
 
+def test_first_layer_two_pointer_input_with_transform():
+    """D.enc0 exactly: x = (clean | noisy) as two one-channel pointers, with a transform, on
+    the 1-2 channel VALU kernel."""
+    ops = _ops()
+    B, L, S, K, M = 3, 2048, 4, 31, 64
+    x0, x1 = rnd(B, 1, L, seed=1), rnd(B, 1, L, seed=2)
+    sc, sh, sl = rnd(2, seed=3), rnd(2, seed=4), rnd(2, seed=5).abs() * 0.3
+    w, b = rnd(M, 2, K, seed=6, scale=0.1), rnd(M, seed=7)
+    ref = conv_ref(xform_ref(torch.cat((x0, x1), 1), sc, sh, sl), w.double(), b.double(), S, roll=5)
+    src = ops.Src(x0.to(DEV), x1.to(DEV), scale=sc.to(DEV), shift=sh.to(DEV), slope=sl.to(DEV))
+    out = ops.conv1d_fwd(src, w.to(DEV), b.to(DEV), S, roll=5)
+    assert max_rel(out, ref) < TOL
+    out_nb = ops.conv1d_fwd(src, w.to(DEV), None, S, roll=5)
+    assert max_rel(out_nb, ref - b.double().view(1, -1, 1)) < TOL
+
+
 def deconv_ref(x, w, b, S):
     K = w.shape[2]
     pad = max(0, (S - K) // -2)
@@ -390,6 +406,15 @@ EDGE_CONV = [
     (2, 7, 9, 64, 4, 32, 0),
     (3, 2, 3, 48, 2, 7, 2),
     (2, 512, 40, 64, 4, 31, 0),
+    # first-layer VALU kernel (1-2 input channels): > 64 output channels (two weight chunks),
+    # strides 2 and 1, short kernels, lengths that are not multiples of the 256-wide tile, 300
+    # samples (the weight gradient needs L/S to be a multiple of 4)
+    (2, 2, 70, 1200, 4, 31, 3),
+    (3, 1, 130, 528, 4, 31, -4),
+    (2, 2, 9, 304, 2, 31, 1),
+    (2, 1, 5, 100, 1, 31, -2),
+    (4, 2, 64, 64, 4, 5, 0),
+    (300, 2, 64, 512, 4, 31, 2),
 ]
 
 
