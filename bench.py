@@ -131,7 +131,7 @@ def cpu_baseline(B=48):
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import segan_oracle as O
     from segan_pytorch_amd.datasets import synthetic_pairs
-    from segan_pytorch_amd.models import SEGAN
+    from segan_pytorch_amd.models import SEGAN, WSEGAN
     opts = default_opts()
     random.seed(111); np.random.seed(111); torch.manual_seed(111)
     m = SEGAN(SimpleNamespace(**opts))
@@ -194,6 +194,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timer', action='store_true')
     ap.add_argument('--no-modes', action='store_true', help='skip the bf16x3 / bf16 side measurements')
+    ap.add_argument('--wsegan', action='store_true',
+                    help='time the WSEGAN step of BASELINE config 4 (--wsegan --misalign_pair) instead '
+                         'of the SEGAN+ step; a side measurement, not the headline metric')
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16x3', 'bf16'],
                     help='forward/data-gradient contraction precision (default: exact fp32, the '
                          'BASELINE configuration; bf16x3 = exact 3-way bf16 split of fp32 operands; '
@@ -203,7 +206,7 @@ def main():
     from segan_pytorch_amd import distributed as sdist
     from segan_pytorch_amd import losses
     from segan_pytorch_amd.datasets import synthetic_pairs
-    from segan_pytorch_amd.models import SEGAN
+    from segan_pytorch_amd.models import SEGAN, WSEGAN
 
     from segan_pytorch_amd import ops as _ops
     _ops.set_precision(args.precision)
@@ -215,7 +218,12 @@ def main():
 
     opts = default_opts()
     random.seed(111); np.random.seed(111); torch.manual_seed(111)
-    model = SEGAN(SimpleNamespace(**opts)).to(dev)
+    if args.wsegan:
+        opts.update(dict(misalign_pair=True, interf_pair=False, pow_weight=0.001, vanilla_gan=False,
+                         n_fft=2048))
+        model = WSEGAN(SimpleNamespace(**opts)).to(dev)
+    else:
+        model = SEGAN(SimpleNamespace(**opts)).to(dev)
     o = SimpleNamespace(**opts)
     Gopt, Dopt = model.build_optimizers(o)
     sdist.broadcast_params(model.G)
@@ -229,8 +237,12 @@ def main():
     random.seed(1000 + rank)
     zgen = torch.Generator(device=dev).manual_seed(rank)
 
+    names = ['utt_additive_{}'.format(i) if i % 2 == 0 else 'utt_{}'.format(i) for i in range(B)]
+
     def one_step():
         z = torch.randn(B, 1024, 16, device=dev, generator=zgen)
+        if args.wsegan:
+            return model.wgan_step(names, clean, noisy, Gopt, Dopt, 100.0, z=z)
         return model.gan_step(clean, noisy, Gopt, Dopt, criterion, 100.0, z=z)
 
     def barrier():
@@ -292,14 +304,17 @@ def main():
             'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': {'fp32': 'f32', 'bf16x3': 'f32 operands as 3 bf16 planes (6 products), f32 accumulate',
                       'bf16': 'bf16 operands, f32 accumulate'}[args.precision], 'data': 'synthetic',
-            'config': {'workload': 'SEGAN+ default G+D (5+5 layers, k31, stride 4, z 1024x16), '
-                                   'batch {} x 16384-sample chunks per GPU, full GAN step '
-                                   '(model.py:292-321), RMSprop, fp32'.format(B),
+            'config': {'workload': ('WSEGAN step with --misalign_pair (model.py:577-669; BASELINE '
+                                    'config 4), same nets, batch {} x 16384-sample chunks per GPU'
+                                    if args.wsegan else
+                                    'SEGAN+ default G+D (5+5 layers, k31, stride 4, z 1024x16), '
+                                    'batch {} x 16384-sample chunks per GPU, full GAN step '
+                                    '(model.py:292-321), RMSprop, fp32').format(B),
                        'global_batch': B * world, 'parallelism': 'dp{}'.format(world)},
             'losses_finite': finite,
             'precision': args.precision,
-            'step_tflops': GFLOP_PER_CHUNK * value / 1e3,
-            'step_frac_of_f32_mfma_peak': GFLOP_PER_CHUNK * value / 1e3 / PEAK_F32_MFMA_TF / world,
+            'step_tflops': (44.33 if args.wsegan else GFLOP_PER_CHUNK) * value / 1e3,
+            'step_frac_of_f32_mfma_peak': (44.33 if args.wsegan else GFLOP_PER_CHUNK) * value / 1e3 / PEAK_F32_MFMA_TF / world,
             'step_hbm_gbs_algorithmic': MB_PER_CHUNK * value / 1e3 / world,
         }
         if timer is not None:

@@ -262,9 +262,8 @@ class SEGAN(Model):
 class WSEGAN(SEGAN):
     """Whispered-speech SEGAN variant (model.py:509-766): one summed discriminator loss
     per step with an optional misaligned / interference fake pair, and a generator loss
-    of LSGAN + STFT log-power L1 + masked L1.  All conv/deconv/BN/dense work runs on the
-    HIP path; the STFT of the power loss uses ``torch.stft`` (rocFFT) — it is not yet a
-    native kernel ("out of scope / next")."""
+    of LSGAN + STFT log-power L1 + masked L1.  Everything runs on the HIP path, the STFT
+    power loss included (``losses.stft_pow_l1``: framing + DFT-as-GEMM + power/log kernels)."""
 
     def __init__(self, opts, name='WSEGAN', generator=None, discriminator=None):
         self.lbd = 1
