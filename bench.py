@@ -276,23 +276,28 @@ def main():
     modes = {}
     if args.precision == 'fp32' and not args.no_modes:
         for prec in ('bf16x3', 'bf16'):
-            _ops.set_precision(prec)
-            for _ in range(2):
-                one_step()
-            barrier()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                lo = one_step()
-            barrier()
-            dm = time.perf_counter() - t1
-            if world > 1:
-                t = torch.tensor([dm], device=dev, dtype=torch.float64)
-                torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-                dm = float(t.item())
-            modes[prec] = {'value': B * world * args.steps / dm, 'unit': 'chunks/s',
-                           'ms_per_step': 1e3 * dm / args.steps,
-                           'losses_finite': all(bool(torch.isfinite(x)) for x in lo)}
-        _ops.set_precision('fp32')
+            try:
+                _ops.set_precision(prec)
+                for _ in range(2):
+                    one_step()
+                barrier()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    lo = one_step()
+                barrier()
+                dm = time.perf_counter() - t1
+                if world > 1:
+                    t = torch.tensor([dm], device=dev, dtype=torch.float64)
+                    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+                    dm = float(t.item())
+                modes[prec] = {'value': B * world * args.steps / dm, 'unit': 'chunks/s',
+                               'ms_per_step': 1e3 * dm / args.steps,
+                               'losses_finite': all(bool(torch.isfinite(x)) for x in lo)}
+            except Exception as e:      # a side measurement must never cost the headline line
+                modes[prec] = {'error': repr(e)}
+                break
+            finally:
+                _ops.set_precision('fp32')
 
     if rank == 0:
         chunks = B * world * args.steps
