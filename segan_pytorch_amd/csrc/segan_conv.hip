@@ -565,16 +565,16 @@ static int launch_corr(CorrArgs& a, int U, hipStream_t st) {
 // comes from an LDS tile (with the segan_src transform applied while staging) and the taps
 // are wave-uniform scalar loads.
 // ====================================================================================
-template <int S, int N, int PM>
+// KT: kernel width known at compile time (31, the SEGAN width: the taps then sit at constant
+// offsets and the scalar loads merge into s_load_dwordx8/x16) or 0 = runtime K.
+template <int S, int N, int PM, int KT>
 __global__ __launch_bounds__(256) void tsmall_kernel(const CorrArgs a, const float* __restrict__ w,
-                                                     int K, int M) {
+                                                     int Krt, int M) {
+  const int K = KT ? KT : Krt;
   constexpr int U = 32 / S;
   constexpr int MC = 16;                 // input channels per LDS chunk
   constexpr int TW = 256 + U;            // window: 256 positions + (U-1) taps + 1 phase shift
   __shared__ float xs[MC][TW + 1];
-  // taps of the chunk, zero padded to 32 per (channel, output channel): the FMA loop then has
-  // no `k < K` branches and reads its weights as 16-byte LDS broadcasts
-  __shared__ __attribute__((aligned(16))) float ws[MC][N][32];
   const int tid = threadIdx.x;
   const int b = blockIdx.y;
   const int q0 = blockIdx.x * 256;
@@ -593,14 +593,6 @@ __global__ __launch_bounds__(256) void tsmall_kernel(const CorrArgs a, const flo
   const int o0 = ok0 ? t0 : 0, o1 = ok1 ? t1 : 0;
   const int bo0 = b * a.in.C0 * a.Lin, bo1 = b * a.in.C1 * a.Lin;
   for (int mc0 = 0; mc0 < M; mc0 += MC) {
-#pragma unroll
-    for (int i = 0; i < (MC * N * 32) / 256; ++i) {
-      const int e = tid + 256 * i;
-      const int k = e & 31, n = (e >> 5) % N, mc = e / (32 * N);
-      const bool ok = mc0 + mc < M && k < K;
-      const float v = w[ok ? ((size_t)(mc0 + mc) * N + n) * K + k : 0];
-      ws[mc][n][k] = ok ? v : 0.0f;
-    }
 #pragma unroll 8
     for (int mc = 0; mc < MC; ++mc) {
       const int m = mc0 + mc < M ? mc0 + mc : 0;
@@ -619,11 +611,9 @@ __global__ __launch_bounds__(256) void tsmall_kernel(const CorrArgs a, const flo
       float xv[U + 1];
 #pragma unroll
       for (int j = 0; j <= U; ++j) xv[j] = xs[mc][tid + j];
-      f32x4 wv[N][8];
-#pragma unroll
-      for (int n = 0; n < N; ++n)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) wv[n][i] = *reinterpret_cast<const f32x4*>(&ws[mc][n][4 * i]);
+      // taps are wave-uniform: scalar loads straight into SGPR operands of the FMAs; tap
+      // indices are clamped and the value selected to zero for k >= K (no branches)
+      const float* wm = w + (size_t)(mc0 + mc) * N * K;
 #pragma unroll
       for (int r = 0; r < S; ++r) {
         const int rho = (r + PM) % S;     // tap phase of output phase r
@@ -631,9 +621,21 @@ __global__ __launch_bounds__(256) void tsmall_kernel(const CorrArgs a, const flo
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const int k = S * u + rho;
+          if (KT) {
+            if (k < KT) {
 #pragma unroll
-          for (int n = 0; n < N; ++n)
-            acc[r][n] = fmaf(wv[n][k >> 2][k & 3], xv[cs + (U - 1) - u], acc[r][n]);
+              for (int n = 0; n < N; ++n)
+                acc[r][n] = fmaf(wm[n * KT + k], xv[cs + (U - 1) - u], acc[r][n]);
+            }
+          } else {
+            const int kc = k < K ? k : K - 1;
+#pragma unroll
+            for (int n = 0; n < N; ++n) {
+              float wv = wm[n * K + kc];
+              wv = k < K ? wv : 0.0f;
+              acc[r][n] = fmaf(wv, xv[cs + (U - 1) - u], acc[r][n]);
+            }
+          }
         }
       }
     }
@@ -664,17 +666,24 @@ __global__ __launch_bounds__(256) void tsmall_kernel(const CorrArgs a, const flo
     }
 }
 
+template <int S, int N, int KT>
+static int launch_tsmall_snk(const CorrArgs& a, const float* w, int K, int M, int pad,
+                             hipStream_t st) {
+  dim3 grid(ceil_div(a.Tcols, 256), a.B);
+  switch (pad % S) {
+    case 0: hipLaunchKernelGGL((tsmall_kernel<S, N, 0, KT>), grid, dim3(256), 0, st, a, w, K, M); break;
+    case 1: hipLaunchKernelGGL((tsmall_kernel<S, N, 1 % S, KT>), grid, dim3(256), 0, st, a, w, K, M); break;
+    case 2: hipLaunchKernelGGL((tsmall_kernel<S, N, 2 % S, KT>), grid, dim3(256), 0, st, a, w, K, M); break;
+    default: hipLaunchKernelGGL((tsmall_kernel<S, N, 3 % S, KT>), grid, dim3(256), 0, st, a, w, K, M); break;
+  }
+  return segan_check_launch("tsmall_kernel");
+}
+
 template <int S, int N>
 static int launch_tsmall_sn(const CorrArgs& a, const float* w, int K, int M, int pad,
                             hipStream_t st) {
-  dim3 grid(ceil_div(a.Tcols, 256), a.B);
-  switch (pad % S) {
-    case 0: hipLaunchKernelGGL((tsmall_kernel<S, N, 0>), grid, dim3(256), 0, st, a, w, K, M); break;
-    case 1: hipLaunchKernelGGL((tsmall_kernel<S, N, 1 % S>), grid, dim3(256), 0, st, a, w, K, M); break;
-    case 2: hipLaunchKernelGGL((tsmall_kernel<S, N, 2 % S>), grid, dim3(256), 0, st, a, w, K, M); break;
-    default: hipLaunchKernelGGL((tsmall_kernel<S, N, 3 % S>), grid, dim3(256), 0, st, a, w, K, M); break;
-  }
-  return segan_check_launch("tsmall_kernel");
+  if (K == 31) return launch_tsmall_snk<S, N, 31>(a, w, K, M, pad, st);
+  return launch_tsmall_snk<S, N, 0>(a, w, K, M, pad, st);
 }
 
 // `a` is filled exactly as for the MFMA T form; w is the UNPACKED weight [M][N][K]
