@@ -796,11 +796,13 @@ __device__ __forceinline__ int wg_sdiv(int x, int Ls, int magic) {
 // (m) x 128 columns ((n,r),u = 128/U virtual channels x U taps), contraction chunks of TK
 // columns, double buffered.  LO_ID / HI_ID: that operand has the identity transform (the
 // gradient operand always has), so its staging is a plain copy.
-template <int U, int TK, bool LO_ID, bool HI_ID>
+// MB x NBT: the block tile (128 x 128, or 64 x 64 for the first layers whose M <= 64 rows and
+// N*S <= 64/U virtual channels would leave 3/4 and more of the big tile empty).
+template <int U, int TK, bool LO_ID, bool HI_ID, int MB, int NBT>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
   constexpr int S = 32 / U;
-  constexpr int MB = 128;
-  constexpr int CVW = 128 / U;       // virtual channels per block (128 output columns)
+  constexpr int CVW = NBT / U;       // virtual channels per block (NBT output columns)
+  constexpr int NI = MB / 64, NJ = NBT / 64;   // 32x32 MFMA blocks per wave (2 x 2 waves)
   constexpr int NN = CVW / S;        // real hi channels per block
   constexpr int AST = TK + 4;        // lo row stride: 16-B aligned rows, conflict-free b128 reads
   constexpr int NJ8 = TK / 8;        // groups of 8 contraction columns
@@ -832,20 +834,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 
   // ---- MFMA operand offsets.  Lane (row/col l31, half h) supplies contraction columns
   // k' = 8j + 4h + i (i = 0..3) of group j: one ds_read_b128 of the lo tile per row block.
-  int aoff[2], bbase[2];
+  int aoff[NI], bbase[NJ];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) aoff[i] = (wm * 64 + 32 * i + l31) * AST + 4 * h;
+  for (int i = 0; i < NI; ++i) aoff[i] = (wm * (MB / 2) + 32 * i + l31) * AST + 4 * h;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int cc = wn * 64 + 32 * j + l31;
+  for (int j = 0; j < NJ; ++j) {
+    const int cc = wn * (NBT / 2) + 32 * j + l31;
     bbase[j] = (cc / U) * RLw + cc % U;
   }
 
-  f32x16 acc[2][2];
+  f32x16 acc[NI][NJ];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
@@ -973,29 +975,29 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     // LDS position of contraction column k' = 8j + 4h (+i): sample s of the chunk sits s*H
     // further right; 4 | Ls keeps the 4 columns of a group in one sample.
     const int t_first = (split_beg + ch * TK) % Ls;
-    int bpos[NJ8][2];
+    int bpos[NJ8][NJ];
 #pragma unroll
     for (int j = 0; j < NJ8; ++j) {
       const int k0 = 8 * j + 4 * h;
       const int p = k0 + wg_sdiv<TK>(t_first + k0, Ls, a.ls_magic) * a.H;
 #pragma unroll
-      for (int jj = 0; jj < 2; ++jj) bpos[j][jj] = bbase[jj] + p;
+      for (int jj = 0; jj < NJ; ++jj) bpos[j][jj] = bbase[jj] + p;
     }
-    f32x4 af0[2], af1[2];
-    float bv0[2], bv1[2];
-    auto read_a = [&](int j, f32x4 (&af)[2]) {
+    f32x4 af0[NI], af1[NI];
+    float bv0[NJ], bv1[NJ];
+    auto read_a = [&](int j, f32x4 (&af)[NI]) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const f32x4*>(Al + aoff[i] + 8 * j);
+      for (int i = 0; i < NI; ++i) af[i] = *reinterpret_cast<const f32x4*>(Al + aoff[i] + 8 * j);
     };
-    auto read_b = [&](int s, float (&bv)[2]) {
+    auto read_b = [&](int s, float (&bv)[NJ]) {
 #pragma unroll
-      for (int jj = 0; jj < 2; ++jj) bv[jj] = Bl[bpos[s / 4][jj] + (s & 3)];
+      for (int jj = 0; jj < NJ; ++jj) bv[jj] = Bl[bpos[s / 4][jj] + (s & 3)];
     };
-    auto mma = [&](const f32x4 (&af)[2], int e, const float (&bv)[2]) {
+    auto mma = [&](const f32x4 (&af)[NI], int e, const float (&bv)[NJ]) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj)
+        for (int jj = 0; jj < NJ; ++jj)
           acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bv[jj], acc[i][jj], 0, 0, 0);
     };
     read_a(0, af0);
@@ -1024,26 +1026,26 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 
   // ---- epilogue: dw[m][n][S*u + r] += acc ----
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int cc = wn * 64 + 32 * j + l31;
+  for (int j = 0; j < NJ; ++j) {
+    const int cc = wn * (NBT / 2) + 32 * j + l31;
     const int cv = cv0 + cc / U;
     const int u = cc % U;
     const int n = cv / S, r = cv % S;
     const int k = S * u + r;
     if (cv >= a.Cv || k >= a.K) continue;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int m = m0 + wm * 64 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int m = m0 + wm * (MB / 2) + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
         if (m < a.M) atomicAdd(a.dw + ((size_t)m * a.N + n) * a.K + k, acc[i][j][e]);
       }
   }
 }
 
-template <int U, bool LO_ID, bool HI_ID>
-static int launch_wgrad_x(WgradArgs& a, hipStream_t st) {
-  constexpr int CVW = 128 / U;
+template <int U, bool LO_ID, bool HI_ID, int MB, int NBT>
+static int launch_wgrad_tile(WgradArgs& a, hipStream_t st) {
+  constexpr int CVW = NBT / U;
   constexpr int TK = 32;
   int NS;
   if (a.Ls >= TK) NS = (a.Ls % TK == 0) ? 1 : 2;
@@ -1068,7 +1070,7 @@ static int launch_wgrad_x(WgradArgs& a, hipStream_t st) {
   a.ls_magic = (65536 + a.Ls - 1) / a.Ls;
   a.per_magic = (65536 + a.Ls + a.H - 1) / (a.Ls + a.H);
   const int ncol = ceil_div(a.Cv, CVW);
-  const int nrow = ceil_div(a.M, 128);
+  const int nrow = ceil_div(a.M, MB);
   // split the (b,t) contraction so the grid has a few workgroups per CU
   const int tiles = ncol * nrow;
   const int chunks = ceil_div(a.Ctot, TK);
@@ -1079,8 +1081,8 @@ static int launch_wgrad_x(WgradArgs& a, hipStream_t st) {
   const int chunks_per = ceil_div(chunks, nsplit);
   nsplit = ceil_div(chunks, chunks_per);
   a.cols_per_split = chunks_per * TK;
-  const size_t lds = (size_t)(2 * 128 * (TK + 4) + 2 * CVW * a.RLw) * sizeof(float);
-  auto kern = wgrad_kernel<U, TK, LO_ID, HI_ID>;
+  const size_t lds = (size_t)(2 * MB * (TK + 4) + 2 * CVW * a.RLw) * sizeof(float);
+  auto kern = wgrad_kernel<U, TK, LO_ID, HI_ID, MB, NBT>;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1089,6 +1091,18 @@ static int launch_wgrad_x(WgradArgs& a, hipStream_t st) {
   }
   hipLaunchKernelGGL(kern, dim3(ncol, nrow, nsplit), dim3(256), lds, st, a);
   return segan_check_launch("wgrad_kernel");
+}
+
+template <int U, bool LO_ID, bool HI_ID>
+static int launch_wgrad_x(WgradArgs& a, hipStream_t st) {
+  static const bool small_on = [] { const char* e = getenv("SEGAN_WGRAD_SMALL"); return !e || atoi(e) != 0; }();
+  // edge layers (1-2 channels on the hi side: N*S <= 64/U virtual channels): 64 columns
+  // suffice, and 64 rows when M <= 64
+  if (small_on && a.Cv <= 64 / U) {
+    if (a.M <= 64) return launch_wgrad_tile<U, LO_ID, HI_ID, 64, 64>(a, st);
+    return launch_wgrad_tile<U, LO_ID, HI_ID, 128, 64>(a, st);
+  }
+  return launch_wgrad_tile<U, LO_ID, HI_ID, 128, 128>(a, st);
 }
 
 template <int U>
