@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SEGAN_ABI_VERSION 4
+#define SEGAN_ABI_VERSION 5
 
 #define SEGAN_PAD_REFLECT 0
 #define SEGAN_PAD_ZERO 1
@@ -233,15 +233,19 @@ int segan_snorm_bwd(const float* dw_sn, const float* w, const float* u, const fl
  * a rectangular window zero-padded to n_fft, centre (reflect) padding of n_fft/2.  Only `win`
  * samples of a frame are non-zero, so the transform is frames[B*NF, win] x basis[win, 2*nbins]
  * (NF = 1 + T/hop, nbins = n_fft/2+1; columns [0,nbins) real, [nbins,2nbins) imaginary) run
- * through segan_gemm.  Requires n_fft/2 < T. */
+ * through segan_gemm.  Rows of the basis and of the spectra are `pitch` =
+ * segan_stft_pitch(n_fft) floats wide (2*nbins rounded up to a multiple of 4, pad columns
+ * zero) so that they are 16-byte aligned for the GEMM.  Requires n_fft/2 < T. */
+int segan_stft_pitch(int n_fft);
 int segan_stft_basis(float* basis, int n_fft, int win, void* stream);
 int segan_stft_frames(const float* x, float* frames, int B, int T, int n_fft, int hop, int win,
                       void* stream);
-/* db[r][k] = 10*log10(re^2 + im^2 + eps) of S[rows][2*nbins]  (eps = 10e-20, model.py:646) */
-int segan_powdb(const float* S, float* db, int64_t rows, int nbins, float eps, void* stream);
+/* db[r][k] = 10*log10(re^2 + im^2 + eps) of S[rows][pitch]  (eps = 10e-20, model.py:646) */
+int segan_powdb(const float* S, float* db, int64_t rows, int nbins, int pitch, float eps,
+                void* stream);
 /* dS = ddb * d(db)/d(re, im) */
-int segan_powdb_bwd(const float* S, const float* ddb, float* dS, int64_t rows, int nbins, float eps,
-                    void* stream);
+int segan_powdb_bwd(const float* S, const float* ddb, float* dS, int64_t rows, int nbins, int pitch,
+                    float eps, void* stream);
 /* dx[B][T] = adjoint of segan_stft_frames applied to dframes[B*NF][win] (overwrites dx) */
 int segan_stft_overlap_add(const float* dframes, float* dx, int B, int T, int n_fft, int hop,
                            int win, void* stream);

@@ -14,7 +14,7 @@ PAD_REFLECT = 0
 PAD_ZERO = 1
 ACT_NONE = 0
 ACT_TANH = 1
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class SeganSrc(Structure):
@@ -67,8 +67,9 @@ SIGNATURES = {
     'segan_pcm16_prep': (c_int, [_P, _P, _P, _P, c_int, c_int, c_double, _P]),
     'segan_stft_basis': (c_int, [_P, c_int, c_int, _P]),
     'segan_stft_frames': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
-    'segan_powdb': (c_int, [_P, _P, c_int64, c_int, c_float, _P]),
-    'segan_powdb_bwd': (c_int, [_P, _P, _P, c_int64, c_int, c_float, _P]),
+    'segan_stft_pitch': (c_int, [c_int]),
+    'segan_powdb': (c_int, [_P, _P, c_int64, c_int, c_int, c_float, _P]),
+    'segan_powdb_bwd': (c_int, [_P, _P, _P, c_int64, c_int, c_int, c_float, _P]),
     'segan_stft_overlap_add': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     'segan_rmsprop_step': (c_int, [_P, _P, _P, c_float, c_float, c_float, c_int64, _P]),
     'segan_adam_step': (c_int, [_P, _P, _P, _P, c_float, c_float, c_float, c_float, c_int, c_int64,

@@ -65,6 +65,133 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
   }
 }
 
+
+// ====================================================================================
+// 128 x 128 x 16 tile kernel for operands with a unit-stride dimension (every GEMM of the
+// dense head and of the STFT power loss has one): float4 global loads along that dimension,
+// k-major LDS tiles so the MFMA fragments are conflict-free ds_read_b32, register prefetch of
+// the next chunk, two LDS buffers, one barrier per chunk.  4 waves as 2 x 2, each 64 x 64.
+// AK / BK: that operand is contiguous along k (else along m resp. n).
+// ====================================================================================
+#define G2T 128
+#define G2K 16
+#define G2P (G2T + 4)
+
+template <bool AK, bool BKC>
+__global__ __launch_bounds__(256, 2) void gemm128_kernel(const float* __restrict__ A, long lda,
+                                                         const float* __restrict__ B, long ldb,
+                                                         float* __restrict__ C, long ldc, int M,
+                                                         int N, int K, int kper) {
+  __shared__ __attribute__((aligned(16))) float Al[2][G2K][G2P];
+  __shared__ __attribute__((aligned(16))) float Bl[2][G2K][G2P];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int m0 = blockIdx.y * G2T, n0 = blockIdx.x * G2T;
+  const int kbeg = blockIdx.z * kper;
+  const int kend = min(K, kbeg + kper);
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // staging: 2048 elements per operand and chunk = two float4 per thread.
+  //   k-contiguous operand: element (row r, k) at P[r*ld + k]; unit e -> (r = e / 4, k4 = e % 4)
+  //   row-contiguous operand: element (row r, k) at P[k*ld + r]; unit e -> (k = e / 32, r4 = e % 32)
+  f32x4 ra[2], rb[2];
+  auto load = [&](int k0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int e = tid + 256 * i;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (AK) {
+        const int r = m0 + e / 4, k = k0 + 4 * (e % 4);
+        if (r < M && k < kend) v = *reinterpret_cast<const f32x4*>(A + (long)r * lda + k);
+        if (k + 3 >= kend) {   // ragged end of the k range (kend % 4 != 0 never happens: host)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = (k + j < kend) ? v[j] : 0.f;
+        }
+      } else {
+        const int k = k0 + e / 32, r = m0 + 4 * (e % 32);
+        if (k < kend && r < M) v = *reinterpret_cast<const f32x4*>(A + (long)k * lda + r);
+      }
+      ra[i] = v;
+      f32x4 w = {0.f, 0.f, 0.f, 0.f};
+      if (BKC) {
+        const int c = n0 + e / 4, k = k0 + 4 * (e % 4);
+        if (c < N && k < kend) w = *reinterpret_cast<const f32x4*>(B + (long)c * ldb + k);
+      } else {
+        const int k = k0 + e / 32, c = n0 + 4 * (e % 32);
+        if (k < kend && c < N) w = *reinterpret_cast<const f32x4*>(B + (long)k * ldb + c);
+      }
+      rb[i] = w;
+    }
+  };
+  auto store = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int e = tid + 256 * i;
+      if (AK) {
+        const int r = e / 4, k = 4 * (e % 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Al[buf][k + j][r] = ra[i][j];
+      } else {
+        *reinterpret_cast<f32x4*>(&Al[buf][e / 32][4 * (e % 32)]) = ra[i];
+      }
+      if (BKC) {
+        const int c = e / 4, k = 4 * (e % 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Bl[buf][k + j][c] = rb[i][j];
+      } else {
+        *reinterpret_cast<f32x4*>(&Bl[buf][e / 32][4 * (e % 32)]) = rb[i];
+      }
+    }
+  };
+  if (kbeg >= kend) return;
+  load(kbeg);
+  store(0);
+  __syncthreads();
+  int buf = 0;
+  for (int k0 = kbeg; k0 < kend; k0 += G2K) {
+    const bool more = k0 + G2K < kend;
+    if (more) load(k0 + G2K);
+#pragma unroll
+    for (int s = 0; s < G2K / 2; ++s) {
+      float av[2], bv[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) av[i] = Al[buf][2 * s + h][wm * 64 + 32 * i + l31];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bv[j] = Bl[buf][2 * s + h][wn * 64 + 32 * j + l31];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) store(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  const bool atomic = gridDim.z > 1;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * 64 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int n = n0 + wn * 64 + 32 * j + l31;
+        if (m < M && n < N) {
+          float* c = C + (long)m * ldc + n;
+          if (atomic) atomicAdd(c, acc[i][j][e]);
+          else *c += acc[i][j][e];
+        }
+      }
+}
+
 extern "C" int segan_gemm(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk,
                           int64_t sbn, float* C, int64_t ldc, int M, int N, int K, int beta0,
                           void* stream) {
@@ -83,6 +210,29 @@ extern "C" int segan_gemm(const float* A, int64_t sam, int64_t sak, const float*
         segan_set_error("gemm: memset2d failed");
         return SEGAN_ELAUNCH;
       }
+    }
+  }
+  // fast path: both operands have a unit stride, 16-byte aligned rows, K a multiple of 4
+  {
+    const bool ak = sak == 1, am = sam == 1, bk = sbk == 1, bn = sbn == 1;
+    const long lda = ak ? sam : sak, ldb = bk ? sbn : sbk;
+    static const bool fast_on = [] { const char* e = getenv("SEGAN_GEMM128"); return !e || atoi(e) != 0; }();
+    if (fast_on && (ak || (am && M % 4 == 0)) && (bk || (bn && N % 4 == 0)) && K % 4 == 0 &&
+        lda % 4 == 0 && ldb % 4 == 0 &&
+        ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0 && (long)M * N >= 64 * 64) {
+      const int tm = ceil_div(M, G2T), tn = ceil_div(N, G2T);
+      int nsplit = ceil_div(512, tm * tn);
+      const int kchunks = ceil_div(K, G2K);
+      if (nsplit > kchunks / 4) nsplit = kchunks / 4;
+      if (nsplit < 1) nsplit = 1;
+      const int kper = ceil_div(kchunks, nsplit) * G2K;
+      nsplit = ceil_div(K, kper);
+      const dim3 grid(tn, tm, nsplit);
+#define G2(AKF, BKF) hipLaunchKernelGGL((gemm128_kernel<AKF, BKF>), grid, dim3(256), 0, st, A, lda, B, ldb, C, (long)ldc, M, N, K, kper)
+      // a k-contiguous view is preferred when both strides are 1 (degenerate 1-wide operands)
+      if (ak && bk) G2(true, true); else if (ak) G2(true, false); else if (bk) G2(false, true); else G2(false, false);
+#undef G2
+      return segan_check_launch("gemm128");
     }
   }
   const int tm = ceil_div(M, GT), tn = ceil_div(N, GT);

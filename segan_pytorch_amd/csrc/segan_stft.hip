@@ -19,18 +19,22 @@ static __device__ __forceinline__ int stft_reflect(int o, int T) {
   return o;
 }
 
-__global__ void stft_basis_kernel(float* __restrict__ basis, int n_fft, int win, int left, int nbins) {
+__global__ void stft_basis_kernel(float* __restrict__ basis, int n_fft, int win, int left, int nbins,
+                                  int pitch) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= win * nbins) return;
   const int j = idx / nbins, k = idx - j * nbins;
+  if (k < pitch - 2 * nbins) basis[(size_t)j * pitch + 2 * nbins + k] = 0.0f;   // pad columns
   // exact argument reduction in integers, then double precision sincospi
   const long m = ((long)k * (left + j)) % n_fft;
   double s, c;
   sincospi(2.0 * (double)m / (double)n_fft, &s, &c);
   const double nrm = 1.0 / sqrt((double)n_fft);
-  basis[(size_t)j * 2 * nbins + k] = (float)(c * nrm);
-  basis[(size_t)j * 2 * nbins + nbins + k] = (float)(-s * nrm);
+  basis[(size_t)j * pitch + k] = (float)(c * nrm);
+  basis[(size_t)j * pitch + nbins + k] = (float)(-s * nrm);
 }
+
+extern "C" int segan_stft_pitch(int n_fft) { return n_fft >= 2 ? round_up(2 * (n_fft / 2 + 1), 4) : 0; }
 
 extern "C" int segan_stft_basis(float* basis, int n_fft, int win, void* stream) {
   SEGAN_REQUIRE(basis, "stft_basis: NULL pointer");
@@ -38,7 +42,8 @@ extern "C" int segan_stft_basis(float* basis, int n_fft, int win, void* stream) 
   const int nbins = n_fft / 2 + 1;
   const int total = win * nbins;
   hipLaunchKernelGGL(stft_basis_kernel, dim3(ceil_div(total, 256)), dim3(256), 0,
-                     (hipStream_t)stream, basis, n_fft, win, (n_fft - win) / 2, nbins);
+                     (hipStream_t)stream, basis, n_fft, win, (n_fft - win) / 2, nbins,
+                     segan_stft_pitch(n_fft));
   return segan_check_launch("stft_basis");
 }
 
@@ -71,52 +76,56 @@ extern "C" int segan_stft_frames(const float* x, float* frames, int B, int T, in
 
 // db[r][k] = 10*log10(re^2 + im^2 + eps),  S rows are [re(0..nbins) | im(0..nbins)]
 __global__ void powdb_kernel(const float* __restrict__ S, float* __restrict__ db, size_t rows,
-                             int nbins, float eps) {
+                             int nbins, int pitch, float eps) {
   const size_t total = rows * nbins;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
        i += (size_t)gridDim.x * blockDim.x) {
     const size_t r = i / nbins;
     const int k = (int)(i - r * nbins);
-    const float re = S[r * 2 * nbins + k], im = S[r * 2 * nbins + nbins + k];
+    const float re = S[r * pitch + k], im = S[r * pitch + nbins + k];
     db[i] = 10.0f * log10f(fmaf(re, re, im * im) + eps);
   }
 }
 
-extern "C" int segan_powdb(const float* S, float* db, int64_t rows, int nbins, float eps,
+extern "C" int segan_powdb(const float* S, float* db, int64_t rows, int nbins, int pitch, float eps,
                            void* stream) {
+  SEGAN_REQUIRE(pitch >= 2 * nbins, "powdb: pitch < 2*nbins");
   SEGAN_REQUIRE(S && db, "powdb: NULL pointer");
   SEGAN_REQUIRE(rows > 0 && nbins > 0, "powdb: bad sizes");
   const size_t total = (size_t)rows * nbins;
   const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
   hipLaunchKernelGGL(powdb_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, S, db,
-                     (size_t)rows, nbins, eps);
+                     (size_t)rows, nbins, pitch, eps);
   return segan_check_launch("powdb");
 }
 
 // dS = ddb * d(10 log10(p + eps))/d(re, im) = ddb * (20/ln 10) * (re, im) / (p + eps)
 __global__ void powdb_bwd_kernel(const float* __restrict__ S, const float* __restrict__ ddb,
-                                 float* __restrict__ dS, size_t rows, int nbins, float eps) {
+                                 float* __restrict__ dS, size_t rows, int nbins, int pitch,
+                                 float eps) {
   const size_t total = rows * nbins;
   const float c = 8.685889638065035f;   // 20 / ln(10)
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
        i += (size_t)gridDim.x * blockDim.x) {
     const size_t r = i / nbins;
     const int k = (int)(i - r * nbins);
-    const float re = S[r * 2 * nbins + k], im = S[r * 2 * nbins + nbins + k];
+    const float re = S[r * pitch + k], im = S[r * pitch + nbins + k];
     const float g = ddb[i] * c / (fmaf(re, re, im * im) + eps);
-    dS[r * 2 * nbins + k] = g * re;
-    dS[r * 2 * nbins + nbins + k] = g * im;
+    dS[r * pitch + k] = g * re;
+    dS[r * pitch + nbins + k] = g * im;
+    if (k < pitch - 2 * nbins) dS[r * pitch + 2 * nbins + k] = 0.0f;   // pad columns
   }
 }
 
 extern "C" int segan_powdb_bwd(const float* S, const float* ddb, float* dS, int64_t rows, int nbins,
-                               float eps, void* stream) {
+                               int pitch, float eps, void* stream) {
+  SEGAN_REQUIRE(pitch >= 2 * nbins, "powdb_bwd: pitch < 2*nbins");
   SEGAN_REQUIRE(S && ddb && dS, "powdb_bwd: NULL pointer");
   SEGAN_REQUIRE(rows > 0 && nbins > 0, "powdb_bwd: bad sizes");
   const size_t total = (size_t)rows * nbins;
   const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
   hipLaunchKernelGGL(powdb_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, S, ddb, dS,
-                     (size_t)rows, nbins, eps);
+                     (size_t)rows, nbins, pitch, eps);
   return segan_check_launch("powdb_bwd");
 }
 

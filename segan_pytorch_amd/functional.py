@@ -585,8 +585,9 @@ class STFTPowL1Fn(torch.autograd.Function):
         y2 = y.reshape(shape[0], shape[-1]).contiguous()
         basis = ops.stft_basis(n_fft, win, x2.device)
         Sx = ops.stft_spectrum(ops.stft_frames(x2, n_fft, hop, win), basis)
-        dbx = ops.powdb(Sx)
-        dby = ops.powdb(ops.stft_spectrum(ops.stft_frames(y2, n_fft, hop, win), basis))
+        nb = n_fft // 2 + 1
+        dbx = ops.powdb(Sx, nb)
+        dby = ops.powdb(ops.stft_spectrum(ops.stft_frames(y2, n_fft, hop, win), basis), nb)
         ctx.save_for_backward(Sx, dbx, dby, basis)
         ctx.geom = (shape, n_fft, hop, win)
         return ops.l1_mean(dbx, dby)
@@ -596,6 +597,6 @@ class STFTPowL1Fn(torch.autograd.Function):
         Sx, dbx, dby, basis = ctx.saved_tensors
         shape, n_fft, hop, win = ctx.geom
         ddb = ops.l1_bwd(dbx, dby, gout=g.contiguous())
-        dfr = ops.stft_spectrum_bwd(ops.powdb_bwd(Sx, ddb), basis)
+        dfr = ops.stft_spectrum_bwd(ops.powdb_bwd(Sx, ddb, n_fft // 2 + 1), basis)
         dx = ops.stft_overlap_add(dfr, shape[0], shape[-1], n_fft, hop, win)
         return dx.view(shape), None, None, None, None

@@ -526,11 +526,17 @@ def l1_mean(x, y):
 _stft_basis_cache = {}
 
 
+def stft_pitch(n_fft):
+    """Row width of the basis / spectra: 2*(n_fft/2+1) rounded up to a multiple of 4."""
+    return (2 * (n_fft // 2 + 1) + 3) // 4 * 4
+
+
 def stft_basis(n_fft, win, device):
-    """[win, 2*(n_fft/2+1)] real DFT basis of a centred rectangular window (cached)."""
+    """[win, pitch] real DFT basis of a centred rectangular window (cached): columns
+    [0, nbins) real part, [nbins, 2*nbins) imaginary part, zero padding up to the pitch."""
     key = (n_fft, win, str(device))
     if key not in _stft_basis_cache:
-        bs = torch.empty((win, 2 * (n_fft // 2 + 1)), device=device, dtype=torch.float32)
+        bs = torch.empty((win, stft_pitch(n_fft)), device=device, dtype=torch.float32)
         check(_lib.load().segan_stft_basis(_ptr(bs), n_fft, win, _stream()), 'stft_basis')
         _stft_basis_cache[key] = bs
     return _stft_basis_cache[key]
@@ -548,7 +554,7 @@ def stft_frames(x, n_fft, hop, win):
 
 
 def stft_spectrum(frames, basis):
-    """frames [R, win] @ basis [win, 2*nbins] -> [R, 2*nbins] (real | imaginary)."""
+    """frames [R, win] @ basis [win, pitch] -> [R, pitch] (real | imaginary | zero pad)."""
     R, win = frames.shape
     N2 = basis.shape[1]
     S = torch.empty((R, N2), device=frames.device, dtype=torch.float32)
@@ -557,7 +563,7 @@ def stft_spectrum(frames, basis):
 
 
 def stft_spectrum_bwd(dS, basis):
-    """dS [R, 2*nbins] @ basis^T -> dframes [R, win]."""
+    """dS [R, pitch] @ basis^T -> dframes [R, win]."""
     R, N2 = dS.shape
     win = basis.shape[0]
     df = torch.empty((R, win), device=dS.device, dtype=torch.float32)
@@ -565,21 +571,21 @@ def stft_spectrum_bwd(dS, basis):
     return df
 
 
-def powdb(S, eps=10e-20):
+def powdb(S, nbins, eps=10e-20):
     _chk(S, 'S', 2)
-    rows, nb = S.shape[0], S.shape[1] // 2
-    db = torch.empty((rows, nb), device=S.device, dtype=torch.float32)
-    check(_lib.load().segan_powdb(_ptr(S), _ptr(db), rows, nb, eps, _stream()), 'powdb')
+    rows, pitch = S.shape
+    db = torch.empty((rows, nbins), device=S.device, dtype=torch.float32)
+    check(_lib.load().segan_powdb(_ptr(S), _ptr(db), rows, nbins, pitch, eps, _stream()), 'powdb')
     return db
 
 
-def powdb_bwd(S, ddb, eps=10e-20):
+def powdb_bwd(S, ddb, nbins, eps=10e-20):
     _chk(S, 'S', 2)
     _chk(ddb, 'ddb', 2)
-    rows, nb = S.shape[0], S.shape[1] // 2
+    rows, pitch = S.shape
     dS = torch.empty_like(S)
-    check(_lib.load().segan_powdb_bwd(_ptr(S), _ptr(ddb), _ptr(dS), rows, nb, eps, _stream()),
-          'powdb_bwd')
+    check(_lib.load().segan_powdb_bwd(_ptr(S), _ptr(ddb), _ptr(dS), rows, nbins, pitch, eps,
+                                      _stream()), 'powdb_bwd')
     return dS
 
 

@@ -248,7 +248,9 @@ def stft_basis(n_fft, win, device):
     left = (n_fft - win) // 2
     ang = 2 * math.pi * ((torch.arange(nb).view(1, -1) * (left + torch.arange(win)).view(-1, 1))
                          % n_fft).double() / n_fft
-    return (torch.cat((torch.cos(ang), -torch.sin(ang)), 1) / math.sqrt(n_fft)).float()
+    bs = (torch.cat((torch.cos(ang), -torch.sin(ang)), 1) / math.sqrt(n_fft)).float()
+    pitch = (2 * nb + 3) // 4 * 4
+    return torch.cat((bs, torch.zeros(win, pitch - 2 * nb)), 1)
 
 
 def stft_frames(x, n_fft, hop, win):
@@ -265,17 +267,16 @@ def stft_spectrum_bwd(dS, basis):
     return (dS.double() @ basis.double().t()).float()
 
 
-def powdb(S, eps=10e-20):
-    nb = S.shape[1] // 2
-    p = S[:, :nb].double() ** 2 + S[:, nb:].double() ** 2
+def powdb(S, nb, eps=10e-20):
+    p = S[:, :nb].double() ** 2 + S[:, nb:2 * nb].double() ** 2
     return (10 * torch.log10(p + eps)).float()
 
 
-def powdb_bwd(S, ddb, eps=10e-20):
-    nb = S.shape[1] // 2
-    re, im = S[:, :nb].double(), S[:, nb:].double()
+def powdb_bwd(S, ddb, nb, eps=10e-20):
+    re, im = S[:, :nb].double(), S[:, nb:2 * nb].double()
     g = ddb.double() * (20.0 / math.log(10.0)) / (re * re + im * im + eps)
-    return torch.cat((g * re, g * im), 1).float()
+    return torch.cat((g * re, g * im, torch.zeros(S.shape[0], S.shape[1] - 2 * nb,
+                                                 dtype=torch.float64)), 1).float()
 
 
 def stft_overlap_add(dframes, B, T, n_fft, hop, win):

@@ -542,7 +542,9 @@ def test_stft_pow_l1_matches_torch_stft(B, T, n_fft):
                     return_complex=True)            # [B, nbins, NF]
     nb = n_fft // 2 + 1
     NF = 1 + T // 160
-    Sc = torch.complex(S[:, :nb].double().cpu(), S[:, nb:].double().cpu()).view(B, NF, nb)
+    assert S.shape[1] == ops.stft_pitch(n_fft) and S.shape[1] % 4 == 0
+    assert float(S[:, 2 * nb:].abs().max()) == 0.0 if S.shape[1] > 2 * nb else True
+    Sc = torch.complex(S[:, :nb].double().cpu(), S[:, nb:2 * nb].double().cpu()).view(B, NF, nb)
     assert (Sc.transpose(1, 2) - st).abs().max().item() < 2e-5 * st.abs().max().item()
     # loss and gradient
     xg = x.to(DEV).requires_grad_(True)
@@ -588,3 +590,27 @@ def test_snorm_fwd_bwd_matches_torch(shape, dim, power_iteration):
     dw = torch.full(shape, 0.25, device=DEV)          # accumulates
     ops.snorm_bwd(g.to(DEV), w.to(DEV), ug, vg, sig, dim, dw)
     assert max_rel(dw - 0.25, wd.grad) < 5e-5
+
+
+@pytest.mark.parametrize('M,N,K', [(300, 256, 16384), (300, 16384, 256), (256, 16384, 300),
+                                   (1236, 2052, 320), (1236, 320, 2052), (130, 72, 64),
+                                   (64, 64, 16), (300, 128, 256), (37, 50, 100)])
+@pytest.mark.parametrize('a_kcontig,b_kcontig', [(True, True), (True, False), (False, True),
+                                                 (False, False)])
+def test_gemm_layouts(M, N, K, a_kcontig, b_kcontig):
+    """segan_gemm with every combination of operand layouts (k-contiguous or row-contiguous):
+    the 128x128 float4 kernel where its alignment conditions hold, the generic 64x64 kernel
+    otherwise; accumulate and overwrite semantics."""
+    ops = _ops()
+    A = rnd(M, K, seed=1)
+    Bm = rnd(K, N, seed=2)
+    ref = A.double() @ Bm.double()
+    Ad = (A if a_kcontig else A.t().contiguous()).to(DEV)        # [M,K] or [K,M]
+    Bd = (Bm.t().contiguous() if b_kcontig else Bm).to(DEV)       # [N,K] or [K,N]
+    sam, sak = (K, 1) if a_kcontig else (1, M)
+    sbk, sbn = (1, K) if b_kcontig else (N, 1)
+    C = torch.full((M, N), 7.0, device=DEV)
+    ops.gemm(Ad, sam, sak, Bd, sbk, sbn, C, M, N, K, True)
+    assert max_rel(C, ref) < TOL
+    ops.gemm(Ad, sam, sak, Bd, sbk, sbn, C, M, N, K, False)
+    assert max_rel(C, 2 * ref) < TOL
