@@ -396,12 +396,6 @@ __global__ void fold_halo_kernel(float* dx, const float* halo, int rows, int L, 
   }
 }
 
-// packed-weight geometry (shared by the pack kernels and the launchers)
-static inline int f_pitch(int M) { return M <= 64 ? 64 : round_up(M, 128); }
-static inline int f_rows(int N) { return round_up(N * 32, KCH); }
-static inline int t_pitch(int N, int S) { return S * t_np(N, S); }
-static inline int t_rows(int M, int S) { return round_up(M * (32 / S), KCH); }
-
 static bool streamk_enabled() {
   static const int env = [] { const char* e = getenv("SEGAN_STREAMK"); return e ? atoi(e) : 1; }();
   return env != 0;
@@ -557,664 +551,10 @@ static int launch_corr(CorrArgs& a, int U, hipStream_t st) {
   return SEGAN_EUNSUPPORTED;
 }
 
-// ====================================================================================
-// T form for 1-2 output channels (the HBM-bound edge layers: the generator's last deconv
-// Cout=1, and the data gradient of the first conv whose input has 1-2 channels).  With so
-// few output channels an MFMA tile would be >90 % padding, so this is a direct VALU kernel:
-// one thread per low-rate position q computes all S phases x N channels, the input window
-// comes from an LDS tile (with the segan_src transform applied while staging) and the taps
-// are wave-uniform scalar loads.
-// ====================================================================================
-// KT: kernel width known at compile time (31, the SEGAN width: the taps then sit at constant
-// offsets and the scalar loads merge into s_load_dwordx8/x16) or 0 = runtime K.
-template <int S, int N, int PM, int KT>
-__global__ __launch_bounds__(256) void tsmall_kernel(const CorrArgs a, const float* __restrict__ w,
-                                                     int Krt, int M) {
-  const int K = KT ? KT : Krt;
-  constexpr int U = 32 / S;
-  constexpr int MC = 16;                 // input channels per LDS chunk
-  constexpr int TW = 256 + U;            // window: 256 positions + (U-1) taps + 1 phase shift
-  __shared__ float xs[MC][TW + 1];
-  const int tid = threadIdx.x;
-  const int b = blockIdx.y;
-  const int q0 = blockIdx.x * 256;
-  const int q = q0 + tid;
-  // window coordinate j <-> input time t = q0 + win_start + j   (win_start = cmin - (U-1))
-  float acc[S][N];
-#pragma unroll
-  for (int r = 0; r < S; ++r)
-#pragma unroll
-    for (int n = 0; n < N; ++n) acc[r][n] = 0.0f;
-
-  // staging: thread owns window positions tid and 256 + tid (the latter only for tid < U);
-  // addresses are clamped so the loads are unconditional
-  const int t0 = q0 + a.win_start + tid, t1 = t0 + 256;
-  const bool ok0 = t0 >= 0 && t0 < a.Lin, ok1 = tid < U && t1 >= 0 && t1 < a.Lin;
-  const int o0 = ok0 ? t0 : 0, o1 = ok1 ? t1 : 0;
-  const int bo0 = b * a.in.C0 * a.Lin, bo1 = b * a.in.C1 * a.Lin;
-  for (int mc0 = 0; mc0 < M; mc0 += MC) {
-#pragma unroll 8
-    for (int mc = 0; mc < MC; ++mc) {
-      const int m = mc0 + mc < M ? mc0 + mc : 0;
-      const bool seg1 = m >= a.in.C0;
-      const float* rowp = seg1 ? a.in.p1 + (size_t)(m - a.in.C0) * a.Lin + bo1
-                               : a.in.p0 + (size_t)m * a.Lin + bo0;
-      const ChanXf xf = segan_chan_xf(a.in, m);
-      const float v0 = rowp[o0], v1 = rowp[o1];
-      const bool mok = mc0 + mc < M;
-      xs[mc][tid] = (mok && ok0) ? segan_apply_xf(xf, v0) : 0.0f;
-      if (tid < U) xs[mc][256 + tid] = (mok && ok1) ? segan_apply_xf(xf, v1) : 0.0f;
-    }
-    __syncthreads();
-    const int mcn = min(MC, M - mc0);
-    for (int mc = 0; mc < mcn; ++mc) {
-      float xv[U + 1];
-#pragma unroll
-      for (int j = 0; j <= U; ++j) xv[j] = xs[mc][tid + j];
-      // taps are wave-uniform: scalar loads straight into SGPR operands of the FMAs; tap
-      // indices are clamped and the value selected to zero for k >= K (no branches)
-      const float* wm = w + (size_t)(mc0 + mc) * N * K;
-#pragma unroll
-      for (int r = 0; r < S; ++r) {
-        const int rho = (r + PM) % S;     // tap phase of output phase r
-        const int cs = (r + PM) / S;      // 0/1: extra input shift of this phase
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int k = S * u + rho;
-          if (KT) {
-            if (k < KT) {
-#pragma unroll
-              for (int n = 0; n < N; ++n)
-                acc[r][n] = fmaf(wm[n * KT + k], xv[cs + (U - 1) - u], acc[r][n]);
-            }
-          } else {
-            const int kc = k < K ? k : K - 1;
-#pragma unroll
-            for (int n = 0; n < N; ++n) {
-              float wv = wm[n * K + kc];
-              wv = k < K ? wv : 0.0f;
-              acc[r][n] = fmaf(wv, xv[cs + (U - 1) - u], acc[r][n]);
-            }
-          }
-        }
-      }
-    }
-    __syncthreads();
-  }
-  if (q >= a.Tcols) return;
-#pragma unroll
-  for (int r = 0; r < S; ++r)
-#pragma unroll
-    for (int n = 0; n < N; ++n) {
-      float v = acc[r][n] + (a.bias ? a.bias[n] : 0.0f);
-      if (a.act == SEGAN_ACT_TANH) v = tanhf(v);
-      const int P = S * q + r;
-      int ii = P - a.o_padL;
-      const size_t rowoff = (size_t)b * N + n;
-      if (ii >= 0 && ii < a.Lout) {
-        if (a.o_roll != 0) {
-          ii -= a.o_roll;
-          if (ii < 0) ii += a.Lout;
-          if (ii >= a.Lout) ii -= a.Lout;
-        }
-        a.out0[rowoff * (size_t)a.Lout + ii] = v;
-      } else if (a.halo != nullptr) {
-        const int hl = a.o_padL + a.o_padR;
-        if (ii < 0) a.halo[rowoff * hl + P] = v;
-        else if (ii - a.Lout < a.o_padR) a.halo[rowoff * hl + a.o_padL + (ii - a.Lout)] = v;
-      }
-    }
-}
-
-template <int S, int N, int KT>
-static int launch_tsmall_snk(const CorrArgs& a, const float* w, int K, int M, int pad,
-                             hipStream_t st) {
-  dim3 grid(ceil_div(a.Tcols, 256), a.B);
-  switch (pad % S) {
-    case 0: hipLaunchKernelGGL((tsmall_kernel<S, N, 0, KT>), grid, dim3(256), 0, st, a, w, K, M); break;
-    case 1: hipLaunchKernelGGL((tsmall_kernel<S, N, 1 % S, KT>), grid, dim3(256), 0, st, a, w, K, M); break;
-    case 2: hipLaunchKernelGGL((tsmall_kernel<S, N, 2 % S, KT>), grid, dim3(256), 0, st, a, w, K, M); break;
-    default: hipLaunchKernelGGL((tsmall_kernel<S, N, 3 % S, KT>), grid, dim3(256), 0, st, a, w, K, M); break;
-  }
-  return segan_check_launch("tsmall_kernel");
-}
-
-template <int S, int N>
-static int launch_tsmall_sn(const CorrArgs& a, const float* w, int K, int M, int pad,
-                            hipStream_t st) {
-  if (K == 31) return launch_tsmall_snk<S, N, 31>(a, w, K, M, pad, st);
-  return launch_tsmall_snk<S, N, 0>(a, w, K, M, pad, st);
-}
-
-// `a` is filled exactly as for the MFMA T form; w is the UNPACKED weight [M][N][K]
-static int launch_tsmall(CorrArgs& a, const float* w, int K, int M, int N, int S, int pad,
-                         hipStream_t st) {
-  if (int e = segan_src_defaults(&a.in, st, "tsmall")) return e;
-  if (N == 1) {
-    if (S == 4) return launch_tsmall_sn<4, 1>(a, w, K, M, pad, st);
-    if (S == 2) return launch_tsmall_sn<2, 1>(a, w, K, M, pad, st);
-    return launch_tsmall_sn<1, 1>(a, w, K, M, pad, st);
-  }
-  if (S == 4) return launch_tsmall_sn<4, 2>(a, w, K, M, pad, st);
-  if (S == 2) return launch_tsmall_sn<2, 2>(a, w, K, M, pad, st);
-  return launch_tsmall_sn<1, 2>(a, w, K, M, pad, st);
-}
-
 
 // ====================================================================================
-// F form for 1-2 input channels (the first conv of G and of D: HBM-bound, and an MFMA tile
-// whose contraction is N*32 <= 64 deep would be mostly the padding to the 64-deep LDS chunk).
-// Direct VALU kernel: a workgroup owns 256 output positions of one sample, stages the padded
-// input window once (reflect / roll / transform applied while staging) and walks the output
-// channels with the taps read as 16-byte LDS broadcasts from a zero-padded [m][n][32] copy of
-// the packed weights.  Stores are coalesced along time.
+// C ABI: forward and data-gradient entry points
 // ====================================================================================
-template <int S, int N>
-__global__ __launch_bounds__(256) void fsmall_kernel(const CorrArgs a, int M) {
-  constexpr int U = 32 / S;
-  constexpr int XW = S * 256 + 32;
-  constexpr int WST = N * 32 + 4;          // row stride of the weight copy (16-B aligned)
-  __shared__ __attribute__((aligned(16))) float xs[N][XW];
-  __shared__ __attribute__((aligned(16))) float ws[64 * WST];
-  const int tid = threadIdx.x;
-  const int b = blockIdx.y;
-  const int t0 = blockIdx.x * 256;
-  for (int j = tid; j < XW; j += 256) {
-    const int idx = segan_hi_index(S * t0 + j, a.Lin, a.padL, a.mode, a.roll);
-#pragma unroll
-    for (int n = 0; n < N; ++n) {
-      float v = 0.0f;
-      if (idx >= 0) v = segan_apply_xf(segan_chan_xf(a.in, n), segan_src_row(a.in, b, n, a.Lin)[idx]);
-      xs[n][j] = v;
-    }
-  }
-  const int t = t0 + tid;
-  for (int m0 = 0; m0 < M; m0 += 64) {
-    // packed F layout: w[m][n][S*u + r] = wp[((n*S + r)*U + u) * RP + m]; rows of taps >= K
-    // are zero.  Lanes run along m so the global reads are coalesced.
-    for (int e = tid; e < 64 * N * 32; e += 256) {
-      const int ml = e & 63, nk = e >> 6;
-      const int n = nk >> 5, k = nk & 31;
-      const int row = (n * S + k % S) * U + k / S;
-      const int m = m0 + ml;
-      ws[ml * WST + n * 32 + k] = m < a.RP ? a.wp[(size_t)row * a.RP + m] : 0.0f;
-    }
-    __syncthreads();
-    float xv[N][32];
-#pragma unroll
-    for (int n = 0; n < N; ++n) {
-      if (S == 4) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const f32x4 v = *reinterpret_cast<const f32x4*>(&xs[n][4 * tid + 4 * i]);
-          xv[n][4 * i] = v[0]; xv[n][4 * i + 1] = v[1]; xv[n][4 * i + 2] = v[2]; xv[n][4 * i + 3] = v[3];
-        }
-      } else {
-#pragma unroll
-        for (int k = 0; k < 32; ++k) xv[n][k] = xs[n][S * tid + k];
-      }
-    }
-    const int mcn = min(64, M - m0);
-    for (int ml = 0; ml < mcn; ++ml) {
-      float acc = a.bias ? a.bias[m0 + ml] : 0.0f;
-#pragma unroll
-      for (int n = 0; n < N; ++n) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const f32x4 wv = *reinterpret_cast<const f32x4*>(&ws[ml * WST + n * 32 + 4 * i]);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc = fmaf(wv[e], xv[n][4 * i + e], acc);
-        }
-      }
-      if (t < a.Lout) a.out0[((size_t)b * M + m0 + ml) * a.Lout + t] = acc;
-    }
-    __syncthreads();
-  }
-}
-
-static int launch_fsmall(CorrArgs& a, int M, int N, int S, hipStream_t st) {
-  if (int e = segan_src_defaults(&a.in, st, "fsmall")) return e;
-  dim3 grid(ceil_div(a.Lout, 256), a.B);
-#define FS(SS, NN) hipLaunchKernelGGL((fsmall_kernel<SS, NN>), grid, dim3(256), 0, st, a, M)
-  if (N == 1) { if (S == 4) FS(4, 1); else if (S == 2) FS(2, 1); else FS(1, 1); }
-  else { if (S == 4) FS(4, 2); else if (S == 2) FS(2, 2); else FS(1, 2); }
-#undef FS
-  return segan_check_launch("fsmall_kernel");
-}
-
-// ====================================================================================
-// wgrad kernel
-// ====================================================================================
-
-// x / Ls for 0 <= x < Ls + TK (Ls >= TK: one compare; else exact multiply-shift, x < 64)
-template <int TK>
-__device__ __forceinline__ int wg_sdiv(int x, int Ls, int magic) {
-  return (Ls >= TK) ? (x >= Ls ? 1 : 0) : ((x * magic) >> 16);
-}
-
-// dW[m][n][S*u+r] += sum over the flattened (sample, time) columns.  Block tile: 128 rows
-// (m) x 128 columns ((n,r),u = 128/U virtual channels x U taps), contraction chunks of TK
-// columns, double buffered.  LO_ID / HI_ID: that operand has the identity transform (the
-// gradient operand always has), so its staging is a plain copy.
-// MB x NBT: the block tile (128 x 128, or 64 x 64 for the first layers whose M <= 64 rows and
-// N*S <= 64/U virtual channels would leave 3/4 and more of the big tile empty).
-template <int U, int TK, bool LO_ID, bool HI_ID, int MB, int NBT>
-__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
-  constexpr int S = 32 / U;
-  constexpr int CVW = NBT / U;       // virtual channels per block (NBT output columns)
-  constexpr int NI = MB / 64, NJ = NBT / 64;   // 32x32 MFMA blocks per wave (2 x 2 waves)
-  constexpr int NN = CVW / S;        // real hi channels per block
-  constexpr int AST = TK + 4;        // lo row stride: 16-B aligned rows, conflict-free b128 reads
-  constexpr int NJ8 = TK / 8;        // groups of 8 contraction columns
-
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int RLw = a.RLw;
-  float* Al0 = smem;                  // [2][MB*AST]
-  float* Bl0 = Al0 + 2 * MB * AST;    // [2][CVW*RLw]
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int l31 = lane & 31, h = lane >> 5;
-
-  if (a.prio_mode == 1) {
-    const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-    const unsigned hsh = (lin * 2654435761u) >> 30;
-    if (hsh == 1) __builtin_amdgcn_s_setprio(1);
-    else if (hsh == 2) __builtin_amdgcn_s_setprio(2);
-    else if (hsh == 3) __builtin_amdgcn_s_setprio(3);
-  }
-  const int cv0 = blockIdx.x * CVW;
-  const int m0 = blockIdx.y * MB;
-  const int split_beg = blockIdx.z * a.cols_per_split;
-  const int split_end = min(split_beg + a.cols_per_split, a.Ctot);
-  if (split_beg >= split_end) return;
-  const int nch = (split_end - split_beg + TK - 1) / TK;
-  const int Ls = a.Ls;
-
-  // ---- MFMA operand offsets.  Lane (row/col l31, half h) supplies contraction columns
-  // k' = 8j + 4h + i (i = 0..3) of group j: one ds_read_b128 of the lo tile per row block.
-  int aoff[NI], bbase[NJ];
-#pragma unroll
-  for (int i = 0; i < NI; ++i) aoff[i] = (wm * (MB / 2) + 32 * i + l31) * AST + 4 * h;
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    const int cc = wn * (NBT / 2) + 32 * j + l31;
-    bbase[j] = (cc / U) * RLw + cc % U;
-  }
-
-  f32x16 acc[NI][NJ];
-#pragma unroll
-  for (int i = 0; i < NI; ++i)
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-
-  // ---- lo staging: thread owns one float4 (4 consecutive columns; Ls % 4 == 0 keeps them
-  // in one sample) of rows ar0 + RPA*i.  Row bases / transforms never change.
-  constexpr int F4A = TK / 4;
-  constexpr int RPA = 256 / F4A;
-  constexpr int NPA = MB / RPA;
-  const int kc4 = tid % F4A, ar0 = tid / F4A;
-  const float* arow[NPA];
-  bool arow_ok[NPA], arow_s1[NPA];
-  ChanXf axf[NPA];
-#pragma unroll
-  for (int i = 0; i < NPA; ++i) {
-    int m = m0 + ar0 + RPA * i;
-    arow_ok[i] = m < a.M;
-    m = arow_ok[i] ? m : 0;
-    arow_s1[i] = m >= a.lo.C0;
-    arow[i] = arow_s1[i] ? a.lo.p1 + (size_t)(m - a.lo.C0) * Ls : a.lo.p0 + (size_t)m * Ls;
-    if (!LO_ID) axf[i] = segan_chan_xf(a.lo, m);
-  }
-  // ---- hi staging: thread owns LDS position tid (< RLw <= 256) of all CVW channels
-  const float* brow[NN];
-  bool brow_s1[NN];
-  ChanXf bxf[NN];
-#pragma unroll
-  for (int c = 0; c < NN; ++c) {
-    int n = cv0 / S + c;
-    n = n < a.N ? n : 0;
-    brow_s1[c] = n >= a.hi.C0;
-    brow[c] = brow_s1[c] ? a.hi.p1 + (size_t)(n - a.hi.C0) * a.Lhi : a.hi.p0 + (size_t)n * a.Lhi;
-    if (!HI_ID) bxf[c] = segan_chan_xf(a.hi, n);
-  }
-
-  f32x4 areg[NPA];
-  float breg[CVW];
-  bool a_ok = false;
-  unsigned b_ok = 0u;
-
-  auto load_chunk = [&](int ch) {
-    const int col0 = split_beg + ch * TK;
-    const int b0 = col0 / Ls;
-    const int t_first = col0 - b0 * Ls;
-    // ---- lo ----
-    {
-      const int c4 = 4 * kc4;
-      a_ok = col0 + c4 < split_end;
-      const int x = t_first + c4;
-      const int sd = wg_sdiv<TK>(x, Ls, a.ls_magic);
-      int bb = b0 + sd;
-      bb = (a_ok && bb < a.B) ? bb : 0;
-      const int t = x - sd * Ls;
-      const int o0 = bb * a.lo.C0 * Ls + t, o1 = bb * a.lo.C1 * Ls + t;
-#pragma unroll
-      for (int i = 0; i < NPA; ++i)
-        areg[i] = *reinterpret_cast<const f32x4*>(arow[i] + (arow_s1[i] ? o1 : o0));
-    }
-    // ---- hi ----
-    int s = 0, tau = 0;
-    if (Ls >= TK) {
-      const int len0 = min(Ls - t_first, TK);
-      if (tid < len0 + a.H) { s = 0; tau = t_first + tid; }
-      else { s = 1; tau = tid - (len0 + a.H); }
-    } else {
-      // chunks start on a sample boundary only when Ls divides TK; general decode otherwise
-      const int len0 = min(Ls - t_first, TK);
-      if (tid < len0 + a.H) { s = 0; tau = t_first + tid; }
-      else {
-        const int jj = tid - (len0 + a.H);
-        const int q = (jj * a.per_magic) >> 16;
-        s = 1 + q;
-        tau = jj - q * (Ls + a.H);
-      }
-    }
-    const int bs = b0 + s;
-    const bool bok = tid < RLw && bs < a.B;
-    const int bsc = bok ? bs : 0;
-    const int so0 = bsc * a.hi.C0 * a.Lhi, so1 = bsc * a.hi.C1 * a.Lhi;
-    int poff[S];
-    b_ok = 0u;
-#pragma unroll
-    for (int r = 0; r < S; ++r) {
-      const int idx = segan_hi_index(S * tau + r, a.Lhi, a.padL, a.mode, a.roll);
-      poff[r] = (bok && idx >= 0) ? idx : 0;
-      if (bok && idx >= 0) b_ok |= 1u << r;
-    }
-#pragma unroll
-    for (int c = 0; c < CVW; ++c)
-      breg[c] = brow[c / S][(brow_s1[c / S] ? so1 : so0) + poff[c % S]];
-  };
-  auto store_chunk = [&](int buf) {
-    float* Al = Al0 + buf * (MB * AST);
-    float* Bl = Bl0 + buf * (CVW * RLw);
-#pragma unroll
-    for (int i = 0; i < NPA; ++i) {
-      const bool ok = a_ok && arow_ok[i];
-      f32x4 v = areg[i];
-      if (!LO_ID) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = segan_apply_xf(axf[i], v[e]);
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.0f;
-      *reinterpret_cast<f32x4*>(Al + (ar0 + RPA * i) * AST + 4 * kc4) = v;
-    }
-    if (tid < RLw) {
-#pragma unroll
-      for (int c = 0; c < CVW; ++c) {
-        const bool ok = (cv0 + c) < a.Cv && ((b_ok >> (c % S)) & 1u);
-        float v = breg[c];
-        if (!HI_ID) v = segan_apply_xf(bxf[c / S], v);
-        Bl[c * RLw + tid] = ok ? v : 0.0f;
-      }
-    }
-  };
-
-  load_chunk(0);
-  store_chunk(0);
-  __syncthreads();
-  for (int ch = 0; ch < nch; ++ch) {
-    const int buf = ch & 1;
-    if (ch + 1 < nch) load_chunk(ch + 1);
-    const float* Al = Al0 + buf * (MB * AST);
-    const float* Bl = Bl0 + buf * (CVW * RLw);
-    // LDS position of contraction column k' = 8j + 4h (+i): sample s of the chunk sits s*H
-    // further right; 4 | Ls keeps the 4 columns of a group in one sample.
-    const int t_first = (split_beg + ch * TK) % Ls;
-    int bpos[NJ8][NJ];
-#pragma unroll
-    for (int j = 0; j < NJ8; ++j) {
-      const int k0 = 8 * j + 4 * h;
-      const int p = k0 + wg_sdiv<TK>(t_first + k0, Ls, a.ls_magic) * a.H;
-#pragma unroll
-      for (int jj = 0; jj < NJ; ++jj) bpos[j][jj] = bbase[jj] + p;
-    }
-    f32x4 af0[NI], af1[NI];
-    float bv0[NJ], bv1[NJ];
-    auto read_a = [&](int j, f32x4 (&af)[NI]) {
-#pragma unroll
-      for (int i = 0; i < NI; ++i) af[i] = *reinterpret_cast<const f32x4*>(Al + aoff[i] + 8 * j);
-    };
-    auto read_b = [&](int s, float (&bv)[NJ]) {
-#pragma unroll
-      for (int jj = 0; jj < NJ; ++jj) bv[jj] = Bl[bpos[s / 4][jj] + (s & 3)];
-    };
-    auto mma = [&](const f32x4 (&af)[NI], int e, const float (&bv)[NJ]) {
-#pragma unroll
-      for (int i = 0; i < NI; ++i)
-#pragma unroll
-        for (int jj = 0; jj < NJ; ++jj)
-          acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bv[jj], acc[i][jj], 0, 0, 0);
-    };
-    read_a(0, af0);
-    read_b(0, bv0);
-#define SB __builtin_amdgcn_sched_barrier(0)
-#pragma unroll
-    for (int j = 0; j < NJ8; j += 2) {
-      // group j (af0), then group j+1 (af1); B one step ahead in alternating sets; the
-      // sched_barriers pin "next reads, then this step's MFMAs"
-      read_a(j + 1, af1);
-      read_b(4 * j + 1, bv1); SB; mma(af0, 0, bv0); SB;
-      read_b(4 * j + 2, bv0); SB; mma(af0, 1, bv1); SB;
-      read_b(4 * j + 3, bv1); SB; mma(af0, 2, bv0); SB;
-      read_b(4 * j + 4, bv0); SB; mma(af0, 3, bv1); SB;
-      if (j + 2 < NJ8) read_a(j + 2, af0);
-      read_b(4 * j + 5, bv1); SB; mma(af1, 0, bv0); SB;
-      read_b(4 * j + 6, bv0); SB; mma(af1, 1, bv1); SB;
-      read_b(4 * j + 7, bv1); SB; mma(af1, 2, bv0); SB;
-      if (4 * j + 8 < TK / 2) read_b(4 * j + 8, bv0);
-      SB; mma(af1, 3, bv1); SB;
-    }
-#undef SB
-    if (ch + 1 < nch) store_chunk(buf ^ 1);
-    __syncthreads();
-  }
-
-  // ---- epilogue: dw[m][n][S*u + r] += acc ----
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    const int cc = wn * (NBT / 2) + 32 * j + l31;
-    const int cv = cv0 + cc / U;
-    const int u = cc % U;
-    const int n = cv / S, r = cv % S;
-    const int k = S * u + r;
-    if (cv >= a.Cv || k >= a.K) continue;
-#pragma unroll
-    for (int i = 0; i < NI; ++i)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int m = m0 + wm * (MB / 2) + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (m < a.M) atomicAdd(a.dw + ((size_t)m * a.N + n) * a.K + k, acc[i][j][e]);
-      }
-  }
-}
-
-template <int U, bool LO_ID, bool HI_ID, int MB, int NBT>
-static int launch_wgrad_tile(WgradArgs& a, hipStream_t st) {
-  constexpr int CVW = NBT / U;
-  constexpr int TK = 32;
-  int NS;
-  if (a.Ls >= TK) NS = (a.Ls % TK == 0) ? 1 : 2;
-  else NS = (TK % a.Ls == 0) ? TK / a.Ls : (TK + a.Ls - 2) / a.Ls + 1;
-  a.H = U - 1;
-  a.RLw = TK + NS * a.H;
-  // row stride = 8 (mod 32): the 4 channels x 8 taps a half-wave reads hit 32 distinct banks
-  a.RLw += (8 - a.RLw % 32 + 32) % 32;
-  if (a.RLw > 256 || a.Ls % 4 != 0) {
-    segan_set_error("wgrad: low-rate length %d unsupported for stride %d (needs a multiple of 4, "
-                    "and >= %d)", a.Ls, 32 / U, U / 2);
-    return SEGAN_EUNSUPPORTED;
-  }
-  if ((long)a.B * a.M * a.Ls >= (1L << 31) || (long)a.B * a.N * a.Lhi >= (1L << 31)) {
-    segan_set_error("wgrad: operand exceeds the 2^31 element indexing limit");
-    return SEGAN_EUNSUPPORTED;
-  }
-  if (int e = segan_src_defaults(&a.lo, st, "wgrad(lo)")) return e;
-  if (int e = segan_src_defaults(&a.hi, st, "wgrad(hi)")) return e;
-  static const int prio_env = [] { const char* e = getenv("SEGAN_PRIO"); return e ? atoi(e) : 0; }();
-  a.prio_mode = prio_env;
-  a.ls_magic = (65536 + a.Ls - 1) / a.Ls;
-  a.per_magic = (65536 + a.Ls + a.H - 1) / (a.Ls + a.H);
-  const int ncol = ceil_div(a.Cv, CVW);
-  const int nrow = ceil_div(a.M, MB);
-  // split the (b,t) contraction so the grid has a few workgroups per CU
-  const int tiles = ncol * nrow;
-  const int chunks = ceil_div(a.Ctot, TK);
-  static const int tgt_env = [] { const char* e = getenv("SEGAN_WGRAD_BLOCKS"); return e ? atoi(e) : 0; }();
-  int nsplit = ceil_div(tgt_env > 0 ? tgt_env : 1536, tiles);
-  if (nsplit > chunks / 4) nsplit = chunks / 4;   // at least 4 chunks per workgroup
-  if (nsplit < 1) nsplit = 1;
-  const int chunks_per = ceil_div(chunks, nsplit);
-  nsplit = ceil_div(chunks, chunks_per);
-  a.cols_per_split = chunks_per * TK;
-  const size_t lds = (size_t)(2 * MB * (TK + 4) + 2 * CVW * a.RLw) * sizeof(float);
-  auto kern = wgrad_kernel<U, TK, LO_ID, HI_ID, MB, NBT>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
-  }
-  hipLaunchKernelGGL(kern, dim3(ncol, nrow, nsplit), dim3(256), lds, st, a);
-  return segan_check_launch("wgrad_kernel");
-}
-
-template <int U, bool LO_ID, bool HI_ID>
-static int launch_wgrad_x(WgradArgs& a, hipStream_t st) {
-  static const bool small_on = [] { const char* e = getenv("SEGAN_WGRAD_SMALL"); return !e || atoi(e) != 0; }();
-  // edge layers (1-2 channels on the hi side: N*S <= 64/U virtual channels): 64 columns
-  // suffice, and 64 rows when M <= 64
-  if (small_on && a.Cv <= 64 / U) {
-    if (a.M <= 64) return launch_wgrad_tile<U, LO_ID, HI_ID, 64, 64>(a, st);
-    return launch_wgrad_tile<U, LO_ID, HI_ID, 128, 64>(a, st);
-  }
-  return launch_wgrad_tile<U, LO_ID, HI_ID, 128, 128>(a, st);
-}
-
-template <int U>
-static int launch_wgrad_t(WgradArgs& a, hipStream_t st) {
-  const bool lo_id = !a.lo.scale && !a.lo.shift && !a.lo.slope;
-  const bool hi_id = !a.hi.scale && !a.hi.shift && !a.hi.slope;
-  if (lo_id && hi_id) return launch_wgrad_x<U, true, true>(a, st);
-  if (lo_id) return launch_wgrad_x<U, true, false>(a, st);
-  if (hi_id) return launch_wgrad_x<U, false, true>(a, st);
-  return launch_wgrad_x<U, false, false>(a, st);
-}
-
-// ====================================================================================
-// weight packing
-// ====================================================================================
-// Both packings are [*, K] -> [K', *] transposes of a 64 x 32 tile through LDS so that the
-// global reads (31 contiguous taps per (m,n)) and the writes (64 contiguous m / n) are both
-// coalesced.  grid.x = tiles of 64 along the transposed axis, grid.y = the other axis.
-__global__ __launch_bounds__(256) void pack_f_kernel(const float* __restrict__ w,
-                                                     float* __restrict__ wf, int M, int N, int K,
-                                                     int S, int U, int pitch, int rows) {
-  __shared__ float t[64][33];
-  const int n = blockIdx.y;                 // may run past N into the zero padding rows
-  const int m0 = blockIdx.x * 64;
-  const int tid = threadIdx.x;
-  for (int e = tid; e < 64 * 32; e += 256) {
-    const int ml = e >> 5, k = e & 31;
-    const int m = m0 + ml;
-    t[ml][k] = (m < M && n < N && k < K) ? w[((size_t)m * N + n) * K + k] : 0.0f;
-  }
-  __syncthreads();
-  for (int e = tid; e < 32 * 64; e += 256) {
-    const int kk = e >> 6, ml = e & 63;     // kk = r*U + u  ->  tap k = S*u + r
-    const int r = kk / U, u = kk - r * U;
-    const int row = (n * S + r) * U + u;
-    if (row < rows && m0 + ml < pitch) wf[(size_t)row * pitch + m0 + ml] = t[ml][S * u + r];
-  }
-}
-
-__global__ __launch_bounds__(256) void pack_t_kernel(const float* __restrict__ w,
-                                                     float* __restrict__ wt, int M, int N, int K,
-                                                     int S, int U, int NP, int pad, int pitch,
-                                                     int rows) {
-  __shared__ float t[64][33];
-  const int m = blockIdx.y;                 // may run past M into the zero padding rows
-  const int n0 = blockIdx.x * 64;
-  const int tid = threadIdx.x;
-  for (int e = tid; e < 64 * 32; e += 256) {
-    const int nl = e >> 5, k = e & 31;
-    const int n = n0 + nl;
-    t[nl][k] = (m < M && n < N && k < K) ? w[((size_t)m * N + n) * K + k] : 0.0f;
-  }
-  __syncthreads();
-  for (int e = tid; e < 32 * 64; e += 256) {
-    const int kk = e >> 6, nl = e & 63;     // kk = u'*S + r
-    const int up = kk / S, r = kk - up * S;
-    const int rho = (r + pad) % S;
-    const int k = S * (U - 1 - up) + rho;   // < 32 always; taps >= K hold zeros in t
-    const int row = m * U + up;
-    const int n = n0 + nl;
-    if (row < rows && n < NP) wt[(size_t)row * pitch + r * NP + n] = t[nl][k];
-  }
-}
-
-// ====================================================================================
-// C ABI
-// ====================================================================================
-static bool stride_ok(int S) { return S == 1 || S == 2 || S == 4; }
-
-extern "C" size_t segan_packed_f_bytes(int M, int N, int S) {
-  if (!stride_ok(S) || M <= 0 || N <= 0) return 0;
-  return (size_t)f_rows(N) * f_pitch(M) * sizeof(float);
-}
-extern "C" size_t segan_packed_t_bytes(int M, int N, int S) {
-  if (!stride_ok(S) || M <= 0 || N <= 0) return 0;
-  return (size_t)t_rows(M, S) * t_pitch(N, S) * sizeof(float);
-}
-
-extern "C" int segan_pack_weights(const float* w, float* wf, float* wt, int M, int N, int K, int S,
-                                  int pad_t, void* stream) {
-  SEGAN_REQUIRE(w != nullptr, "pack_weights: w is NULL");
-  SEGAN_REQUIRE(stride_ok(S), "pack_weights: stride %d not in {1,2,4}", S);
-  SEGAN_REQUIRE(K >= 1 && K <= 32, "pack_weights: kernel width %d not in [1,32]", K);
-  SEGAN_REQUIRE(M > 0 && N > 0, "pack_weights: bad channel counts %d,%d", M, N);
-  SEGAN_REQUIRE(pad_t >= 0, "pack_weights: negative padding");
-  hipStream_t st = (hipStream_t)stream;
-  const int U = 32 / S;
-  if (wf) {
-    const int pitch = f_pitch(M), rows = f_rows(N);
-    // rows = round_up(N*32, 64): cover the padding rows with one extra n when N is odd
-    hipLaunchKernelGGL(pack_f_kernel, dim3(pitch / 64, ceil_div(rows, 32)), dim3(256), 0, st, w,
-                       wf, M, N, K, S, U, pitch, rows);
-  }
-  if (wt) {
-    const int NP = t_np(N, S);
-    const int pitch = t_pitch(N, S), rows = t_rows(M, S);
-    hipLaunchKernelGGL(pack_t_kernel, dim3(ceil_div(NP, 64), ceil_div(rows, U)), dim3(256), 0, st,
-                       w, wt, M, N, K, S, U, NP, pad_t, pitch, rows);
-  }
-  return segan_check_launch("pack_weights");
-}
-
-static int check_src(const segan_src* s, int C, const char* what) {
-  SEGAN_REQUIRE(s != nullptr && s->p0 != nullptr, "%s: source is NULL", what);
-  SEGAN_REQUIRE(s->C0 > 0 && s->C1 >= 0 && s->C0 + s->C1 == C,
-                "%s: channel segments %d+%d != %d", what, s->C0, s->C1, C);
-  SEGAN_REQUIRE(s->C1 == 0 || s->p1 != nullptr, "%s: second segment pointer is NULL", what);
-  return SEGAN_OK;
-}
-
-static bool precision_ok(int p) { return p == 0 || p == 1 || p == 3; }
-
 extern "C" int segan_conv1d_fwd(const segan_src* x, const void* wf, const float* bias, float* out,
                                 int B, int N, int M, int L, int K, int S, int padL, int mode,
                                 int roll, int precision, void* stream) {
@@ -1243,7 +583,7 @@ extern "C" int segan_conv1d_fwd(const segan_src* x, const void* wf, const float*
   a.out0_elems = (size_t)B * M * a.Tcols;
   if (precision) return segan_corr_bf_f(a, U, wf, precision, (hipStream_t)stream);
   static const bool fsmall_on = [] { const char* e = getenv("SEGAN_FSMALL"); return !e || atoi(e) != 0; }();
-  if (N <= 2 && fsmall_on) return launch_fsmall(a, M, N, S, (hipStream_t)stream);
+  if (N <= 2 && fsmall_on) return segan_launch_fsmall(a, M, N, S, (hipStream_t)stream);
   return launch_corr<true, false>(a, U, (hipStream_t)stream);
 }
 
@@ -1310,7 +650,7 @@ extern "C" int segan_deconv1d_fwd(const segan_src* x, const void* wt, const floa
   a.OC0 = N; a.OC1 = 0; a.Lout = S * Ls; a.act = act;
   a.o_padL = 0; a.o_roll = 0; a.o_padR = 0;
   a.out0_elems = (size_t)B * N * S * Ls;
-  if (w && N <= 2) return launch_tsmall(a, w, K, M, N, S, pad, (hipStream_t)stream);
+  if (w && N <= 2) return segan_launch_tsmall(a, w, K, M, N, S, pad, (hipStream_t)stream);
   if (precision && act == SEGAN_ACT_NONE)
     return segan_corr_bf_t(a, U, wt, precision, (hipStream_t)stream);
   SEGAN_REQUIRE(precision == 0, "deconv1d_fwd: tanh epilogue only on the fp32 path");
@@ -1349,7 +689,7 @@ extern "C" int segan_conv1d_dgrad(const float* da, const void* wt, const float* 
   a.o_padL = padL; a.o_roll = roll; a.o_padR = padR;
   a.out0_elems = (size_t)B * N * L;
   a.halo_elems = (size_t)B * N * (padL + padR);
-  int e = (w && N <= 2) ? launch_tsmall(a, w, K, M, N, S, 0, st)
+  int e = (w && N <= 2) ? segan_launch_tsmall(a, w, K, M, N, S, 0, st)
           : precision   ? segan_corr_bf_t(a, U, wt, precision, st)
                         : launch_corr<false, true>(a, U, st);
   if (e) return e;
@@ -1363,39 +703,4 @@ extern "C" int segan_conv1d_dgrad(const float* da, const void* wt, const float* 
     return segan_check_launch("fold_halo_kernel");
   }
   return SEGAN_OK;
-}
-
-extern "C" size_t segan_wgrad_scratch_bytes(int B, int M, int Ls, int precision) {
-  if (precision == SEGAN_PREC_FP32 || B <= 0 || M <= 0 || Ls <= 0) return 0;
-  return segan_wgrad_bf_scratch_bytes(B, M, Ls, precision == SEGAN_PREC_BF16 ? 1 : 3);
-}
-
-extern "C" int segan_wgrad(const segan_src* lo, const segan_src* hi, float* dw, int B, int M, int N,
-                           int Ls, int K, int S, int padL, int mode, int roll, int precision,
-                           void* scratch, void* stream) {
-  SEGAN_REQUIRE(precision_ok(precision), "wgrad: bad precision %d", precision);
-  SEGAN_REQUIRE(stride_ok(S), "wgrad: stride %d not in {1,2,4}", S);
-  SEGAN_REQUIRE(K >= 1 && K <= 32, "wgrad: kernel width %d not in [1,32]", K);
-  SEGAN_REQUIRE(B > 0 && N > 0 && M > 0 && Ls > 0, "wgrad: bad sizes");
-  SEGAN_REQUIRE(dw != nullptr, "wgrad: dw is NULL");
-  SEGAN_REQUIRE(mode == SEGAN_PAD_REFLECT || mode == SEGAN_PAD_ZERO, "wgrad: bad pad mode");
-  if (int e = check_src(lo, M, "wgrad(lo)")) return e;
-  if (int e = check_src(hi, N, "wgrad(hi)")) return e;
-  const int L = S * Ls;
-  SEGAN_REQUIRE(roll > -L && roll < L, "wgrad: |roll| must be < L");
-  WgradArgs a = {};
-  a.lo = *lo; a.hi = *hi; a.dw = dw;
-  a.B = B; a.M = M; a.N = N; a.K = K; a.Ls = Ls; a.Lhi = L;
-  a.Cv = N * S; a.padL = padL; a.mode = mode; a.roll = roll;
-  a.Ctot = B * Ls;
-  hipStream_t st = (hipStream_t)stream;
-  if (precision != SEGAN_PREC_FP32) {
-    a.lo_pk = scratch;
-    return segan_wgrad_bf(a, 32 / S, precision == SEGAN_PREC_BF16 ? 1 : 3, st);
-  }
-  switch (S) {
-    case 4: return launch_wgrad_t<8>(a, st);
-    case 2: return launch_wgrad_t<16>(a, st);
-    default: return launch_wgrad_t<32>(a, st);
-  }
 }

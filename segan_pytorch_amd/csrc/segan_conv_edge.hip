@@ -1,0 +1,230 @@
+// segan_conv_edge.hip — direct VALU kernels for the HBM-bound edge layers (1-2 channels on
+// one side), where an MFMA tile would be mostly padding: the T form for 1-2 output channels
+// (last deconv of G; data gradient of the first conv) and the F form for 1-2 input channels
+// (first conv of G and of D).  See segan_conv.hip for the two forms.
+#include "segan_conv_shared.h"
+
+// ====================================================================================
+// T form for 1-2 output channels (the HBM-bound edge layers: the generator's last deconv
+// Cout=1, and the data gradient of the first conv whose input has 1-2 channels).  With so
+// few output channels an MFMA tile would be >90 % padding, so this is a direct VALU kernel:
+// one thread per low-rate position q computes all S phases x N channels, the input window
+// comes from an LDS tile (with the segan_src transform applied while staging) and the taps
+// are wave-uniform scalar loads.
+// ====================================================================================
+// KT: kernel width known at compile time (31, the SEGAN width: the taps then sit at constant
+// offsets and the scalar loads merge into s_load_dwordx8/x16) or 0 = runtime K.
+template <int S, int N, int PM, int KT>
+__global__ __launch_bounds__(256) void tsmall_kernel(const CorrArgs a, const float* __restrict__ w,
+                                                     int Krt, int M) {
+  const int K = KT ? KT : Krt;
+  constexpr int U = 32 / S;
+  constexpr int MC = 16;                 // input channels per LDS chunk
+  constexpr int TW = 256 + U;            // window: 256 positions + (U-1) taps + 1 phase shift
+  __shared__ float xs[MC][TW + 1];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y;
+  const int q0 = blockIdx.x * 256;
+  const int q = q0 + tid;
+  // window coordinate j <-> input time t = q0 + win_start + j   (win_start = cmin - (U-1))
+  float acc[S][N];
+#pragma unroll
+  for (int r = 0; r < S; ++r)
+#pragma unroll
+    for (int n = 0; n < N; ++n) acc[r][n] = 0.0f;
+
+  // staging: thread owns window positions tid and 256 + tid (the latter only for tid < U);
+  // addresses are clamped so the loads are unconditional
+  const int t0 = q0 + a.win_start + tid, t1 = t0 + 256;
+  const bool ok0 = t0 >= 0 && t0 < a.Lin, ok1 = tid < U && t1 >= 0 && t1 < a.Lin;
+  const int o0 = ok0 ? t0 : 0, o1 = ok1 ? t1 : 0;
+  const int bo0 = b * a.in.C0 * a.Lin, bo1 = b * a.in.C1 * a.Lin;
+  for (int mc0 = 0; mc0 < M; mc0 += MC) {
+#pragma unroll 8
+    for (int mc = 0; mc < MC; ++mc) {
+      const int m = mc0 + mc < M ? mc0 + mc : 0;
+      const bool seg1 = m >= a.in.C0;
+      const float* rowp = seg1 ? a.in.p1 + (size_t)(m - a.in.C0) * a.Lin + bo1
+                               : a.in.p0 + (size_t)m * a.Lin + bo0;
+      const ChanXf xf = segan_chan_xf(a.in, m);
+      const float v0 = rowp[o0], v1 = rowp[o1];
+      const bool mok = mc0 + mc < M;
+      xs[mc][tid] = (mok && ok0) ? segan_apply_xf(xf, v0) : 0.0f;
+      if (tid < U) xs[mc][256 + tid] = (mok && ok1) ? segan_apply_xf(xf, v1) : 0.0f;
+    }
+    __syncthreads();
+    const int mcn = min(MC, M - mc0);
+    for (int mc = 0; mc < mcn; ++mc) {
+      float xv[U + 1];
+#pragma unroll
+      for (int j = 0; j <= U; ++j) xv[j] = xs[mc][tid + j];
+      // taps are wave-uniform: scalar loads straight into SGPR operands of the FMAs; tap
+      // indices are clamped and the value selected to zero for k >= K (no branches)
+      const float* wm = w + (size_t)(mc0 + mc) * N * K;
+#pragma unroll
+      for (int r = 0; r < S; ++r) {
+        const int rho = (r + PM) % S;     // tap phase of output phase r
+        const int cs = (r + PM) / S;      // 0/1: extra input shift of this phase
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int k = S * u + rho;
+          if (KT) {
+            if (k < KT) {
+#pragma unroll
+              for (int n = 0; n < N; ++n)
+                acc[r][n] = fmaf(wm[n * KT + k], xv[cs + (U - 1) - u], acc[r][n]);
+            }
+          } else {
+            const int kc = k < K ? k : K - 1;
+#pragma unroll
+            for (int n = 0; n < N; ++n) {
+              float wv = wm[n * K + kc];
+              wv = k < K ? wv : 0.0f;
+              acc[r][n] = fmaf(wv, xv[cs + (U - 1) - u], acc[r][n]);
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (q >= a.Tcols) return;
+#pragma unroll
+  for (int r = 0; r < S; ++r)
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      float v = acc[r][n] + (a.bias ? a.bias[n] : 0.0f);
+      if (a.act == SEGAN_ACT_TANH) v = tanhf(v);
+      const int P = S * q + r;
+      int ii = P - a.o_padL;
+      const size_t rowoff = (size_t)b * N + n;
+      if (ii >= 0 && ii < a.Lout) {
+        if (a.o_roll != 0) {
+          ii -= a.o_roll;
+          if (ii < 0) ii += a.Lout;
+          if (ii >= a.Lout) ii -= a.Lout;
+        }
+        a.out0[rowoff * (size_t)a.Lout + ii] = v;
+      } else if (a.halo != nullptr) {
+        const int hl = a.o_padL + a.o_padR;
+        if (ii < 0) a.halo[rowoff * hl + P] = v;
+        else if (ii - a.Lout < a.o_padR) a.halo[rowoff * hl + a.o_padL + (ii - a.Lout)] = v;
+      }
+    }
+}
+
+template <int S, int N, int KT>
+static int launch_tsmall_snk(const CorrArgs& a, const float* w, int K, int M, int pad,
+                             hipStream_t st) {
+  dim3 grid(ceil_div(a.Tcols, 256), a.B);
+  switch (pad % S) {
+    case 0: hipLaunchKernelGGL((tsmall_kernel<S, N, 0, KT>), grid, dim3(256), 0, st, a, w, K, M); break;
+    case 1: hipLaunchKernelGGL((tsmall_kernel<S, N, 1 % S, KT>), grid, dim3(256), 0, st, a, w, K, M); break;
+    case 2: hipLaunchKernelGGL((tsmall_kernel<S, N, 2 % S, KT>), grid, dim3(256), 0, st, a, w, K, M); break;
+    default: hipLaunchKernelGGL((tsmall_kernel<S, N, 3 % S, KT>), grid, dim3(256), 0, st, a, w, K, M); break;
+  }
+  return segan_check_launch("tsmall_kernel");
+}
+
+template <int S, int N>
+static int launch_tsmall_sn(const CorrArgs& a, const float* w, int K, int M, int pad,
+                            hipStream_t st) {
+  if (K == 31) return launch_tsmall_snk<S, N, 31>(a, w, K, M, pad, st);
+  return launch_tsmall_snk<S, N, 0>(a, w, K, M, pad, st);
+}
+
+// `a` is filled exactly as for the MFMA T form; w is the UNPACKED weight [M][N][K]
+int segan_launch_tsmall(CorrArgs& a, const float* w, int K, int M, int N, int S, int pad,
+                         hipStream_t st) {
+  if (int e = segan_src_defaults(&a.in, st, "tsmall")) return e;
+  if (N == 1) {
+    if (S == 4) return launch_tsmall_sn<4, 1>(a, w, K, M, pad, st);
+    if (S == 2) return launch_tsmall_sn<2, 1>(a, w, K, M, pad, st);
+    return launch_tsmall_sn<1, 1>(a, w, K, M, pad, st);
+  }
+  if (S == 4) return launch_tsmall_sn<4, 2>(a, w, K, M, pad, st);
+  if (S == 2) return launch_tsmall_sn<2, 2>(a, w, K, M, pad, st);
+  return launch_tsmall_sn<1, 2>(a, w, K, M, pad, st);
+}
+
+
+// ====================================================================================
+// F form for 1-2 input channels (the first conv of G and of D: HBM-bound, and an MFMA tile
+// whose contraction is N*32 <= 64 deep would be mostly the padding to the 64-deep LDS chunk).
+// Direct VALU kernel: a workgroup owns 256 output positions of one sample, stages the padded
+// input window once (reflect / roll / transform applied while staging) and walks the output
+// channels with the taps read as 16-byte LDS broadcasts from a zero-padded [m][n][32] copy of
+// the packed weights.  Stores are coalesced along time.
+// ====================================================================================
+template <int S, int N>
+__global__ __launch_bounds__(256) void fsmall_kernel(const CorrArgs a, int M) {
+  constexpr int U = 32 / S;
+  constexpr int XW = S * 256 + 32;
+  constexpr int WST = N * 32 + 4;          // row stride of the weight copy (16-B aligned)
+  __shared__ __attribute__((aligned(16))) float xs[N][XW];
+  __shared__ __attribute__((aligned(16))) float ws[64 * WST];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y;
+  const int t0 = blockIdx.x * 256;
+  for (int j = tid; j < XW; j += 256) {
+    const int idx = segan_hi_index(S * t0 + j, a.Lin, a.padL, a.mode, a.roll);
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      float v = 0.0f;
+      if (idx >= 0) v = segan_apply_xf(segan_chan_xf(a.in, n), segan_src_row(a.in, b, n, a.Lin)[idx]);
+      xs[n][j] = v;
+    }
+  }
+  const int t = t0 + tid;
+  for (int m0 = 0; m0 < M; m0 += 64) {
+    // packed F layout: w[m][n][S*u + r] = wp[((n*S + r)*U + u) * RP + m]; rows of taps >= K
+    // are zero.  Lanes run along m so the global reads are coalesced.
+    for (int e = tid; e < 64 * N * 32; e += 256) {
+      const int ml = e & 63, nk = e >> 6;
+      const int n = nk >> 5, k = nk & 31;
+      const int row = (n * S + k % S) * U + k / S;
+      const int m = m0 + ml;
+      ws[ml * WST + n * 32 + k] = m < a.RP ? a.wp[(size_t)row * a.RP + m] : 0.0f;
+    }
+    __syncthreads();
+    float xv[N][32];
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      if (S == 4) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(&xs[n][4 * tid + 4 * i]);
+          xv[n][4 * i] = v[0]; xv[n][4 * i + 1] = v[1]; xv[n][4 * i + 2] = v[2]; xv[n][4 * i + 3] = v[3];
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 32; ++k) xv[n][k] = xs[n][S * tid + k];
+      }
+    }
+    const int mcn = min(64, M - m0);
+    for (int ml = 0; ml < mcn; ++ml) {
+      float acc = a.bias ? a.bias[m0 + ml] : 0.0f;
+#pragma unroll
+      for (int n = 0; n < N; ++n) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(&ws[ml * WST + n * 32 + 4 * i]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc = fmaf(wv[e], xv[n][4 * i + e], acc);
+        }
+      }
+      if (t < a.Lout) a.out0[((size_t)b * M + m0 + ml) * a.Lout + t] = acc;
+    }
+    __syncthreads();
+  }
+}
+
+int segan_launch_fsmall(CorrArgs& a, int M, int N, int S, hipStream_t st) {
+  if (int e = segan_src_defaults(&a.in, st, "fsmall")) return e;
+  dim3 grid(ceil_div(a.Lout, 256), a.B);
+#define FS(SS, NN) hipLaunchKernelGGL((fsmall_kernel<SS, NN>), grid, dim3(256), 0, st, a, M)
+  if (N == 1) { if (S == 4) FS(4, 1); else if (S == 2) FS(2, 1); else FS(1, 1); }
+  else { if (S == 4) FS(4, 2); else if (S == 2) FS(2, 2); else FS(1, 2); }
+#undef FS
+  return segan_check_launch("fsmall_kernel");
+}

@@ -100,6 +100,28 @@ struct WgradArgs {
   int Mp;                 // its row pitch (M rounded up to 128)
 };
 
+// packed-weight geometry (shared by the pack kernels and the launchers)
+static inline int f_pitch(int M) { return M <= 64 ? 64 : round_up(M, 128); }
+static inline int f_rows(int N) { return round_up(N * 32, KCH); }
+static inline int t_pitch(int N, int S) { return S * t_np(N, S); }
+static inline int t_rows(int M, int S) { return round_up(M * (32 / S), KCH); }
+
+// argument checks shared by the C-ABI translation units
+static inline bool stride_ok(int S) { return S == 1 || S == 2 || S == 4; }
+static inline bool precision_ok(int p) { return p == 0 || p == 1 || p == 3; }
+static inline int check_src(const segan_src* s, int C, const char* what) {
+  SEGAN_REQUIRE(s != nullptr && s->p0 != nullptr, "%s: source is NULL", what);
+  SEGAN_REQUIRE(s->C0 > 0 && s->C1 >= 0 && s->C0 + s->C1 == C,
+                "%s: channel segments %d+%d != %d", what, s->C0, s->C1, C);
+  SEGAN_REQUIRE(s->C1 == 0 || s->p1 != nullptr, "%s: second segment pointer is NULL", what);
+  return SEGAN_OK;
+}
+
+// direct VALU kernels of the 1-2 channel edge layers (segan_conv_edge.hip); `a` is filled
+// exactly as for the MFMA forms, w is the UNPACKED weight [M][N][K]
+int segan_launch_tsmall(CorrArgs& a, const float* w, int K, int M, int N, int S, int pad, hipStream_t st);
+int segan_launch_fsmall(CorrArgs& a, int M, int N, int S, hipStream_t st);
+
 // split-bf16 entry points (segan_conv_bf.hip); `a` is filled exactly as for the fp32 kernels
 int segan_corr_bf_f(CorrArgs& a, int U, const void* wp3, int planes, hipStream_t st);
 int segan_corr_bf_t(CorrArgs& a, int U, const void* wp3, int planes, hipStream_t st);
