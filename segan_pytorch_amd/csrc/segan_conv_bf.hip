@@ -277,13 +277,19 @@ __global__ __launch_bounds__(256, NPL == 1 ? 3 : 2) void corr_bf_kernel(const Co
     store_w(0);
     __syncthreads();
   }
+  bool in_flight = false;     // the activation tile of the next channel group is being loaded
   for (int st = c0; st < c1; ++st) {
     const int buf = (st - c0) & 1;
     const int cg = st / TCH, tc = st - cg * TCH;
     const bool more = st + 1 < c1;
     const bool new_group = more && ((st + 1) % TCH == 0);
     if (more) load_w(st + 1);
-    if (new_group) load_in(cg + 1);
+    // issue the next group's activation loads at the FIRST stage of this group (not the last):
+    // TCH stages of MFMA work cover their latency
+    if (!in_flight && (cg + 1) * TCH < c1) {
+      load_in(cg + 1);
+      in_flight = true;
+    }
     const u32x4* Wl = Wl0 + buf * (NPL * TU * 2 * MB);
 #pragma unroll
     for (int tu = 0; tu < TU; ++tu) {
@@ -325,6 +331,7 @@ __global__ __launch_bounds__(256, NPL == 1 ? 3 : 2) void corr_bf_kernel(const Co
       // every wave is done reading the activation tile of this group before it is replaced
       __syncthreads();
       store_in(cg + 1);
+      in_flight = false;
     }
     if (more) store_w(buf ^ 1);
     __syncthreads();
