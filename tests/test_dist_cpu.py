@@ -66,3 +66,86 @@ def test_single_process_is_a_noop():
     assert sdist.world_size() == 1 and sdist.rank() == 0
     t = torch.ones(4)
     assert sdist.allreduce_mean_(t) is t and sdist.shard_batch(t) is t
+
+
+# ---- gradient equality of a data-parallel GAN step -----------------
+def _dp_opts():
+    import json
+    here = os.path.dirname(os.path.abspath(__file__))
+    fx = torch.load(os.path.join(here, 'golden', 'tiny_step.pt'), map_location='cpu',
+                    weights_only=False)
+    o = dict(fx['opts'])
+    o['dnorm_type'] = None          # no BatchNorm: the only cross-sample coupling of the step
+    return o, fx
+
+
+def _dp_step(o, fx, clean, noisy, z, seed):
+    """One GAN step on CPU (test-only emulation of the kernel entry points)."""
+    import random
+    import sys
+    from types import SimpleNamespace
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import emu_ops
+    emu_ops.install()
+    from segan_pytorch_amd import losses
+    from segan_pytorch_amd.models import SEGAN
+    random.seed(1)
+    torch.manual_seed(1)
+    m = SEGAN(SimpleNamespace(**o))            # same seed -> identical replicas
+    m.G.load_state_dict(fx['G0'])
+    Gopt, Dopt = m.build_optimizers(SimpleNamespace(**o))
+    m.G.train()
+    m.D.train()
+    random.seed(seed)                          # identical phase shifts on every rank
+    m.gan_step(clean, noisy, Gopt, Dopt, losses.MSELoss(), 100.0, z=z)
+    out = {'Dg.' + k: p.grad.detach().clone() for k, p in m.D.named_parameters()}
+    out.update({'Gg.' + k: p.grad.detach().clone() for k, p in m.G.named_parameters()})
+    out.update({'Dw.' + k: p.detach().clone() for k, p in m.D.named_parameters()})
+    emu_ops.uninstall()
+    return out
+
+
+def _dp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from segan_pytorch_amd import distributed as sdist
+    sdist.init_from_env(backend='gloo')
+    o, fx = _dp_opts()
+    g = torch.Generator().manual_seed(3)
+    clean = torch.rand(4, 1, 1024, generator=g) * 2 - 1
+    noisy = (clean + 0.1 * torch.randn(4, 1, 1024, generator=g)).clamp(-1, 1)
+    z = torch.randn(4, 32, 16, generator=g)
+    sl = slice(2 * rank, 2 * rank + 2)
+    out = _dp_step(o, fx, clean[sl].contiguous(), noisy[sl].contiguous(), z[sl].contiguous(), 11)
+    q.put((rank, {k: v.numpy() for k, v in out.items()}))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gan_step_equals_the_full_batch_step():
+    """Global batch 4 split 2 + 2 over two gloo ranks (D without BatchNorm): after the
+    gradient all-reduce both ranks hold the gradients — and after the optimizer step the
+    weights — of the single-process step on all 4 samples."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    o, fx = _dp_opts()
+    g = torch.Generator().manual_seed(3)
+    clean = torch.rand(4, 1, 1024, generator=g) * 2 - 1
+    noisy = (clean + 0.1 * torch.randn(4, 1, 1024, generator=g)).clamp(-1, 1)
+    z = torch.randn(4, 32, 16, generator=g)
+    full = _dp_step(o, fx, clean, noisy, z, 11)
+    for k, v in full.items():
+        scale = max(v.abs().max().item(), 1e-30)
+        for r in (0, 1):
+            err = (torch.from_numpy(res[r][k]) - v).abs().max().item()
+            # gradients: fp32 summation order; weights: within 10 % of an RMSprop step
+            tol = 5e-5 if k.startswith('Dw.') else 2e-5 * scale
+            assert err < tol, (k, r, err)
