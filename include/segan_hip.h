@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SEGAN_ABI_VERSION 5
+#define SEGAN_ABI_VERSION 6
 
 #define SEGAN_PAD_REFLECT 0
 #define SEGAN_PAD_ZERO 1
@@ -150,6 +150,14 @@ int segan_bn_stats(const float* x, const float* gamma, const float* beta, float 
                    float momentum, float* running_mean, float* running_var, float* mean,
                    float* rstd, float* scale, float* shift, float* ws, int B, int C, int L,
                    void* stream);
+/* The same in two calls, for synchronised BatchNorm under data parallelism: `partial` leaves
+ * this rank's (count, mean, M2) per channel and batch split in ws[nsplit][C][3]; the caller
+ * all-gathers the ranks' ws; `final` combines nsplit_total = world*nsplit partials (Chan et
+ * al.) exactly as segan_bn_stats does for one rank. */
+int segan_bn_partial(const float* x, float* ws, int B, int C, int L, void* stream);
+int segan_bn_final(const float* ws, int nsplit_total, const float* gamma, const float* beta,
+                   float eps, float momentum, float* running_mean, float* running_var, float* mean,
+                   float* rstd, float* scale, float* shift, int C, void* stream);
 
 /* y = prelu(x*scale[c] + shift[c], slope[c]) materialised (used for the FC input
  * h.view(B,-1) of discriminator.py:181 and for int_act / ret_hid outputs). */
@@ -173,6 +181,18 @@ int segan_act_bwd(const float* a, const float* dh, const float* dskip, const flo
                   const float* bn_gamma, const float* bn_beta, float* da, float* dslope,
                   float* dalpha, float* dgamma, float* dbeta, float* dbias, float* ws, int B, int C,
                   int L, void* stream);
+/* The BatchNorm branch of segan_act_bwd in two calls (synchronised BatchNorm): `reduce`
+ * accumulates dslope / dgamma / dbeta from this rank's samples and leaves the per-channel
+ * (sum g, sum g*xhat) in totals[C][2]; the caller all-reduces (sums) totals; `apply` writes da
+ * with the global totals and the global per-channel element count, and accumulates dbias. */
+int segan_act_bwd_bn_reduce(const float* a, const float* dh, const float* slope,
+                            const float* bn_mean, const float* bn_rstd, const float* bn_gamma,
+                            const float* bn_beta, float* dslope, float* dgamma, float* dbeta,
+                            float* totals, float* ws, int B, int C, int L, void* stream);
+int segan_act_bwd_bn_apply(const float* a, const float* dh, const float* slope,
+                           const float* bn_mean, const float* bn_rstd, const float* bn_gamma,
+                           const float* bn_beta, const float* totals, float* da, float* dbias,
+                           float* ws, int B, int C, int L, double count_total, void* stream);
 
 /* tanh backward of the generator output with the L1 term of model.py:316-319 fused:
  *   g = dy_adv (may be NULL) + l1_scale * sign(y - clean) (when clean != NULL)

@@ -14,7 +14,7 @@ PAD_REFLECT = 0
 PAD_ZERO = 1
 ACT_NONE = 0
 ACT_TANH = 1
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class SeganSrc(Structure):
@@ -49,6 +49,10 @@ SIGNATURES = {
     'segan_bn_nsplit': (c_int, [c_int, c_int, c_int]),
     'segan_bn_stats': (c_int, [_P, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, _P, c_int, c_int,
                                c_int, _P]),
+    'segan_bn_partial': (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    'segan_bn_final': (c_int, [_P, c_int, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, c_int, _P]),
+    'segan_act_bwd_bn_reduce': (c_int, [_P] * 12 + [c_int, c_int, c_int, _P]),
+    'segan_act_bwd_bn_apply': (c_int, [_P] * 11 + [c_int, c_int, c_int, c_double, _P]),
     'segan_affine_prelu': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     'segan_sum_skip': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     'segan_bce_logits_const': (c_int, [_P, c_float, _P, _P, _P, c_float, c_int, _P]),

@@ -170,6 +170,29 @@ extern "C" int segan_bn_stats(const float* x, const float* gamma, const float* b
   return segan_check_launch("bn_stats");
 }
 
+// segan_bn_stats in two calls for synchronised BatchNorm: `partial` leaves this rank's
+// (count, mean, M2) per channel and batch split in ws[nsplit][C][3]; after an all-gather of the
+// ranks' ws, `final` combines nsplit_total = world * nsplit partials exactly like segan_bn_stats.
+extern "C" int segan_bn_partial(const float* x, float* ws, int B, int C, int L, void* stream) {
+  SEGAN_REQUIRE(x && ws, "bn_partial: NULL pointer");
+  SEGAN_REQUIRE(B > 0 && C > 0 && L > 0, "bn_partial: bad sizes");
+  const int ns = pw_nsplit(B, C, L);
+  hipLaunchKernelGGL(bn_partial_kernel, dim3(C, ns), dim3(PW_THREADS), 0, (hipStream_t)stream, x, ws,
+                     B, C, L, ns);
+  return segan_check_launch("bn_partial");
+}
+
+extern "C" int segan_bn_final(const float* ws, int nsplit_total, const float* gamma,
+                              const float* beta, float eps, float momentum, float* running_mean,
+                              float* running_var, float* mean, float* rstd, float* scale,
+                              float* shift, int C, void* stream) {
+  SEGAN_REQUIRE(ws && nsplit_total > 0 && C > 0, "bn_final: bad arguments");
+  hipLaunchKernelGGL(bn_final_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, (hipStream_t)stream, ws,
+                     gamma, beta, eps, momentum, running_mean, running_var, mean, rstd, scale, shift,
+                     C, nsplit_total);
+  return segan_check_launch("bn_final");
+}
+
 // ---------------------------------------------------------------------------------
 // y = prelu(x*scale + shift, slope)
 // ---------------------------------------------------------------------------------
@@ -237,6 +260,7 @@ struct ActBwdArgs {
   float* da;
   float* ws;      // [nsplit][C][4] partials, then [C][2] totals of (dbeta, dgamma)
   int B, C, L, nsplit;
+  float inv_count;   // 1 / (elements per channel the BatchNorm statistics were taken over)
 };
 
 // PHASE 0: no BN (single pass).  PHASE 1: BN reductions.  PHASE 2: BN apply.
@@ -257,9 +281,8 @@ __global__ void act_bwd_kernel(const ActBwdArgs p) {
   }
   if (PHASE == 2) {
     const float* tot = p.ws + (size_t)p.nsplit * p.C * 4 + (size_t)c * 2;
-    const float invn = 1.0f / ((float)p.B * (float)p.L);
-    dbeta_m = tot[0] * invn;
-    dgamma_m = tot[1] * invn;
+    dbeta_m = tot[0] * p.inv_count;
+    dgamma_m = tot[1] * p.inv_count;
   }
   float r[3] = {0.f, 0.f, 0.f};
   const bool has_skip = p.dskip != nullptr;
@@ -376,6 +399,7 @@ extern "C" int segan_act_bwd(const float* a, const float* dh, const float* dskip
   p.mean = bn_mean; p.rstd = bn_rstd; p.gamma = bn_gamma; p.beta = bn_beta;
   p.da = da; p.ws = ws; p.B = B; p.C = C; p.L = L;
   p.nsplit = pw_nsplit(B, C, L);
+  p.inv_count = 1.0f / ((float)B * (float)L);
   const dim3 grid(C, p.nsplit), fgrid(ceil_div(C, 64));
   if (!bn_mean) {
     hipLaunchKernelGGL(act_bwd_kernel<0>, grid, dim3(PW_THREADS), 0, st, p);
@@ -390,6 +414,60 @@ extern "C" int segan_act_bwd(const float* a, const float* dh, const float* dskip
                        dbeta, dbias);
   }
   return segan_check_launch("act_bwd");
+}
+
+// The BatchNorm branch of segan_act_bwd in two calls, so that a data-parallel run can sum the
+// per-channel totals over the ranks between them (synchronised BatchNorm): `reduce` leaves
+// (sum g, sum g*xhat) per channel in totals[C][2]; `apply` consumes them with the GLOBAL
+// element count per channel.  ws as for segan_act_bwd.
+extern "C" int segan_act_bwd_bn_reduce(const float* a, const float* dh, const float* slope,
+                                       const float* bn_mean, const float* bn_rstd,
+                                       const float* bn_gamma, const float* bn_beta, float* dslope,
+                                       float* dgamma, float* dbeta, float* totals, float* ws, int B,
+                                       int C, int L, void* stream) {
+  SEGAN_REQUIRE(a && dh && bn_mean && bn_rstd && totals && ws, "act_bwd_bn_reduce: NULL pointer");
+  SEGAN_REQUIRE(B > 0 && C > 0 && L > 0, "act_bwd_bn_reduce: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  ActBwdArgs p;
+  p.a = a; p.dh = dh; p.dskip = nullptr; p.slope = slope; p.alpha = nullptr;
+  p.mean = bn_mean; p.rstd = bn_rstd; p.gamma = bn_gamma; p.beta = bn_beta;
+  p.da = nullptr; p.ws = ws; p.B = B; p.C = C; p.L = L;
+  p.nsplit = pw_nsplit(B, C, L);
+  p.inv_count = 1.0f / ((float)B * (float)L);
+  hipLaunchKernelGGL(act_bwd_kernel<1>, dim3(C, p.nsplit), dim3(PW_THREADS), 0, st, p);
+  hipLaunchKernelGGL(act_bwd_final_kernel<1>, dim3(ceil_div(C, 64)), dim3(64), 0, st, p, dslope,
+                     (float*)nullptr, dgamma, dbeta, (float*)nullptr);
+  if (hipMemcpyAsync(totals, ws + (size_t)p.nsplit * C * 4, (size_t)C * 2 * sizeof(float),
+                     hipMemcpyDeviceToDevice, st) != hipSuccess) {
+    segan_set_error("act_bwd_bn_reduce: copy of the totals failed");
+    return SEGAN_ELAUNCH;
+  }
+  return segan_check_launch("act_bwd_bn_reduce");
+}
+
+extern "C" int segan_act_bwd_bn_apply(const float* a, const float* dh, const float* slope,
+                                      const float* bn_mean, const float* bn_rstd,
+                                      const float* bn_gamma, const float* bn_beta,
+                                      const float* totals, float* da, float* dbias, float* ws, int B,
+                                      int C, int L, double count_total, void* stream) {
+  SEGAN_REQUIRE(a && dh && bn_mean && bn_rstd && totals && da && ws, "act_bwd_bn_apply: NULL pointer");
+  SEGAN_REQUIRE(B > 0 && C > 0 && L > 0 && count_total >= (double)B * L, "act_bwd_bn_apply: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  ActBwdArgs p;
+  p.a = a; p.dh = dh; p.dskip = nullptr; p.slope = slope; p.alpha = nullptr;
+  p.mean = bn_mean; p.rstd = bn_rstd; p.gamma = bn_gamma; p.beta = bn_beta;
+  p.da = da; p.ws = ws; p.B = B; p.C = C; p.L = L;
+  p.nsplit = pw_nsplit(B, C, L);
+  p.inv_count = (float)(1.0 / count_total);
+  if (hipMemcpyAsync(ws + (size_t)p.nsplit * C * 4, totals, (size_t)C * 2 * sizeof(float),
+                     hipMemcpyDeviceToDevice, st) != hipSuccess) {
+    segan_set_error("act_bwd_bn_apply: copy of the totals failed");
+    return SEGAN_ELAUNCH;
+  }
+  hipLaunchKernelGGL(act_bwd_kernel<2>, dim3(C, p.nsplit), dim3(PW_THREADS), 0, st, p);
+  hipLaunchKernelGGL(act_bwd_final_kernel<2>, dim3(ceil_div(C, 64)), dim3(64), 0, st, p,
+                     (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, dbias);
+  return segan_check_launch("act_bwd_bn_apply");
 }
 
 // ---------------------------------------------------------------------------------

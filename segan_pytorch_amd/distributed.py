@@ -103,3 +103,27 @@ def shard_batch(t, dim=0):
         raise ValueError('global batch {} is not divisible by world size {}'.format(n, ws))
     per = n // ws
     return t.narrow(dim, rk * per, per)
+
+
+# ---- synchronised BatchNorm (optional) --------------------------------
+def sync_bn_enabled():
+    """SEGAN_SYNC_BN=1 under data parallelism: D's BatchNorm statistics (forward) and the
+    per-channel gradient sums (backward) are taken over the GLOBAL batch, so N ranks of batch
+    b reproduce one process at batch N*b.  Default off: every replica normalises with its own
+    batch, like the reference at its per-GPU batch size."""
+    return is_dist() and os.environ.get('SEGAN_SYNC_BN', '0') == '1'
+
+
+def bn_stats_sync(x, gamma, beta, eps, momentum, running_mean, running_var):
+    ws = ops.bn_partial(x)                                   # [nsplit, C, 3]
+    parts = [torch.empty_like(ws) for _ in range(world_size())]
+    dist.all_gather(parts, ws)
+    return ops.bn_final(torch.cat(parts, 0).contiguous(), gamma, beta, eps, momentum, running_mean,
+                        running_var)
+
+
+def act_bwd_bn_sync(a, dh, slope, bn, dslope=None, dgamma=None, dbeta=None, dbias=None):
+    totals, ws = ops.act_bwd_bn_reduce(a, dh, slope, bn, dslope, dgamma, dbeta)
+    dist.all_reduce(totals, op=dist.ReduceOp.SUM)
+    count = float(a.shape[0]) * float(a.shape[2]) * world_size()
+    return ops.act_bwd_bn_apply(a, dh, slope, bn, totals, count, dbias, ws)

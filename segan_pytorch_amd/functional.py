@@ -67,6 +67,24 @@ def _gb(p, needed=True):
     return grad_buf(p)
 
 
+def _bn_train_stats(c, bn):
+    """BatchNorm training statistics of pre-activation c: over this rank's batch, or over the
+    global batch when synchronised BatchNorm is on (distributed.sync_bn_enabled)."""
+    from . import distributed as sdist
+    fn = sdist.bn_stats_sync if sdist.sync_bn_enabled() else ops.bn_stats
+    return fn(c, bn.weight, bn.bias, bn.eps, bn.momentum if bn.momentum is not None else 0.1,
+              bn.running_mean, bn.running_var)
+
+
+def _act_bwd_bn(a, dh, slope, bn, dslope, dgamma, dbeta, dbias):
+    """Backward of BN + PReLU; the per-channel sums are all-reduced when BatchNorm is synced."""
+    from . import distributed as sdist
+    if sdist.sync_bn_enabled():
+        return sdist.act_bwd_bn_sync(a, dh, slope, bn, dslope, dgamma, dbeta, dbias)
+    return ops.act_bwd(a, dh, slope=slope, bn=bn, dslope=dslope, dgamma=dgamma, dbeta=dbeta,
+                       dbias=dbias)
+
+
 def _ones(n, ref):
     return torch.ones(n, device=ref.device, dtype=torch.float32)
 
@@ -301,10 +319,7 @@ class DiscriminatorFn(torch.autograd.Function):
             if blk.norm is not None:
                 bn = blk.norm
                 if training:
-                    mean, rstd, scale, shift = ops.bn_stats(
-                        c, bn.weight, bn.bias, bn.eps,
-                        bn.momentum if bn.momentum is not None else 0.1,
-                        bn.running_mean, bn.running_var)
+                    mean, rstd, scale, shift = _bn_train_stats(c, bn)
                     if bn.num_batches_tracked is not None:
                         bn.num_batches_tracked += 1
                     bns.append((mean, rstd, bn.weight, bn.bias))
@@ -381,9 +396,8 @@ class DiscriminatorFn(torch.autograd.Function):
                 raise RuntimeError('Discriminator backward in eval() mode with BatchNorm is not '
                                    'supported; call .train() (the reference never does this)')
             if bn is not None:
-                dc = ops.act_bwd(cs[l], dh, slope=blk.act.weight, bn=bn,
-                                 dslope=_gb(blk.act.weight), dgamma=_gb(bn[2]), dbeta=_gb(bn[3]),
-                                 dbias=_gb(blk.conv.bias))
+                dc = _act_bwd_bn(cs[l], dh, blk.act.weight, bn, _gb(blk.act.weight), _gb(bn[2]),
+                                 _gb(bn[3]), _gb(blk.conv.bias))
             else:
                 dc = ops.act_bwd(cs[l], dh, slope=blk.act.weight, dslope=_gb(blk.act.weight),
                                  dbias=_gb(blk.conv.bias))
@@ -424,9 +438,7 @@ class ConvBlockFn(torch.autograd.Function):
         if blk.norm is not None:
             bn = blk.norm
             if blk.training:
-                mean, rstd, scale, shift = ops.bn_stats(
-                    c, bn.weight, bn.bias, bn.eps, bn.momentum if bn.momentum is not None else 0.1,
-                    bn.running_mean, bn.running_var)
+                mean, rstd, scale, shift = _bn_train_stats(c, bn)
                 if bn.num_batches_tracked is not None:
                     bn.num_batches_tracked += 1
                 bn_saved = (mean, rstd, bn.weight, bn.bias)
@@ -463,8 +475,8 @@ class ConvBlockFn(torch.autograd.Function):
             if da_lin is not None or dh is None:
                 raise RuntimeError('gradient through the linear output of a normalised '
                                    'GConv1DBlock is unsupported')
-            dc = ops.act_bwd(c, dh, slope=blk.act.weight, bn=bn, dslope=_gb(blk.act.weight),
-                             dgamma=_gb(bn[2]), dbeta=_gb(bn[3]), dbias=_gb(blk.conv.bias))
+            dc = _act_bwd_bn(c, dh, blk.act.weight, bn, _gb(blk.act.weight), _gb(bn[2]), _gb(bn[3]),
+                             _gb(blk.conv.bias))
         padL = ops.conv_pad(K, S)[0]
         if W.needs_grad(blk.conv):
             gw = W.grad_target(blk.conv)

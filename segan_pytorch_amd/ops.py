@@ -362,6 +362,59 @@ def bn_stats(x, gamma, beta, eps, momentum, running_mean, running_var):
     return mean, rstd, scale, shift
 
 
+def bn_partial(x):
+    """This rank's BatchNorm partial statistics ws[nsplit, C, 3] = (count, mean, M2)."""
+    _chk(x, 'x', 3)
+    B, C, L = x.shape
+    ns = _lib.load().segan_bn_nsplit(B, C, L)
+    ws = torch.empty((ns, C, 3), device=x.device, dtype=torch.float32)
+    check(_lib.load().segan_bn_partial(_ptr(x), _ptr(ws), B, C, L, _stream()), 'bn_partial')
+    return ws
+
+
+def bn_final(ws_all, gamma, beta, eps, momentum, running_mean, running_var):
+    """Combine partial statistics [nsplit_total, C, 3] (all ranks); returns (mean, rstd, scale,
+    shift) and updates the running statistics like bn_stats."""
+    _chk(ws_all, 'ws_all', 3)
+    C = ws_all.shape[1]
+    mean = torch.empty(C, device=ws_all.device, dtype=torch.float32)
+    rstd, scale, shift = torch.empty_like(mean), torch.empty_like(mean), torch.empty_like(mean)
+    check(_lib.load().segan_bn_final(_ptr(ws_all), ws_all.shape[0], _ptr(gamma), _ptr(beta), eps,
+                                     momentum, _ptr(running_mean), _ptr(running_var), _ptr(mean),
+                                     _ptr(rstd), _ptr(scale), _ptr(shift), C, _stream()), 'bn_final')
+    return mean, rstd, scale, shift
+
+
+def act_bwd_bn_reduce(a, dh, slope, bn, dslope=None, dgamma=None, dbeta=None):
+    """First half of the BatchNorm backward: per-channel (sum g, sum g*xhat) of this rank's
+    samples -> totals [C, 2]; accumulates dslope / dgamma / dbeta.  Returns (totals, ws)."""
+    _chk(a, 'a', 3)
+    B, C, L = a.shape
+    mean, rstd, gamma, beta = bn
+    totals = torch.empty((C, 2), device=a.device, dtype=torch.float32)
+    ws = _ws(B, C, L, 4, 2, a.device)
+    check(_lib.load().segan_act_bwd_bn_reduce(_ptr(a), _ptr(dh), _ptr(slope), _ptr(mean), _ptr(rstd),
+                                              _ptr(gamma), _ptr(beta), _ptr(dslope), _ptr(dgamma),
+                                              _ptr(dbeta), _ptr(totals), _ptr(ws), B, C, L, _stream()),
+          'act_bwd_bn_reduce')
+    return totals, ws
+
+
+def act_bwd_bn_apply(a, dh, slope, bn, totals, count_total, dbias=None, ws=None):
+    """Second half: da from the (globally summed) totals and the global element count."""
+    _chk(a, 'a', 3)
+    B, C, L = a.shape
+    mean, rstd, gamma, beta = bn
+    da = torch.empty_like(a)
+    if ws is None:
+        ws = _ws(B, C, L, 4, 2, a.device)
+    check(_lib.load().segan_act_bwd_bn_apply(_ptr(a), _ptr(dh), _ptr(slope), _ptr(mean), _ptr(rstd),
+                                             _ptr(gamma), _ptr(beta), _ptr(totals), _ptr(da),
+                                             _ptr(dbias), _ptr(ws), B, C, L, float(count_total),
+                                             _stream()), 'act_bwd_bn_apply')
+    return da
+
+
 def affine_prelu(x, scale=None, shift=None, slope=None):
     _chk(x, 'x', 3)
     B, C, L = x.shape

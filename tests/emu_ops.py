@@ -114,6 +114,67 @@ def bn_stats(x, gamma, beta, eps, momentum, running_mean, running_var):
     return mean.float(), rstd.float(), scale.float(), shift.float()
 
 
+def bn_partial(x):
+    xd = x.double()
+    n = float(x.shape[0] * x.shape[2])
+    mean = xd.mean((0, 2))
+    m2 = ((xd - mean.view(1, -1, 1)) ** 2).sum((0, 2))
+    return torch.stack((torch.full_like(mean, n), mean, m2), 1).float().unsqueeze(0)   # [1, C, 3]
+
+
+def bn_final(ws_all, gamma, beta, eps, momentum, running_mean, running_var):
+    w = ws_all.double()
+    n, mean, m2 = torch.zeros(w.shape[1], dtype=torch.float64), None, None
+    for s_ in range(w.shape[0]):                       # Chan et al. pairwise combination
+        nb, mb, qb = w[s_, :, 0], w[s_, :, 1], w[s_, :, 2]
+        if mean is None:
+            n, mean, m2 = nb.clone(), mb.clone(), qb.clone()
+            continue
+        tot = n + nb
+        d = mb - mean
+        mean = mean + d * nb / tot
+        m2 = m2 + qb + d * d * n * nb / tot
+        n = tot
+    var = m2 / n
+    rstd = (var + eps).rsqrt()
+    scale = gamma.detach().double() * rstd
+    shift = beta.detach().double() - mean * scale
+    if running_mean is not None:
+        running_mean.mul_(1 - momentum).add_(momentum * mean.float())
+        running_var.mul_(1 - momentum).add_(momentum * (m2 / (n - 1).clamp_min(1)).float())
+    return mean.float(), rstd.float(), scale.float(), shift.float()
+
+
+def _bn_bwd_terms(a, dh, slope, bn):
+    mean, rstd, gamma, beta = bn
+    ad = a.double()
+    mu, rs = mean.double().view(1, -1, 1), rstd.double().view(1, -1, 1)
+    ga, be = gamma.detach().double().view(1, -1, 1), beta.detach().double().view(1, -1, 1)
+    sl = slope.detach().double().view(1, -1, 1)
+    xh = (ad - mu) * rs
+    v = ga * xh + be
+    dhd = dh.double()
+    g = dhd * torch.where(v > 0, torch.ones_like(v), sl.expand_as(v))
+    return xh, v, g, dhd, ga, rs
+
+
+def act_bwd_bn_reduce(a, dh, slope, bn, dslope=None, dgamma=None, dbeta=None):
+    xh, v, g, dhd, ga, rs = _bn_bwd_terms(a, dh, slope, bn)
+    _acc(dslope, (dhd * torch.where(v > 0, torch.zeros_like(v), v)).sum((0, 2)))
+    db, dg = g.sum((0, 2)), (g * xh).sum((0, 2))
+    _acc(dbeta, db)
+    _acc(dgamma, dg)
+    return torch.stack((db, dg), 1).float().contiguous(), None
+
+
+def act_bwd_bn_apply(a, dh, slope, bn, totals, count_total, dbias=None, ws=None):
+    xh, v, g, dhd, ga, rs = _bn_bwd_terms(a, dh, slope, bn)
+    db, dg = totals[:, 0].double().view(1, -1, 1), totals[:, 1].double().view(1, -1, 1)
+    d = ga * rs * (g - db / count_total - xh * dg / count_total)
+    _acc(dbias, d.sum((0, 2)))
+    return d.float()
+
+
 def affine_prelu(x, scale=None, shift=None, slope=None):
     return _mat(ops.Src(x, scale=scale, shift=shift, slope=slope)).float()
 
@@ -351,7 +412,8 @@ _NAMES = ['conv1d_fwd', 'conv1d_dgrad', 'wgrad', 'deconv1d_fwd', 'deconv1d_dgrad
           'affine_prelu', 'sum_skip', 'bce_logits_const', 'bce_logits_const_bwd', 'act_bwd', 'tanh_bwd', 'linear_fwd', 'linear_dgrad', 'linear_wgrad',
           'bias_prelu_rows', 'bias_prelu_rows_bwd', 'mse_const', 'mse_const_bwd', 'l1_mean',
           'l1_bwd', 'stft_basis', 'stft_frames', 'stft_spectrum', 'stft_spectrum_bwd', 'powdb',
-          'powdb_bwd', 'stft_overlap_add', 'snorm_fwd', 'snorm_bwd', 'rmsprop_step', 'adam_step', 'fill_', 'scale_', '_chk']
+          'powdb_bwd', 'stft_overlap_add', 'snorm_fwd', 'snorm_bwd', 'bn_partial', 'bn_final', 'act_bwd_bn_reduce',
+          'act_bwd_bn_apply', 'rmsprop_step', 'adam_step', 'fill_', 'scale_', '_chk']
 
 
 def install():

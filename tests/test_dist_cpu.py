@@ -79,7 +79,7 @@ def _dp_opts():
     return o, fx
 
 
-def _dp_step(o, fx, clean, noisy, z, seed):
+def _dp_step(o, fx, clean, noisy, z, seed, buffers=False):
     """One GAN step on CPU (test-only emulation of the kernel entry points)."""
     import random
     import sys
@@ -101,6 +101,9 @@ def _dp_step(o, fx, clean, noisy, z, seed):
     out = {'Dg.' + k: p.grad.detach().clone() for k, p in m.D.named_parameters()}
     out.update({'Gg.' + k: p.grad.detach().clone() for k, p in m.G.named_parameters()})
     out.update({'Dw.' + k: p.detach().clone() for k, p in m.D.named_parameters()})
+    if buffers:
+        out.update({'Db.' + k: b.detach().clone().float() for k, b in m.D.named_buffers()
+                    if 'running' in k})
     emu_ops.uninstall()
     return out
 
@@ -149,3 +152,55 @@ def test_two_rank_gan_step_equals_the_full_batch_step():
             # gradients: fp32 summation order; weights: within 10 % of an RMSprop step
             tol = 5e-5 if k.startswith('Dw.') else 2e-5 * scale
             assert err < tol, (k, r, err)
+
+
+def _syncbn_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank), SEGAN_SYNC_BN='1')
+    torch.set_num_threads(2)
+    from segan_pytorch_amd import distributed as sdist
+    sdist.init_from_env(backend='gloo')
+    assert sdist.sync_bn_enabled()
+    o, fx = _dp_opts()
+    o['dnorm_type'] = 'bnorm'
+    g = torch.Generator().manual_seed(3)
+    clean = torch.rand(4, 1, 1024, generator=g) * 2 - 1
+    noisy = (clean + 0.1 * torch.randn(4, 1, 1024, generator=g)).clamp(-1, 1)
+    z = torch.randn(4, 32, 16, generator=g)
+    sl = slice(2 * rank, 2 * rank + 2)
+    out = _dp_step(o, fx, clean[sl].contiguous(), noisy[sl].contiguous(), z[sl].contiguous(), 11,
+                   buffers=True)
+    q.put((rank, {k: v.numpy() for k, v in out.items()}))
+    dist.destroy_process_group()
+
+
+def test_two_rank_sync_batchnorm_equals_the_full_batch_step():
+    """SEGAN_SYNC_BN=1: with D's BatchNorm statistics and backward sums taken over both ranks,
+    the 2 + 2 data-parallel step reproduces the single-process step at batch 4 — gradients,
+    stepped weights and the BatchNorm running statistics."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_syncbn_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    o, fx = _dp_opts()
+    o['dnorm_type'] = 'bnorm'
+    g = torch.Generator().manual_seed(3)
+    clean = torch.rand(4, 1, 1024, generator=g) * 2 - 1
+    noisy = (clean + 0.1 * torch.randn(4, 1, 1024, generator=g)).clamp(-1, 1)
+    z = torch.randn(4, 32, 16, generator=g)
+    full = _dp_step(o, fx, clean, noisy, z, 11, buffers=True)
+    for k, v in full.items():
+        if (k.endswith('conv.bias') and k.startswith(('Dg.', 'Dw.'))) or k.endswith('running_mean'):
+            continue            # zero-gradient bias in front of BatchNorm: roundoff noise that
+                                # RMSprop turns into a +-lr step; the running mean tracks it
+        scale = max(v.abs().max().item(), 1e-30)
+        for r in (0, 1):
+            err = (torch.from_numpy(res[r][k]).double() - v.double()).abs().max().item()
+            tol = 5e-5 if k.startswith('Dw.') else 5e-5 * scale
+            assert err < tol, (k, r, err, scale)

@@ -614,3 +614,42 @@ def test_gemm_layouts(M, N, K, a_kcontig, b_kcontig):
     assert max_rel(C, ref) < TOL
     ops.gemm(Ad, sam, sak, Bd, sbk, sbn, C, M, N, K, False)
     assert max_rel(C, 2 * ref) < TOL
+
+
+def test_split_batchnorm_entry_points_equal_the_fused_ones():
+    """The two-call forms used by synchronised BatchNorm (bn_partial + bn_final, and
+    act_bwd_bn_reduce + act_bwd_bn_apply) against the fused calls on one rank, and with the
+    partials of two half-batches gathered as two 'ranks'."""
+    ops = _ops()
+    B, C, L = 6, 20, 256
+    x = rnd(B, C, L, seed=1).to(DEV) * 1.7 + 0.3
+    gamma, beta = (rnd(C, seed=2).abs() + 0.5).to(DEV), rnd(C, seed=3).to(DEV)
+    slope = (rnd(C, seed=4).abs() * 0.3).to(DEV)
+    rm0, rv0 = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    rm1, rv1 = rm0.clone(), rv0.clone()
+    rm2, rv2 = rm0.clone(), rv0.clone()
+    fused = ops.bn_stats(x, gamma, beta, 1e-5, 0.1, rm0, rv0)
+    split = ops.bn_final(ops.bn_partial(x), gamma, beta, 1e-5, 0.1, rm1, rv1)
+    halves = torch.cat((ops.bn_partial(x[:3].contiguous()), ops.bn_partial(x[3:].contiguous())), 0)
+    two = ops.bn_final(halves.contiguous(), gamma, beta, 1e-5, 0.1, rm2, rv2)
+    for a, b_, c in zip(fused, split, two):
+        assert max_rel(b_, a) < 1e-6 and max_rel(c, a) < 1e-5
+    assert max_rel(rv1, rv0) < 1e-6 and max_rel(rv2, rv0) < 1e-5 and max_rel(rm2, rm0) < 1e-5
+    mean, rstd = fused[0], fused[1]
+    bn = (mean, rstd, gamma, beta)
+    dh = rnd(B, C, L, seed=5).to(DEV)
+    g0 = [torch.zeros(C, device=DEV) for _ in range(4)]
+    g1 = [torch.zeros(C, device=DEV) for _ in range(4)]
+    ref = ops.act_bwd(x, dh, slope=slope, bn=bn, dslope=g0[0], dgamma=g0[1], dbeta=g0[2], dbias=g0[3])
+    totals, ws = ops.act_bwd_bn_reduce(x, dh, slope, bn, g1[0], g1[1], g1[2])
+    got = ops.act_bwd_bn_apply(x, dh, slope, bn, totals, B * L, g1[3], ws)
+    assert max_rel(got, ref) < 1e-6
+    for a, b_ in zip(g0[:3], g1[:3]):
+        assert max_rel(b_, a) < 1e-6
+    assert (g1[3] - g0[3]).abs().max().item() < 1e-4 * max(1.0, dh.abs().max().item())
+    # two "ranks": totals summed over the halves, global count
+    h = [(x[:3].contiguous(), dh[:3].contiguous()), (x[3:].contiguous(), dh[3:].contiguous())]
+    parts = [ops.act_bwd_bn_reduce(xa, da_, slope, bn) for xa, da_ in h]
+    tot = parts[0][0] + parts[1][0]
+    da2 = torch.cat([ops.act_bwd_bn_apply(xa, da_, slope, bn, tot, B * L) for xa, da_ in h], 0)
+    assert max_rel(da2, ref) < 1e-5

@@ -97,6 +97,9 @@ FLAGS = [
     # ---- additions ----
     ('--synthetic', dict(type=int, default=0,
                          help='train on this many fixed-seed synthetic chunk pairs')),
+    ('--sync_bn', dict(action='store_true', default=False,
+                       help='data parallel: take D\'s BatchNorm statistics over the global batch '
+                            '(N ranks of batch b behave like one process at batch N*b)')),
     ('--pcm_shard', dict(type=str, default=None,
                          help='prefix of a pre-sliced int16 shard (scripts/make_pcm_shard.py): batches '
                               'are normalised and pre-emphasised on the GPU')),
@@ -112,6 +115,8 @@ def build_parser():
 
 
 def main(opts):
+    if getattr(opts, 'sync_bn', False):
+        os.environ['SEGAN_SYNC_BN'] = '1'
     rank, world, local = sdist.init_from_env()
     use_cuda = torch.cuda.is_available() and not opts.no_cuda
     if not use_cuda:
