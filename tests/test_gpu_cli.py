@@ -40,3 +40,31 @@ def test_train_then_clean(tmp_path):
     assert out.returncode == 0, out.stderr[-2000:]
     rate, enh = wavfile.read(str(out_dir / 'a.wav'))
     assert rate == 16000 and enh.shape[0] == 21000 and np.isfinite(enh).all()
+
+
+def test_train_wsegan_snorm_from_a_pcm_shard(tmp_path):
+    """The run_wsegan_train.sh flavour end to end: int16 shard -> GPU normalise / pre-emphasis
+    -> WSEGAN step with the misaligned pair, spectral norm in D and Adam."""
+    from segan_pytorch_amd.datasets import build_pcm_shard
+    rng = np.random.default_rng(1)
+    cd, nd = tmp_path / 'clean', tmp_path / 'noisy'
+    cd.mkdir()
+    nd.mkdir()
+    for i in range(3):
+        c = (rng.standard_normal(6000) * 4000).astype(np.int16)
+        wavfile.write(str(cd / 'u{}.wav'.format(i)), 16000, c)
+        wavfile.write(str(nd / 'u{}.wav'.format(i)), 16000,
+                      (c + rng.standard_normal(6000) * 500).astype(np.int16))
+    n = build_pcm_shard(str(cd), str(nd), str(tmp_path / 'sh'), slice_size=1024, stride=0.5)
+    assert n >= 8
+    ck = str(tmp_path / 'ckpt')
+    cmd = [sys.executable, os.path.join(ROOT, 'train.py'), '--save_path', ck, '--pcm_shard',
+           str(tmp_path / 'sh'), '--batch_size', '4', '--epoch', '1', '--save_freq', '1',
+           '--wsegan', '--misalign_pair', '--dnorm_type', 'snorm', '--opt', 'adam',
+           '--genc_fmaps', '8', '16', '32', '--denc_fmaps', '8', '16', '32', '--genc_poolings',
+           '4', '4', '4', '--denc_poolings', '4', '4', '4', '--z_dim', '32', '--slice_size', '1024',
+           '--num_workers', '0']
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    names = os.listdir(ck)
+    assert any(n_.startswith('weights_EOE_G-Generator-') for n_ in names)
