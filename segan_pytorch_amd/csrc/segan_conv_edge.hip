@@ -133,10 +133,149 @@ static int launch_tsmall_sn(const CorrArgs& a, const float* w, int K, int M, int
   return launch_tsmall_snk<S, N, 0>(a, w, K, M, pad, st);
 }
 
+
+// The same T form with FOUR consecutive low-rate positions per thread (stride 4, width 31:
+// the SEGAN geometry).  The one-position kernel above is LDS-issue bound (9 window reads per
+// 31 FMAs); here a thread reads its 12-entry window with three 16-byte LDS loads, does 4 x 31
+// FMAs per output channel on it, and owns 16 consecutive output samples (four 16-byte stores
+// when the run is aligned and unrolled).  A workgroup covers 1024 positions of one sample.
+template <int N, int PM>
+__global__ __launch_bounds__(256) void tsmall4_kernel(const CorrArgs a, const float* __restrict__ w,
+                                                      int M) {
+  constexpr int S = 4, U = 8, KT = 31, Q = 4;
+  constexpr int MC = 8;                    // input channels per LDS chunk
+  constexpr int TWQ = Q * 256 + 12;        // window entries a workgroup touches (>= 1024 + U + 1)
+  __shared__ __attribute__((aligned(16))) float xs[MC][TWQ];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y;
+  const int q0 = blockIdx.x * (Q * 256);
+  float acc[Q][S][N];
+#pragma unroll
+  for (int i = 0; i < Q; ++i)
+#pragma unroll
+    for (int r = 0; r < S; ++r)
+#pragma unroll
+      for (int n = 0; n < N; ++n) acc[i][r][n] = 0.0f;
+  // staging: window entry j <-> input time q0 + win_start + j; thread owns entries
+  // tid + 256*i (i < 4) and 1024 + tid (tid < 12)
+  int so[5];
+  unsigned sok = 0u;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int j = tid + 256 * i;
+    const int t = q0 + a.win_start + j;
+    const bool ok = (i < 4 || tid < 12) && t >= 0 && t < a.Lin;
+    so[i] = ok ? t : 0;
+    if (ok) sok |= 1u << i;
+  }
+  const int bo0 = b * a.in.C0 * a.Lin, bo1 = b * a.in.C1 * a.Lin;
+  for (int mc0 = 0; mc0 < M; mc0 += MC) {
+#pragma unroll
+    for (int mc = 0; mc < MC; ++mc) {
+      const bool mok = mc0 + mc < M;
+      const int m = mok ? mc0 + mc : 0;
+      const bool seg1 = m >= a.in.C0;
+      const float* rowp = seg1 ? a.in.p1 + (size_t)(m - a.in.C0) * a.Lin + bo1
+                               : a.in.p0 + (size_t)m * a.Lin + bo0;
+      const ChanXf xf = segan_chan_xf(a.in, m);
+      float v[5];
+#pragma unroll
+      for (int i = 0; i < 5; ++i) v[i] = rowp[so[i]];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        xs[mc][tid + 256 * i] = (mok && ((sok >> i) & 1u)) ? segan_apply_xf(xf, v[i]) : 0.0f;
+      if (tid < 12) xs[mc][1024 + tid] = (mok && ((sok >> 4) & 1u)) ? segan_apply_xf(xf, v[4]) : 0.0f;
+    }
+    __syncthreads();
+    const int mcn = min(MC, M - mc0);
+    for (int mc = 0; mc < mcn; ++mc) {
+      float xv[12];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const f32x4 t4 = *reinterpret_cast<const f32x4*>(&xs[mc][4 * tid + 4 * i]);
+        xv[4 * i] = t4[0]; xv[4 * i + 1] = t4[1]; xv[4 * i + 2] = t4[2]; xv[4 * i + 3] = t4[3];
+      }
+      const float* wm = w + (size_t)(mc0 + mc) * N * KT;
+#pragma unroll
+      for (int r = 0; r < S; ++r) {
+        const int rho = (r + PM) % S, cs = (r + PM) / S;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int k = S * u + rho;
+          if (k < KT) {
+#pragma unroll
+            for (int n = 0; n < N; ++n) {
+              const float wv = wm[n * KT + k];
+#pragma unroll
+              for (int i = 0; i < Q; ++i)
+                acc[i][r][n] = fmaf(wv, xv[i + cs + (U - 1) - u], acc[i][r][n]);
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int n = 0; n < N; ++n) {
+    const float bs = a.bias ? a.bias[n] : 0.0f;
+    const size_t rowoff = (size_t)b * N + n;
+#pragma unroll
+    for (int i = 0; i < Q; ++i) {
+      const int q = q0 + Q * tid + i;
+      if (q >= a.Tcols) continue;
+      float v[S];
+#pragma unroll
+      for (int r = 0; r < S; ++r) {
+        v[r] = acc[i][r][n] + bs;
+        if (a.act == SEGAN_ACT_TANH) v[r] = tanhf(v[r]);
+      }
+      const int i0 = S * q - a.o_padL;
+      if (a.o_roll == 0 && i0 >= 0 && i0 + 3 < a.Lout && (a.o_padL & 3) == 0) {
+        const f32x4 o = {v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(a.out0 + rowoff * (size_t)a.Lout + i0) = o;
+        continue;
+      }
+#pragma unroll
+      for (int r = 0; r < S; ++r) {
+        const int P = S * q + r;
+        int ii = P - a.o_padL;
+        if (ii >= 0 && ii < a.Lout) {
+          if (a.o_roll != 0) {
+            ii -= a.o_roll;
+            if (ii < 0) ii += a.Lout;
+            if (ii >= a.Lout) ii -= a.Lout;
+          }
+          a.out0[rowoff * (size_t)a.Lout + ii] = v[r];
+        } else if (a.halo != nullptr) {
+          const int hl = a.o_padL + a.o_padR;
+          if (ii < 0) a.halo[rowoff * hl + P] = v[r];
+          else if (ii - a.Lout < a.o_padR) a.halo[rowoff * hl + a.o_padL + (ii - a.Lout)] = v[r];
+        }
+      }
+    }
+  }
+}
+
+template <int N>
+static int launch_tsmall4(const CorrArgs& a, const float* w, int M, int pad, hipStream_t st) {
+  dim3 grid(ceil_div(a.Tcols, 1024), a.B);
+  switch (pad % 4) {
+    case 0: hipLaunchKernelGGL((tsmall4_kernel<N, 0>), grid, dim3(256), 0, st, a, w, M); break;
+    case 1: hipLaunchKernelGGL((tsmall4_kernel<N, 1>), grid, dim3(256), 0, st, a, w, M); break;
+    case 2: hipLaunchKernelGGL((tsmall4_kernel<N, 2>), grid, dim3(256), 0, st, a, w, M); break;
+    default: hipLaunchKernelGGL((tsmall4_kernel<N, 3>), grid, dim3(256), 0, st, a, w, M); break;
+  }
+  return segan_check_launch("tsmall4_kernel");
+}
+
 // `a` is filled exactly as for the MFMA T form; w is the UNPACKED weight [M][N][K]
 int segan_launch_tsmall(CorrArgs& a, const float* w, int K, int M, int N, int S, int pad,
                          hipStream_t st) {
   if (int e = segan_src_defaults(&a.in, st, "tsmall")) return e;
+  static const bool q4_on = [] { const char* e = getenv("SEGAN_TSMALL4"); return !e || atoi(e) != 0; }();
+  if (q4_on && S == 4 && K == 31 && a.Tcols >= 1024)
+    return N == 1 ? launch_tsmall4<1>(a, w, M, pad, st) : launch_tsmall4<2>(a, w, M, pad, st);
   if (N == 1) {
     if (S == 4) return launch_tsmall_sn<4, 1>(a, w, K, M, pad, st);
     if (S == 2) return launch_tsmall_sn<2, 1>(a, w, K, M, pad, st);

@@ -415,6 +415,9 @@ EDGE_CONV = [
     (2, 1, 5, 100, 1, 31, -2),
     (4, 2, 64, 64, 4, 5, 0),
     (300, 2, 64, 512, 4, 31, 2),
+    # long enough for the 4-positions-per-thread edge kernel (L/4 + 8 >= 1024)
+    (2, 2, 64, 8192, 4, 31, 3),
+    (3, 1, 16, 4112, 4, 31, -7),
 ]
 
 
@@ -426,6 +429,8 @@ def test_conv_edge_geometry(B, N, M, L, S, K, roll):
 EDGE_DECONV = [
     (1, 5, 7, 8, 4, 31), (1, 3, 2, 16, 4, 31), (300, 4, 6, 8, 4, 31), (2, 130, 3, 16, 2, 31),
     (2, 1024, 24, 16, 4, 31),
+    # last-layer shape (1-2 output channels) long enough for the 4-positions-per-thread kernel
+    (2, 128, 1, 2048, 4, 31), (3, 20, 2, 1100, 4, 31),
 ]
 
 
