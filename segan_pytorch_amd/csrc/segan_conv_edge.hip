@@ -358,8 +358,86 @@ __global__ __launch_bounds__(256) void fsmall_kernel(const CorrArgs a, int M) {
   }
 }
 
+
+// The same F form with FOUR consecutive output positions per thread (stride 4): the per-m tap
+// broadcast (16 LDS reads for 2 channels) then feeds 4 x 62 FMAs instead of 62, and a thread
+// stores 16 contiguous bytes per output channel.  A workgroup covers 1024 positions.
+template <int N>
+__global__ __launch_bounds__(256) void fsmall4_kernel(const CorrArgs a, int M) {
+  constexpr int S = 4, U = 8, Q = 4;
+  constexpr int XW = S * Q * 256 + 32;     // padded input samples a workgroup touches
+  constexpr int WST = N * 32 + 4;
+  constexpr int XR = S * (Q - 1) + 32;     // 44 input samples per thread and channel
+  __shared__ __attribute__((aligned(16))) float xs[N][XW];
+  __shared__ __attribute__((aligned(16))) float ws[64 * WST];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y;
+  const int t0 = blockIdx.x * (Q * 256);
+  for (int j = tid; j < XW; j += 256) {
+    const int idx = segan_hi_index(S * t0 + j, a.Lin, a.padL, a.mode, a.roll);
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      float v = 0.0f;
+      if (idx >= 0) v = segan_apply_xf(segan_chan_xf(a.in, n), segan_src_row(a.in, b, n, a.Lin)[idx]);
+      xs[n][j] = v;
+    }
+  }
+  const int t = t0 + Q * tid;
+  for (int m0 = 0; m0 < M; m0 += 64) {
+    for (int e = tid; e < 64 * N * 32; e += 256) {
+      const int ml = e & 63, nk = e >> 6;
+      const int n = nk >> 5, k = nk & 31;
+      const int row = (n * S + k % S) * U + k / S;
+      const int m = m0 + ml;
+      ws[ml * WST + n * 32 + k] = m < a.RP ? a.wp[(size_t)row * a.RP + m] : 0.0f;
+    }
+    __syncthreads();
+    float xv[N][XR];
+#pragma unroll
+    for (int n = 0; n < N; ++n)
+#pragma unroll
+      for (int i = 0; i < XR / 4; ++i) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(&xs[n][S * Q * tid + 4 * i]);
+        xv[n][4 * i] = v[0]; xv[n][4 * i + 1] = v[1]; xv[n][4 * i + 2] = v[2]; xv[n][4 * i + 3] = v[3];
+      }
+    const int mcn = min(64, M - m0);
+    for (int ml = 0; ml < mcn; ++ml) {
+      const float bs = a.bias ? a.bias[m0 + ml] : 0.0f;
+      float acc[Q] = {bs, bs, bs, bs};
+#pragma unroll
+      for (int n = 0; n < N; ++n) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(&ws[ml * WST + n * 32 + 4 * i]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int q = 0; q < Q; ++q) acc[q] = fmaf(wv[e], xv[n][S * q + 4 * i + e], acc[q]);
+        }
+      }
+      float* o = a.out0 + ((size_t)b * M + m0 + ml) * a.Lout + t;
+      if (t + Q <= a.Lout && (a.Lout & 3) == 0) {
+        const f32x4 ov = {acc[0], acc[1], acc[2], acc[3]};
+        *reinterpret_cast<f32x4*>(o) = ov;
+      } else {
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+          if (t + q < a.Lout) o[q] = acc[q];
+      }
+    }
+    __syncthreads();
+  }
+}
+
 int segan_launch_fsmall(CorrArgs& a, int M, int N, int S, hipStream_t st) {
   if (int e = segan_src_defaults(&a.in, st, "fsmall")) return e;
+  static const bool q4_on = [] { const char* e = getenv("SEGAN_FSMALL4"); return !e || atoi(e) != 0; }();
+  if (q4_on && S == 4 && a.Lout >= 1024) {
+    dim3 grid4(ceil_div(a.Lout, 1024), a.B);
+    if (N == 1) hipLaunchKernelGGL((fsmall4_kernel<1>), grid4, dim3(256), 0, st, a, M);
+    else hipLaunchKernelGGL((fsmall4_kernel<2>), grid4, dim3(256), 0, st, a, M);
+    return segan_check_launch("fsmall4_kernel");
+  }
   dim3 grid(ceil_div(a.Lout, 256), a.B);
 #define FS(SS, NN) hipLaunchKernelGGL((fsmall_kernel<SS, NN>), grid, dim3(256), 0, st, a, M)
   if (N == 1) { if (S == 4) FS(4, 1); else if (S == 2) FS(2, 1); else FS(1, 1); }
