@@ -1,7 +1,7 @@
 """Diagnostic: gradient of the adversarial loss w.r.t. the generator output (through D)
 on the GPU vs the CPU oracle, using the SAME (GPU-side) discriminator weights."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, ROOT + '/tests', ROOT + '/oracle'):
     sys.path.insert(0, p)
 import random

@@ -1,7 +1,7 @@
 """Diagnostic: G-phase gradients on the GPU vs the CPU oracle fed with the GPU's own
 post-step discriminator weights (separates kernel error from RMSprop sensitivity)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, ROOT + '/tests', ROOT + '/oracle'):
     sys.path.insert(0, p)
 import random

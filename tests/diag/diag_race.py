@@ -3,7 +3,7 @@ backward on fixed inputs and report any run that deviates from the first by more
 atomics noise.  Run it while another process loads the GPU."""
 import os, sys, random
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 sys.path.insert(0, os.path.join(ROOT, 'oracle'))

@@ -2,7 +2,7 @@
 seeds fixed: every quantity must repeat to fp32-atomics noise.  Prints which ones deviate."""
 import os, sys, random, copy
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 sys.path.insert(0, os.path.join(ROOT, 'oracle'))

@@ -190,7 +190,7 @@ def _default_step_attempt(fx):
                      (g_adv, 'g_adv_loss'), (g_l1, 'g_l1_loss')):
         # d_fake / g_adv are D(G(noisy)): the discriminator amplifies the generator's ~1e-6
         # output roundoff (and g_adv sees D after its ill-conditioned step, see (2)); measured
-        # worst case over repeated runs 2.4e-5 (scripts/diag_flaky.py)
+        # worst case over repeated runs 2.4e-5 (tests/diag/diag_flaky.py)
         assert max_rel(got, fx[key]) < (1e-4 if key in ('g_adv_loss', 'd_fake_loss') else ACT_TOL), key
     dn, gn = dict(m.D.named_parameters()), dict(m.G.named_parameters())
     # (1) discriminator-phase gradients against the reference: strict
@@ -206,7 +206,7 @@ def _default_step_attempt(fx):
     # 25.8 M weights): two correct fp32 implementations end up with post-step weights that
     # differ by up to a full step (5e-4) on those elements, and the generator gradient
     # inherits ~1e-3 of that (worst sampled element over repeated runs: 1e-2, varying with
-    # the order of the fp32 atomics; scripts/diag_flaky.py).  Loose bound here, strict in (3).
+    # the order of the fp32 atomics; tests/diag/diag_flaky.py).  Loose bound here, strict in (3).
     for k, c in fx['g_grads'].items():
         _chk(gn[k].grad, c, 5e-2)
     # (3) strict: the same generator-phase gradients against the CPU oracle evaluated with
@@ -233,7 +233,7 @@ def test_default_segan_plus_step_matches_reference(segan_plus_b2):
     start at slope 0 (ReLU): when the post-step D happens to put a deep-layer pre-activation
     within fp32 roundoff of zero, the CPU and the GPU take different sides of the gate, the
     gradient of that unit's 1024-sample receptive field changes by a discrete amount and every
-    generator gradient moves by ~1e-3 (seen in 2 of 25 steps; scripts/diag_race2.py shows the
+    generator gradient moves by ~1e-3 (seen in 2 of 25 steps; tests/diag/diag_race2.py shows the
     contiguous 1024-sample blocks).  The post-step D differs from run to run (order of the fp32
     atomics through the ill-conditioned RMSprop step), so the attempts are independent: every
     attempt must stay within 2e-2 and one of up to three must meet the strict 1e-4."""
