@@ -1,0 +1,46 @@
+"""Summarise the SQ counter passes of scripts/pmc_sq.sh per kernel template:
+MFMA-busy share of the SIMD time, VALU / LDS / VMEM instructions per MFMA, wait buckets.
+usage: python scripts/pmc_sq_summary.py OUTDIR LAYER [LAYER...] > profiles/rNN_sq_counters.json
+
+SQ_VALU_MFMA_BUSY_CYCLES counts cycles, SQ_BUSY_CYCLES / SQ_WAVE_CYCLES / SQ_WAIT_* /
+SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md, cycle-constants table); with 4 SIMDs
+per CU, mfma_busy = MFMA_BUSY / (4 * 4 * BUSY_CYCLES per CU-sum) is reported both raw and as
+the ratio the guide's derived MfmaUtil uses."""
+import collections
+import csv
+import glob
+import json
+import sys
+
+out, layers = sys.argv[1], sys.argv[2:]
+res = {}
+for layer in layers:
+    per = collections.defaultdict(lambda: collections.defaultdict(float))
+    n = collections.Counter()
+    for p in 'AB':
+        for f in glob.glob('%s/sq%s_%s/**/*counter_collection.csv' % (out, p, layer), recursive=True):
+            for r in csv.DictReader(open(f)):
+                k = r['Kernel_Name']
+                if 'corr_kernel' not in k and 'wgrad_kernel' not in k:
+                    continue
+                per[k][r['Counter_Name']] += float(r['Counter_Value'])
+                if r['Counter_Name'] in ('SQ_WAVE_CYCLES', 'SQ_INSTS_MFMA'):
+                    n[(k, r['Counter_Name'])] += 1
+    for k, c in per.items():
+        mf = c.get('SQ_INSTS_MFMA', 0.0) or 1.0
+        wc = c.get('SQ_WAVE_CYCLES', 0.0) or 1.0
+        res.setdefault(layer, {})[k] = {
+            'launches': n[(k, 'SQ_WAVE_CYCLES')],
+            'mfma_busy_cycles_over_4x_busy_cycles': c.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / (4.0 * (c.get('SQ_BUSY_CYCLES', 0) or 1.0)),
+            'valu_per_mfma': c.get('SQ_INSTS_VALU', 0) / mf,
+            'lds_per_mfma': c.get('SQ_INSTS_LDS', 0) / mf,
+            'vmem_per_mfma': c.get('SQ_INSTS_VMEM', 0) / mf,
+            'salu_per_mfma': c.get('SQ_INSTS_SALU', 0) / mf,
+            'wave_cycles_wait_any': c.get('SQ_WAIT_ANY', 0) / wc,
+            'wave_cycles_wait_inst_any': c.get('SQ_WAIT_INST_ANY', 0) / wc,
+            'wave_cycles_active_inst_any': c.get('SQ_ACTIVE_INST_ANY', 0) / wc,
+            'wave_cycles_wait_inst_lds': c.get('SQ_WAIT_INST_LDS', 0) / (per[k].get('SQ_WAVE_CYCLES', 0) or 1.0),
+            'lds_bank_conflict_over_idx_active': c.get('SQ_LDS_BANK_CONFLICT', 0) / (c.get('SQ_LDS_IDX_ACTIVE', 0) or 1.0),
+            'raw': dict(c),
+        }
+json.dump(res, sys.stdout, indent=1)
