@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SEGAN_ABI_VERSION 6
+#define SEGAN_ABI_VERSION 7
 
 #define SEGAN_PAD_REFLECT 0
 #define SEGAN_PAD_ZERO 1
@@ -84,6 +84,16 @@ size_t segan_packed_bf_bytes(int M, int N, int S, int tform, int planes);
 int segan_pack_weights_bf(const float* w, void* out, int M, int N, int K, int S, int tform,
                           int pad_t, int planes, void* stream);
 
+/* Scratch of the four forward / data-gradient contractions below (`scratch`, `scratch_bytes`;
+ * may be NULL / 0).  The fp32 kernels run whole rounds of equal tiles one per workgroup and cut
+ * the tiles of the last, partial round along the contraction across ALL workgroups
+ * (stream-K); a cut tile's pieces are written to `scratch` as accumulator slabs and summed in
+ * chunk order by a second small kernel — a fixed order, so results are bit-reproducible run
+ * to run (no atomics).  segan_corr_scratch_bytes() is the size that always suffices (128 MiB);
+ * with less (or NULL) the launch simply stays one-tile-per-workgroup.  The scratch must not be
+ * shared by launches that may run concurrently (different streams). */
+size_t segan_corr_scratch_bytes(void);
+
 /* GConv1DBlock forward without norm/activation (modules.py:91-99):
  *   out[b,m,t] = bias[m] + sum_{n,k} w[m,n,k] * pad(roll(x))[b,n,S*t+k]
  * x: [B, N, L] (segan_src), out: [B, M, L/S].  mode = reflect with
@@ -93,7 +103,7 @@ int segan_pack_weights_bf(const float* w, void* out, int M, int N, int K, int S,
  * PReLU/BN through its own segan_src. */
 int segan_conv1d_fwd(const segan_src* x, const void* wf, const float* bias, float* out, int B,
                      int N, int M, int L, int K, int S, int padL, int mode, int roll,
-                     int precision, void* stream);
+                     int precision, void* scratch, size_t scratch_bytes, void* stream);
 
 /* Data gradient of the above (autograd of modules.py:98-99): dx[b,n,i] += over the
  * reflect-padded, rolled coordinates.  da: [B, M, L/S]; dx: [B, N, L] is fully
@@ -102,7 +112,7 @@ int segan_conv1d_fwd(const segan_src* x, const void* wf, const float* bias, floa
  * VALU kernel is used instead of the MFMA tile kernel and `wt` may be NULL. */
 int segan_conv1d_dgrad(const float* da, const void* wt, const float* w, float* dx, float* halo,
                        int B, int N, int M, int L, int K, int S, int padL, int roll, int precision,
-                       void* stream);
+                       void* scratch, size_t scratch_bytes, void* stream);
 
 /* Weight gradient shared by both layer types (W form):
  *   dw[m,n,k] += sum_{b,t} lo[b,m,t] * pad(roll(hi))[b,n,S*t+k]
@@ -128,14 +138,15 @@ int segan_wgrad(const segan_src* lo, const segan_src* hi, float* dw, int B, int 
  * kernel is used and `wt` may be NULL. */
 int segan_deconv1d_fwd(const segan_src* x, const void* wt, const float* w, const float* bias,
                        float* y, int B, int M, int N, int Ls, int K, int S, int pad, int act,
-                       int precision, void* stream);
+                       int precision, void* scratch, size_t scratch_bytes, void* stream);
 
 /* Data gradient of the deconv: dx[b,m,t] = sum_{n,k} w[m,n,k] * dy[b,n,S*t+k-pad].
  * The M rows are split at M0 into two destinations (dx0: [B,M0,Ls], dx1:
  * [B,M-M0,Ls]); a NULL destination skips that half's tiles entirely (the z half of
  * the first decoder layer needs no gradient). */
 int segan_deconv1d_dgrad(const float* dy, const void* wf, float* dx0, float* dx1, int B, int M,
-                         int M0, int N, int Ls, int K, int S, int pad, int precision, void* stream);
+                         int M0, int N, int Ls, int K, int S, int pad, int precision, void* scratch,
+                         size_t scratch_bytes, void* stream);
 
 /* ---- per-channel pointwise / reduction kernels ------------------------------------ */
 

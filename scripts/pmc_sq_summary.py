@@ -21,7 +21,7 @@ for layer in layers:
         for f in glob.glob('%s/sq%s_%s/**/*counter_collection.csv' % (out, p, layer), recursive=True):
             for r in csv.DictReader(open(f)):
                 k = r['Kernel_Name']
-                if 'corr_kernel' not in k and 'wgrad_kernel' not in k:
+                if 'corr' not in k and 'wgrad' not in k:
                     continue
                 per[k][r['Counter_Name']] += float(r['Counter_Value'])
                 if r['Counter_Name'] in ('SQ_WAVE_CYCLES', 'SQ_INSTS_MFMA'):

@@ -14,7 +14,7 @@ PAD_REFLECT = 0
 PAD_ZERO = 1
 ACT_NONE = 0
 ACT_TANH = 1
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class SeganSrc(Structure):
@@ -35,17 +35,18 @@ SIGNATURES = {
     'segan_pack_weights': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     'segan_packed_bf_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     'segan_pack_weights_bf': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    'segan_corr_scratch_bytes': (c_size_t, []),
     'segan_conv1d_fwd': (c_int, [_SRC, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-                                 c_int, c_int, c_int, _P]),
+                                 c_int, c_int, c_int, _P, c_size_t, _P]),
     'segan_conv1d_dgrad': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-                                   c_int, c_int, _P]),
+                                   c_int, c_int, _P, c_size_t, _P]),
     'segan_wgrad': (c_int, [_SRC, _SRC, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                             c_int, c_int, _P, _P]),
     'segan_wgrad_scratch_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
     'segan_deconv1d_fwd': (c_int, [_SRC, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-                                   c_int, c_int, _P]),
+                                   c_int, c_int, _P, c_size_t, _P]),
     'segan_deconv1d_dgrad': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-                                     c_int, c_int, _P]),
+                                     c_int, c_int, _P, c_size_t, _P]),
     'segan_bn_nsplit': (c_int, [c_int, c_int, c_int]),
     'segan_bn_stats': (c_int, [_P, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, _P, c_int, c_int,
                                c_int, _P]),

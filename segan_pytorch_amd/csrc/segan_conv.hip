@@ -21,25 +21,299 @@
 // (segan_src), so none of those tensors is ever materialised in HBM.
 #include "segan_conv_shared.h"
 
-// Staging discipline (both kernels): load_chunk() only ISSUES global loads — every
-// address is clamped to a valid element, so there is no branch and no wait between
-// them and they stay in flight under the MFMA loop; masking, the segan_src transform
-// and the LDS writes happen in store_chunk(), after the compute of the previous chunk.
-//
 // Tile geometry: MB rows x NB columns per 256-thread workgroup, waves WM x (4/WM).
 //   F form: rows = output channels m; waves 2x2.
 //   T form: rows = (phase r, channel n) with ALL S phases of MB/S channels in one tile and
 //           waves 1x4 (NB=128) so that one lane ends up holding the S consecutive output
 //           samples S*q..S*q+S-1 of a channel: full-line stores instead of stride-S ones.
+//
+// What the instruction stream beside the MFMAs costs was measured (profiles/r02_mfma_issue_cost
+// .json): v_mfma_f32_32x32x2_f32 issues every 64 cycles per SIMD, and every VALU instruction
+// any wave of that SIMD issues takes ~5 of those cycles, every VMEM instruction ~25, a
+// ds_write_b32 ~4, a ds_write_b128 ~12; SALU and ds_read_b32 are (almost) free.  The staging
+// code of corr2_kernel is therefore built from buffer loads whose per-lane offsets never
+// change (wave-uniform parts go through the SGPR offset, masking through the descriptor's
+// range check), LDS-DMA for the weight tile, and per-wave-uniform transforms.
+template <int MB, int NB, int WM, int U>
+struct TileGeom {
+  static constexpr int S = 32 / U;
+  static constexpr int WN = 4 / WM;
+  static constexpr int NI = MB / (32 * WM);
+  static constexpr int NJ = NB / (32 * WN);
+  static constexpr int NPT = MB / S;   // T form: channels per tile
+};
+
+// which tile a workgroup works on, and which chunk range of it (stream-K pieces)
+struct TileWork {
+  int tile, c0, c1;
+  bool partial;
+  int piece;   // slab index of a partial piece inside the workgroup's two slabs
+};
+
+// Work decomposition (data-parallel + stream-K hybrid).  The first a.sk_nfull tiles are
+// whole-tile work items, strided over the grid.  The remaining tiles — fewer than the grid,
+// i.e. the partial last round that would leave CUs idle — are cut in the (tile, chunk)
+// iteration space into equal contiguous ranges, one per workgroup.  A piece of a cut tile is
+// written as an accumulator slab to the stream-K workspace; corr_fixup_kernel adds the slabs
+// of a tile in chunk order (a FIXED order: results are bit-reproducible) and stores it.
+struct TileIter {
+  int tileA;
+  long unit, unit_end;
+  int first_tile;
+  __device__ __forceinline__ void init(const CorrArgs& a, int nch) {
+    tileA = blockIdx.x;
+    unit = (long)blockIdx.x * a.sk_units;
+    unit_end = min(unit + (long)a.sk_units, a.sk_total);
+    first_tile = (int)(unit / nch);
+  }
+  __device__ __forceinline__ bool next(const CorrArgs& a, int nch, TileWork& w) {
+    if (tileA < a.sk_nfull) {
+      w.tile = tileA; w.c0 = 0; w.c1 = nch; w.partial = false; w.piece = 0;
+      tileA += gridDim.x;
+      return true;
+    }
+    if (unit < unit_end) {
+      const int t = (int)(unit / nch);
+      w.c0 = (int)(unit - (long)t * nch);
+      w.c1 = min(nch, w.c0 + (int)(unit_end - unit));
+      unit += w.c1 - w.c0;
+      w.tile = a.sk_nfull + t;
+      w.partial = (w.c0 != 0) || (w.c1 != nch);
+      w.piece = t - first_tile;
+      return true;
+    }
+    return false;
+  }
+};
+
+// per-lane column bookkeeping of a tile: which (sample, time) the lane's NJ columns are and
+// where they sit in the LDS activation tile
+template <int NB, int WN, int NJ>
+__device__ __forceinline__ void lane_columns(const CorrArgs& a, const ColTile& ct, int wn, int l31,
+                                             int h, int (&col_b)[NJ], int (&col_t)[NJ],
+                                             int (&boff)[NJ]) {
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int cl = wn * (NB / WN) + 32 * j + l31;
+    const int col = ct.col0 + cl;
+    if (col < a.Ctot) {
+      const int b = col / a.Tcols;
+      col_b[j] = b;
+      col_t[j] = col - b * a.Tcols;
+      boff[j] = cl + (b - ct.b0) * a.H + h;
+    } else {
+      col_b[j] = -1;
+      col_t[j] = 0;
+      boff[j] = h;
+    }
+  }
+}
+
+// accumulator slab of a stream-K piece: [NI*NJ*4][256] float4, thread-minor (coalesced 16-byte
+// accesses)
+template <int NI, int NJ>
+__device__ __forceinline__ void slab_store(float* slab, const f32x16 (&acc)[NI][NJ], int tid) {
+  f32x4* s4 = reinterpret_cast<f32x4*>(slab);
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2],
+                         acc[i][j][4 * q + 3]};
+        s4[((i * NJ + j) * 4 + q) * 256 + tid] = v;
+      }
+}
+template <int NI, int NJ>
+__device__ __forceinline__ void slab_add(const float* slab, f32x16 (&acc)[NI][NJ], int tid) {
+  const f32x4* s4 = reinterpret_cast<const f32x4*>(slab);
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 v = s4[((i * NJ + j) * 4 + q) * 256 + tid];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] += v[e];
+      }
+}
+
+// ---- epilogue: bias, optional tanh, store of a finished tile ----
+template <int MB, int NB, int WM, int U, bool OUT_HI>
+__device__ __forceinline__ void corr_store_tile(
+    const CorrArgs& a, const f32x16 (&acc)[TileGeom<MB, NB, WM, U>::NI][TileGeom<MB, NB, WM, U>::NJ],
+    int m0, int n0, int wm, int h, const int (&col_b)[TileGeom<MB, NB, WM, U>::NJ],
+    const int (&col_t)[TileGeom<MB, NB, WM, U>::NJ]) {
+  using G = TileGeom<MB, NB, WM, U>;
+  constexpr int S = G::S, NI = G::NI, NJ = G::NJ, NPT = G::NPT;
+  if (!OUT_HI) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + 32 * (wm * NI + i) + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (row >= a.Rvalid) continue;
+        // LO store: out[b, row, t]
+        float* dst;
+        int oc, och;
+        if (row < a.OC0) { dst = a.out0; oc = a.OC0; och = row; }
+        else { dst = a.out1; oc = a.OC1; och = row - a.OC0; }
+        if (dst == nullptr) continue;
+        const float bs = a.bias ? a.bias[row] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          if (col_b[j] < 0) continue;
+          float v = acc[i][j][e] + bs;
+          if (a.act == SEGAN_ACT_TANH) v = tanhf(v);
+          dst[((size_t)col_b[j] * oc + och) * (size_t)a.Lout + col_t[j]] = v;
+        }
+      }
+    }
+  } else {
+    // HI store.  Row block ib of the tile is phase r = 32*ib / NPT of channels n0 + nl.
+    constexpr bool QUAD = (S == 4 && WM == 1 && NI == 4);  // lane holds all 4 phases of (n, q)
+    const int hl = a.o_padL + a.o_padR;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        if (col_b[j] < 0) continue;
+        const int q = col_t[j];
+        if (QUAD) {
+          const int n = n0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (n >= a.Nout) continue;
+          const float bs = a.bias ? a.bias[n] : 0.0f;
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[r] = acc[r][j][e] + bs;
+            if (a.act == SEGAN_ACT_TANH) v[r] = tanhf(v[r]);
+          }
+          const size_t rowoff = (size_t)col_b[j] * a.Nout + n;
+          const int i0 = 4 * q - a.o_padL;
+          if (a.o_roll == 0 && i0 >= 0 && i0 + 3 < a.Lout && (a.o_padL & 3) == 0) {
+            f32x4 o = {v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(a.out0 + rowoff * (size_t)a.Lout + i0) = o;
+            continue;
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int P = 4 * q + r;
+            int ii = P - a.o_padL;
+            if (ii >= 0 && ii < a.Lout) {
+              if (a.o_roll != 0) {
+                ii -= a.o_roll;
+                if (ii < 0) ii += a.Lout;
+                if (ii >= a.Lout) ii -= a.Lout;
+              }
+              a.out0[rowoff * (size_t)a.Lout + ii] = v[r];
+            } else if (a.halo != nullptr) {
+              if (ii < 0) a.halo[rowoff * hl + P] = v[r];
+              else if (ii - a.Lout < a.o_padR) a.halo[rowoff * hl + a.o_padL + (ii - a.Lout)] = v[r];
+            }
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < NI; ++i) {
+            const int rloc = 32 * (wm * NI + i) + (e & 3) + 8 * (e >> 2) + 4 * h;
+            const int r = rloc / NPT;
+            const int n = n0 + rloc % NPT;
+            if (n >= a.Nout) continue;
+            float v = acc[i][j][e] + (a.bias ? a.bias[n] : 0.0f);
+            if (a.act == SEGAN_ACT_TANH) v = tanhf(v);
+            const int P = S * q + r;
+            int ii = P - a.o_padL;
+            const size_t rowoff = (size_t)col_b[j] * a.Nout + n;
+            if (ii >= 0 && ii < a.Lout) {
+              if (a.o_roll != 0) {
+                ii -= a.o_roll;
+                if (ii < 0) ii += a.Lout;
+                if (ii >= a.Lout) ii -= a.Lout;
+              }
+              a.out0[rowoff * (size_t)a.Lout + ii] = v;
+            } else if (a.halo != nullptr) {
+              if (ii < 0) a.halo[rowoff * hl + P] = v;
+              else if (ii - a.Lout < a.o_padR) a.halo[rowoff * hl + a.o_padL + (ii - a.Lout)] = v;
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// F form: rows of a tile that all go to a NULL destination (the z half of the first decoder
+// layer's data gradient) are skipped
+template <int MB, bool OUT_HI>
+__device__ __forceinline__ bool tile_is_dead(const CorrArgs& a, int m0) {
+  if (OUT_HI) return false;
+  if (a.out0 == nullptr && m0 + MB <= a.OC0) return true;
+  if (a.out1 == nullptr && m0 >= a.OC0) return true;
+  return false;
+}
+
+// The MFMA loop over one staged chunk, shared by both kernels.  Operands of step s+1 are read
+// from LDS before the MFMAs of step s are issued (two named register sets; everything is
+// unrolled so all indices are static); sched_barrier pins that order so the LDS latency of the
+// next operands is covered by the MFMAs instead of being exposed.
+template <int MB, int U, int KC, int NI, int NJ, bool SHIFT>
+__device__ __forceinline__ void corr_mma_chunk(const float* Wl, const float* Il, int RLs,
+                                               const int (&aoff)[NI], const int (&boff)[NJ],
+                                               const int (&rsh)[NI], f32x16 (&acc)[NI][NJ]) {
+  constexpr int NBI = SHIFT ? NI : 1;
+  float av0[NI], av1[NI], bv0[NBI][NJ], bv1[NBI][NJ];
+  auto read_step = [&](int s, float (&av)[NI], float (&bv)[NBI][NJ]) {
+    const int kk = 2 * s;
+    const int c = kk / U, u = kk % U;
+    // volatile LDS pointers: every operand read stays a ds_read_b32 with an immediate offset
+    // (merged ds_read2 forms need a VALU address add per step, which costs MFMA issue time)
+    typedef const volatile __attribute__((address_space(3))) float* ldsp;
+    ldsp wr = (ldsp)(Wl + kk * MB);
+    ldsp ir = (ldsp)(Il + c * RLs + u);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) av[i] = wr[aoff[i]];
+#pragma unroll
+    for (int i = 0; i < NBI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) bv[i][j] = ir[boff[j] + (SHIFT ? rsh[i] : 0)];
+  };
+  auto mma_step = [&](const float (&av)[NI], const float (&bv)[NBI][NJ]) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[SHIFT ? i : 0][j], acc[i][j],
+                                                         0, 0, 0);
+  };
+  read_step(0, av0, bv0);
+#pragma unroll
+  for (int s = 0; s < KC / 2; s += 2) {
+    read_step(s + 1, av1, bv1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_step(av0, bv0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (s + 2 < KC / 2) read_step(s + 2, av0, bv0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_step(av1, bv1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// ====================================================================================
+// corr_kernel: the general form (any channel split, any window length up to 512, any pad
+// mode with any transform).  Staging discipline: load_chunk() only ISSUES global loads —
+// every address is clamped to a valid element, so there is no branch and no wait between
+// them and they stay in flight under the MFMA loop; masking, the segan_src transform and the
+// LDS writes happen in store_chunk(), after the compute of the previous chunk.
+// ====================================================================================
 template <int MB, int NB, int WM, int U, bool IN_HI, bool OUT_HI, bool SHIFT, int MAXPOS, int KC>
 __global__ __launch_bounds__(256, 2) void corr_kernel(const CorrArgs a) {
-  constexpr int S = 32 / U;
+  using G = TileGeom<MB, NB, WM, U>;
+  constexpr int S = G::S, WN = G::WN, NI = G::NI, NJ = G::NJ, NPT = G::NPT;
   constexpr int SI = IN_HI ? S : 1;   // indices per staged position
   constexpr int CV = KC / U;          // virtual channels per chunk
-  constexpr int WN = 4 / WM;
-  constexpr int NI = MB / (32 * WM);
-  constexpr int NJ = NB / (32 * WN);
-  constexpr int NPT = MB / S;         // T form: channels per tile
   static_assert(!OUT_HI || NPT % 32 == 0, "T-form tiles hold whole 32-row phase blocks");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -53,40 +327,17 @@ __global__ __launch_bounds__(256, 2) void corr_kernel(const CorrArgs a) {
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, h = lane >> 5;
 
-  // Work decomposition (data-parallel + stream-K hybrid).  The first a.sk_nfull tiles are
-  // whole-tile work items, strided over the grid.  The remaining tiles — fewer than the
-  // grid, i.e. the partial last round that would leave CUs idle — are cut in the (tile,
-  // chunk) iteration space into equal contiguous ranges, one per workgroup; a tile cut
-  // across workgroups is combined with fp32 atomics into the zero-initialised output (its
-  // bias is added by the piece that holds chunk 0).  Classic launch: sk_nfull = #tiles.
   const int nch = (a.Ktot + KC - 1) / KC;
-  int tileA = blockIdx.x;
-  long unit = (long)blockIdx.x * a.sk_units;
-  const long unit_end = min(unit + (long)a.sk_units, a.sk_total);
-  for (;;) {
-  int tile, c0, c1;
-  if (tileA < a.sk_nfull) {
-    tile = tileA; c0 = 0; c1 = nch;
-    tileA += gridDim.x;
-  } else if (unit < unit_end) {
-    const int t = (int)(unit / nch);
-    c0 = (int)(unit - (long)t * nch);
-    c1 = min(nch, c0 + (int)(unit_end - unit));
-    unit += c1 - c0;
-    tile = a.sk_nfull + t;
-  } else {
-    break;
-  }
-  const bool partial = (c0 != 0) || (c1 != nch);
-  const int rowtile = a.rt0 + tile / a.ncoltiles;
-  const int coltile = tile % a.ncoltiles;
+  TileIter it;
+  it.init(a, nch);
+  TileWork tw;
+  while (it.next(a, nch, tw)) {
+  const int c0 = tw.c0, c1 = tw.c1;
+  const int rowtile = a.rt0 + tw.tile / a.ncoltiles;
+  const int coltile = tw.tile % a.ncoltiles;
   const int m0 = rowtile * MB;          // F form: first row; T form: n0 = rowtile * NPT
   const int n0 = rowtile * NPT;
-  if (!OUT_HI) {
-    // dual destination: skip tiles whose rows all go to a NULL destination
-    if (a.out0 == nullptr && m0 + MB <= a.OC0) continue;
-    if (a.out1 == nullptr && m0 >= a.OC0) continue;
-  }
+  if (tile_is_dead<MB, OUT_HI>(a, m0)) continue;
   const ColTile ct = make_coltile(coltile * NB, a.Tcols, NB);
 
   // ---- per-thread staging positions of the activation tile (fixed for all chunks) ----
@@ -132,21 +383,7 @@ __global__ __launch_bounds__(256, 2) void corr_kernel(const CorrArgs a) {
     rsh[i] = SHIFT ? a.rowshift[rloc / NPT] : 0;
   }
   int col_b[NJ], col_t[NJ];
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    const int cl = wn * (NB / WN) + 32 * j + l31;
-    const int col = ct.col0 + cl;
-    if (col < a.Ctot) {
-      const int b = col / a.Tcols;
-      col_b[j] = b;
-      col_t[j] = col - b * a.Tcols;
-      boff[j] = cl + (b - ct.b0) * a.H + h;
-    } else {
-      col_b[j] = -1;
-      col_t[j] = 0;
-      boff[j] = h;
-    }
-  }
+  lane_columns<NB, WN, NJ>(a, ct, wn, l31, h, col_b, col_t, boff);
 
   f32x16 acc[NI][NJ];
 #pragma unroll
@@ -215,156 +452,248 @@ __global__ __launch_bounds__(256, 2) void corr_kernel(const CorrArgs a) {
   for (int ch = c0; ch < c1; ++ch) {
     const int buf = (ch - c0) & 1;
     if (ch + 1 < c1) load_chunk(ch + 1);
-    const float* Wl = Wl0 + buf * (KC * MB);
-    const float* Il = Il0 + buf * (CV * RLs);
-    // operands of step s+1 are read from LDS before the MFMAs of step s are issued
-    // (two named register sets; everything is unrolled so all indices are static)
-    constexpr int NBI = SHIFT ? NI : 1;
-    float av0[NI], av1[NI], bv0[NBI][NJ], bv1[NBI][NJ];
-    auto read_step = [&](int s, float (&av)[NI], float (&bv)[NBI][NJ]) {
-      const int kk = 2 * s;
-      const int c = kk / U, u = kk % U;
-      const float* wr = Wl + kk * MB;
-      const float* ir = Il + c * RLs + u;
-#pragma unroll
-      for (int i = 0; i < NI; ++i) av[i] = wr[aoff[i]];
-#pragma unroll
-      for (int i = 0; i < NBI; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) bv[i][j] = ir[boff[j] + (SHIFT ? rsh[i] : 0)];
-    };
-    auto mma_step = [&](const float (&av)[NI], const float (&bv)[NBI][NJ]) {
-#pragma unroll
-      for (int i = 0; i < NI; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[SHIFT ? i : 0][j], acc[i][j],
-                                                           0, 0, 0);
-    };
-    // sched_barrier pins "reads of step s+1, then MFMAs of step s" so the LDS latency of the
-    // next operands is covered by the MFMAs instead of being exposed
-    read_step(0, av0, bv0);
-#pragma unroll
-    for (int s = 0; s < KC / 2; s += 2) {
-      read_step(s + 1, av1, bv1);
-      __builtin_amdgcn_sched_barrier(0);
-      mma_step(av0, bv0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (s + 2 < KC / 2) read_step(s + 2, av0, bv0);
-      __builtin_amdgcn_sched_barrier(0);
-      mma_step(av1, bv1);
-      __builtin_amdgcn_sched_barrier(0);
-    }
+    corr_mma_chunk<MB, U, KC, NI, NJ, SHIFT>(Wl0 + buf * (KC * MB), Il0 + buf * (CV * RLs), RLs,
+                                             aoff, boff, rsh, acc);
     if (ch + 1 < c1) store_chunk(ch + 1, buf ^ 1);
     __syncthreads();
   }
 
-  // ---- epilogue ----
-  const bool add_bias = (c0 == 0);
-  if (!OUT_HI) {
+  if (tw.partial)
+    slab_store<NI, NJ>(a.sk_ws + (size_t)(blockIdx.x * 2 + tw.piece) * (MB * NB), acc, tid);
+  else
+    corr_store_tile<MB, NB, WM, U, OUT_HI>(a, acc, m0, n0, wm, h, col_b, col_t);
+  }  // tile loop
+}
+
+// ====================================================================================
+// corr2_kernel: the same contraction with a staging path that costs the matrix pipe almost
+// nothing (see the head of this file).  Per chunk of KC = 32 contraction rows a wave issues
+//   * NPASS buffer_load_dwordx4 ... lds : the weight tile goes HBM/L2 -> LDS directly;
+//   * <= 4 buffer_load_dword with per-lane offsets that never change: a wave stages ONE
+//     (virtual) channel of the chunk, positions lane + 64*i; everything that varies per chunk
+//     (channel row, channel segment) is wave-uniform and goes through the scalar offset, and
+//     masked positions carry an out-of-range offset (the load returns 0);
+//   * the segan_src transform with wave-uniform scale / shift / slope (skipped for identity),
+//     one ds_write_b32 per element.
+// Preconditions (checked by the launcher, else corr_kernel runs): window of at most 256
+// positions; the channel split C0 a multiple of the chunk's channels (T form); no shift with
+// zero padding (a padded zero must stay zero after the transform).
+// ====================================================================================
+#define CORR2_KC 32
+#define CORR2_NLD 4
+
+__device__ __forceinline__ float buf_load_f32(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+
+template <int MB, int NB, int WM, int U, bool IN_HI, bool OUT_HI, bool SHIFT, bool XF>
+__global__ __launch_bounds__(256, 2) void corr2_kernel(const CorrArgs a) {
+  using G = TileGeom<MB, NB, WM, U>;
+  constexpr int S = G::S, WN = G::WN, NI = G::NI, NJ = G::NJ, NPT = G::NPT;
+  constexpr int KC = CORR2_KC;
+  constexpr int CV = KC / U;          // virtual channels per chunk (== S)
+  constexpr int SL = 4 / CV;          // waves that share a channel, each a slice of positions
+  constexpr int NLD = CORR2_NLD;
+  static_assert(CV == S, "one real channel per chunk of a HI input");
+  static_assert(!OUT_HI || NPT % 32 == 0, "T-form tiles hold whole 32-row phase blocks");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int RLs = a.RLs;              // padded row: a multiple of 64*SL, every lane may write
+  float* Wl0 = smem;                  // [2][KC*MB]
+  float* Il0 = smem + 2 * KC * MB;   // [2][CV*RLs]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int wc = wave % CV;           // the chunk channel this wave stages
+  const int wslice = wave / CV;       // its slice of positions
+  const int nld = a.nld;
+
+  const __amdgpu_buffer_rsrc_t wrsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, 0x7fffffff, 0x00020000);
+  // weight tile: one LDS-DMA instruction moves 64 lanes x 16 B = 256/MB rows of MB floats
+  constexpr int F4R = MB / 4;         // lanes per row
+  constexpr int RPI = 64 / F4R;       // rows per instruction
+  constexpr int NINS = KC / RPI;      // instructions per chunk and workgroup
+  constexpr int NPASS = NINS / 4;     // per wave
+  static_assert(NINS % 4 == 0, "weight tile instructions divide among 4 waves");
+
+  const int nch = (a.Ktot + KC - 1) / KC;
+  const int nchan = IN_HI ? a.Cv / S : a.Cv;   // real channels of the input
+  TileIter it;
+  it.init(a, nch);
+  TileWork tw;
+  while (it.next(a, nch, tw)) {
+  const int c0 = tw.c0, c1 = tw.c1;
+  const int rowtile = a.rt0 + tw.tile / a.ncoltiles;
+  const int coltile = tw.tile % a.ncoltiles;
+  const int m0 = rowtile * MB;
+  const int n0 = rowtile * NPT;
+  if (tile_is_dead<MB, OUT_HI>(a, m0)) continue;
+  const ColTile ct = make_coltile(coltile * NB, a.Tcols, NB);
+
+  // ---- activation descriptors, rebased to the tile's first sample (offsets stay small) ----
+  const long left = (long)(a.B - ct.b0) * a.Lin * 4;
+  const long nb0 = left * a.in.C0, nb1 = left * a.in.C1;
+  const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.in.p0) + (size_t)ct.b0 * a.in.C0 * a.Lin, 0,
+      (int)(nb0 < 0x7fffffffL ? nb0 : 0x7fffffffL), 0x00020000);
+  const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(
+      a.in.C1 ? const_cast<float*>(a.in.p1) + (size_t)ct.b0 * a.in.C1 * a.Lin
+              : const_cast<float*>(a.in.p0),
+      0, (int)(nb1 < 0x7fffffffL ? nb1 : 0x7fffffffL), 0x00020000);
+
+  // ---- per-lane load offsets of this wave's channel: positions lane + 64*(wslice + SL*i) ----
+  // (the launcher guarantees C0 == C1 whenever a tile spans several samples of two segments, so
+  // one set of offsets serves both)
+  int vo[NLD];
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = m0 + 32 * (wm * NI + i) + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (row >= a.Rvalid) continue;
-        // LO store: out[b, row, t]
-        float* dst;
-        int oc, och;
-        if (row < a.OC0) { dst = a.out0; oc = a.OC0; och = row; }
-        else { dst = a.out1; oc = a.OC1; och = row - a.OC0; }
-        if (dst == nullptr) continue;
-        const float bs = (a.bias && add_bias) ? a.bias[row] : 0.0f;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          if (col_b[j] < 0) continue;
-          float v = acc[i][j][e] + bs;
-          float* o = dst + ((size_t)col_b[j] * oc + och) * (size_t)a.Lout + col_t[j];
-          if (partial) { atomicAdd(o, v); continue; }
-          if (a.act == SEGAN_ACT_TANH) v = tanhf(v);
-          *o = v;
-        }
-      }
-    }
-  } else {
-    // HI store.  Row block ib of the tile is phase r = 32*ib / NPT of channels n0 + nl.
-    constexpr bool QUAD = (S == 4 && WM == 1 && NI == 4);  // lane holds all 4 phases of (n, q)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        if (col_b[j] < 0) continue;
-        const int q = col_t[j];
-        if (QUAD) {
-          const int n = n0 + (e & 3) + 8 * (e >> 2) + 4 * h;
-          if (n >= a.Nout) continue;
-          const float bs = (a.bias && add_bias) ? a.bias[n] : 0.0f;
-          float v[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            v[r] = acc[r][j][e] + bs;
-            if (!partial && a.act == SEGAN_ACT_TANH) v[r] = tanhf(v[r]);
-          }
-          const size_t rowoff = (size_t)col_b[j] * a.Nout + n;
-          const int i0 = 4 * q - a.o_padL;
-          if (!partial && a.o_roll == 0 && i0 >= 0 && i0 + 3 < a.Lout && (a.o_padL & 3) == 0) {
-            f32x4 o = {v[0], v[1], v[2], v[3]};
-            *reinterpret_cast<f32x4*>(a.out0 + rowoff * (size_t)a.Lout + i0) = o;
-            continue;
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int P = 4 * q + r;
-            int ii = P - a.o_padL;
-            if (ii >= 0 && ii < a.Lout) {
-              if (a.o_roll != 0) {
-                ii -= a.o_roll;
-                if (ii < 0) ii += a.Lout;
-                if (ii >= a.Lout) ii -= a.Lout;
-              }
-              float* o = a.out0 + rowoff * (size_t)a.Lout + ii;
-              if (partial) atomicAdd(o, v[r]); else *o = v[r];
-            } else if (a.halo != nullptr) {
-              const int hl = a.o_padL + a.o_padR;
-              float* o = nullptr;
-              if (ii < 0) o = a.halo + rowoff * hl + P;
-              else if (ii - a.Lout < a.o_padR) o = a.halo + rowoff * hl + a.o_padL + (ii - a.Lout);
-              if (o) { if (partial) atomicAdd(o, v[r]); else *o = v[r]; }
-            }
-          }
-        } else {
-#pragma unroll
-          for (int i = 0; i < NI; ++i) {
-            const int rloc = 32 * (wm * NI + i) + (e & 3) + 8 * (e >> 2) + 4 * h;
-            const int r = rloc / NPT;
-            const int n = n0 + rloc % NPT;
-            if (n >= a.Nout) continue;
-            float v = acc[i][j][e] + ((a.bias && add_bias) ? a.bias[n] : 0.0f);
-            if (!partial && a.act == SEGAN_ACT_TANH) v = tanhf(v);
-            const int P = S * q + r;
-            int ii = P - a.o_padL;
-            const size_t rowoff = (size_t)col_b[j] * a.Nout + n;
-            if (ii >= 0 && ii < a.Lout) {
-              if (a.o_roll != 0) {
-                ii -= a.o_roll;
-                if (ii < 0) ii += a.Lout;
-                if (ii >= a.Lout) ii -= a.Lout;
-              }
-              float* o = a.out0 + rowoff * (size_t)a.Lout + ii;
-              if (partial) atomicAdd(o, v); else *o = v;
-            } else if (a.halo != nullptr) {
-              const int hl = a.o_padL + a.o_padR;
-              float* o = nullptr;
-              if (ii < 0) o = a.halo + rowoff * hl + P;
-              else if (ii - a.Lout < a.o_padR) o = a.halo + rowoff * hl + a.o_padL + (ii - a.Lout);
-              if (o) { if (partial) atomicAdd(o, v); else *o = v; }
-            }
-          }
-        }
+  for (int i = 0; i < NLD; ++i) {
+    const int j = lane + 64 * (wslice + SL * i);
+    vo[i] = (int)0x80000000u;      // out of range: the load returns 0
+    if (i < nld && j < a.RLv) {
+      int s, tau;
+      lds_pos_decode(ct, j, a.Tcols, a.H, s, tau);
+      if (ct.b0 + s < a.B) {
+        const int wq = tau + a.win_start;
+        int idx = -1;
+        if (IN_HI) idx = segan_hi_index(S * wq + wc, a.Lin, a.padL, a.mode, a.roll);
+        else if (wq >= 0 && wq < a.Lin) idx = wq;
+        if (idx >= 0) vo[i] = (s * a.in.C0 * a.Lin + idx) * 4;
       }
     }
   }
-  }  // segment loop
+  const int il_w = wc * RLs + lane + 64 * wslice;   // LDS element of load 0
+
+  // ---- weight tile: per-lane byte offset inside the packed buffer ----
+  const int wrr = lane / F4R, wc4 = lane % F4R;
+  const int wgcol = OUT_HI ? ((4 * wc4) / NPT) * a.NP + n0 + (4 * wc4) % NPT : m0 + 4 * wc4;
+  const int wvo = (wrr * a.RP + wgcol) * 4;
+
+  // ---- per-lane operand offsets ----
+  int aoff[NI], boff[NJ], rsh[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int rloc = 32 * (wm * NI + i);
+    aoff[i] = h * MB + rloc + l31;
+    rsh[i] = SHIFT ? a.rowshift[rloc / NPT] : 0;
+  }
+  int col_b[NJ], col_t[NJ];
+  lane_columns<NB, WN, NJ>(a, ct, wn, l31, h, col_b, col_t, boff);
+
+  f32x16 acc[NI][NJ];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+  float ireg[NLD];
+  float xsc = 1.0f, xsh = 0.0f, xsl = 1.0f;
+
+  auto load_chunk = [&](int ch, int buf) {
+    // weights: global -> LDS
+    float* Wl = Wl0 + buf * (KC * MB);
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+      const int q = wave + 4 * p;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          wrsrc, (__attribute__((address_space(3))) void*)(Wl + q * 256), 16, wvo,
+          (ch * KC + q * RPI) * a.RP * 4, 0, 0);
+    }
+    // activations: this wave's channel of the chunk
+    const int chan = IN_HI ? ch : ch * CV + wc;
+    const bool cok = chan < nchan;
+    const bool seg1 = chan >= a.in.C0;
+    const int cc = seg1 ? chan - a.in.C0 : chan;
+    const int soff = cok ? cc * a.Lin * 4 : (int)0x7fffffff;   // beyond every range: zeros
+    if (XF) {
+      // wave-uniform: scalar loads (the vectors were written by earlier kernels; the launcher
+      // replaced NULL vectors by ones / zeros, so identity parts cost nothing special)
+      typedef const __attribute__((address_space(4))) float* cptr;
+      const int cx = cok ? chan : 0;
+      xsl = ((cptr)a.in.slope)[cx];
+      xsc = ((cptr)a.in.scale)[cx];
+      xsh = ((cptr)a.in.shift)[cx];
+    }
+    const __amdgpu_buffer_rsrc_t rs = seg1 ? r1 : r0;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i)
+      if (i < nld) ireg[i] = buf_load_f32(rs, vo[i], soff);
+  };
+  auto store_chunk = [&](int buf) {
+    float* Il = Il0 + buf * (CV * RLs) + il_w;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      if (i < nld) {
+        float v = ireg[i];
+        if (XF) {
+          v = fmaf(v, xsc, xsh);
+          v = v > 0.0f ? v : v * xsl;
+        }
+        Il[64 * SL * i] = v;
+      }
+    }
+  };
+
+  load_chunk(c0, 0);
+  store_chunk(0);
+  __syncthreads();
+  for (int ch = c0; ch < c1; ++ch) {
+    const int buf = (ch - c0) & 1;
+    if (ch + 1 < c1) load_chunk(ch + 1, buf ^ 1);
+    corr_mma_chunk<MB, U, KC, NI, NJ, SHIFT>(Wl0 + buf * (KC * MB), Il0 + buf * (CV * RLs), RLs,
+                                             aoff, boff, rsh, acc);
+    if (ch + 1 < c1) store_chunk(buf ^ 1);
+    __syncthreads();
+  }
+
+  if (tw.partial)
+    slab_store<NI, NJ>(a.sk_ws + (size_t)(blockIdx.x * 2 + tw.piece) * (MB * NB), acc, tid);
+  else
+    corr_store_tile<MB, NB, WM, U, OUT_HI>(a, acc, m0, n0, wm, h, col_b, col_t);
+  }  // tile loop
+}
+
+// Stream-K second pass: one workgroup per cut tile adds the slabs of its pieces in chunk
+// order and stores the tile.  Tiles that one workgroup happened to hold whole were stored by
+// the main kernel.
+template <int MB, int NB, int WM, int U, bool OUT_HI, int KC>
+__global__ __launch_bounds__(256) void corr_fixup_kernel(const CorrArgs a) {
+  using G = TileGeom<MB, NB, WM, U>;
+  constexpr int WN = G::WN, NI = G::NI, NJ = G::NJ, NPT = G::NPT;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int nch = (a.Ktot + KC - 1) / KC;
+  const int t = blockIdx.x;
+  const long u0 = (long)t * nch, u1 = u0 + nch - 1;
+  const int g_first = (int)(u0 / a.sk_units), g_last = (int)(u1 / a.sk_units);
+  if (g_first == g_last) return;
+  const int tile = a.sk_nfull + t;
+  const int rowtile = a.rt0 + tile / a.ncoltiles;
+  const int coltile = tile % a.ncoltiles;
+  const int m0 = rowtile * MB, n0 = rowtile * NPT;
+  if (tile_is_dead<MB, OUT_HI>(a, m0)) return;
+  const ColTile ct = make_coltile(coltile * NB, a.Tcols, NB);
+  int col_b[NJ], col_t[NJ], boff[NJ];
+  lane_columns<NB, WN, NJ>(a, ct, wn, l31, h, col_b, col_t, boff);
+  f32x16 acc[NI][NJ];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+  for (int g = g_first; g <= g_last; ++g) {
+    const int piece = t - (int)(((long)g * a.sk_units) / nch);
+    slab_add<NI, NJ>(a.sk_ws + (size_t)(g * 2 + piece) * (MB * NB), acc, tid);
+  }
+  corr_store_tile<MB, NB, WM, U, OUT_HI>(a, acc, m0, n0, wm, h, col_b, col_t);
 }
 
 // fold the reflect halo of a conv dgrad back into dx.  When L > padL + padR + 1 the padL left
@@ -396,9 +725,61 @@ __global__ void fold_halo_kernel(float* dx, const float* halo, int rows, int L, 
   }
 }
 
-static bool streamk_enabled() {
-  static const int env = [] { const char* e = getenv("SEGAN_STREAMK"); return e ? atoi(e) : 1; }();
-  return env != 0;
+// ---- launch plumbing ---------------------------------------------------------------------
+// One process drives one GPU, but nothing here assumes it: what is cached is cached per device.
+static int cur_device() {
+  int d = 0;
+  (void)hipGetDevice(&d);
+  return d & 15;
+}
+
+template <typename K>
+static void allow_big_lds(K kern, bool (&done)[16]) {
+  const int d = cur_device();
+  if (!done[d]) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    done[d] = true;
+  }
+}
+
+// workgroups resident per CU (registers / LDS), cached per device and LDS size
+template <typename K>
+static int resident_per_cu(K kern, size_t lds, int (&occ)[16], size_t (&occ_lds)[16]) {
+  const int d = cur_device();
+  if (occ[d] == 0 || occ_lds[d] != lds) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), 256,
+                                                     lds) != hipSuccess || nb < 1)
+      nb = 2;
+    occ[d] = nb > 4 ? 4 : nb;
+    occ_lds[d] = lds;
+  }
+  return occ[d];
+}
+
+// Data-parallel + stream-K plan of a launch of `ntiles` equal tiles of `nch` chunks.  All
+// workgroups do the same amount of work and several are resident per CU, so a one-tile-per-
+// workgroup launch takes ceil(tiles / resident) rounds; when the last round would leave more
+// than 3 % of the CU-time idle, whole rounds are run tile-per-workgroup and the tiles of the
+// last partial round are cut along the contraction across all workgroups (slabs in the
+// caller's scratch + corr_fixup_kernel; without enough scratch the launch stays classic).
+static unsigned plan_streamk(CorrArgs& a, int ntiles, int nch, int occ, size_t slab_floats,
+                             bool allow) {
+  a.sk_nfull = ntiles;
+  a.sk_units = 1;
+  a.sk_total = 0;
+  const double classic_eff = (double)ntiles / (256.0 * ceil_div(ntiles, 256));
+  if (!allow || a.act != SEGAN_ACT_NONE || ntiles < 64 || nch < 8 || classic_eff >= 0.97)
+    return (unsigned)ntiles;
+  const int G = 256 * occ;
+  if (a.sk_ws == nullptr || a.sk_ws_floats < (size_t)G * 2 * slab_floats) return (unsigned)ntiles;
+  a.sk_nfull = (ntiles / G) * G;
+  const int rem = ntiles - a.sk_nfull;
+  if (rem == 0) return (unsigned)ntiles;
+  a.sk_total = (long)rem * nch;
+  a.sk_units = (int)((a.sk_total + G - 1) / G);
+  return (unsigned)G;
 }
 
 template <int MB, int NB, int WM, int U, bool IN_HI, bool OUT_HI, bool SHIFT, int MAXPOS, int KC>
@@ -412,68 +793,73 @@ static int launch_corr_t(CorrArgs a, hipStream_t st, bool allow_sk) {
     return SEGAN_EUNSUPPORTED;
   }
   auto kern = corr_kernel<MB, NB, WM, U, IN_HI, OUT_HI, SHIFT, MAXPOS, KC>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
-  }
+  static bool attr_done[16];
+  static int occ[16];
+  static size_t occ_lds[16];
+  allow_big_lds(kern, attr_done);
   // rows below rt0 all go to a NULL destination (the z half of the first decoder layer)
   a.rt0 = (!OUT_HI && a.out0 == nullptr) ? a.OC0 / MB : 0;
   const int ntiles = (nrowtiles - a.rt0) * a.ncoltiles;
   const int nch = ceil_div(a.Ktot, KC);
-  a.sk_nfull = ntiles;
-  a.sk_units = 0;
-  a.sk_total = 0;
-  unsigned grid = (unsigned)ntiles;
-  // hybrid when one-tile-per-workgroup would leave >3 % of the CU-time idle at the end
-  const double classic_eff = (double)ntiles / (256.0 * ceil_div(ntiles, 256));
-  if (allow_sk && streamk_enabled() && a.act == SEGAN_ACT_NONE && ntiles >= 64 && nch >= 8 &&
-      classic_eff < 0.97) {
-    // workgroups resident per CU (registers / LDS): the grid is exactly one resident round
-    static int occ_cache = 0;
-    static size_t occ_lds = 0;
-    if (occ_cache == 0 || occ_lds != lds) {
-      int nb = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern),
-                                                       256, lds) != hipSuccess || nb < 1)
-        nb = 2;
-      occ_cache = nb > 4 ? 4 : nb;
-      occ_lds = lds;
-    }
-    const int occ = occ_cache;
-    const int G = 256 * occ;
-    a.sk_nfull = (ntiles / G) * G;
-    const int rem = ntiles - a.sk_nfull;
-    a.sk_total = (long)rem * nch;
-    a.sk_units = (int)((a.sk_total + G - 1) / G);
-    grid = (unsigned)G;
-    // tiles cut across workgroups are accumulated with atomics: zero the destinations
-    hipError_t e = hipSuccess;
-    if (a.out0 && a.out0_elems) e = hipMemsetAsync(a.out0, 0, a.out0_elems * sizeof(float), st);
-    if (e == hipSuccess && a.out1 && a.out1_elems)
-      e = hipMemsetAsync(a.out1, 0, a.out1_elems * sizeof(float), st);
-    if (e == hipSuccess && a.halo && a.halo_elems)
-      e = hipMemsetAsync(a.halo, 0, a.halo_elems * sizeof(float), st);
-    if (e != hipSuccess) {
-      segan_set_error("corr: memset failed: %s", hipGetErrorString(e));
-      return SEGAN_ELAUNCH;
-    }
-  }
+  const unsigned grid = plan_streamk(a, ntiles, nch, resident_per_cu(kern, lds, occ, occ_lds),
+                                     (size_t)MB * NB, allow_sk);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
-  return segan_check_launch("corr_kernel");
+  if (int e = segan_check_launch("corr_kernel")) return e;
+  if (a.sk_total > 0) {
+    hipLaunchKernelGGL((corr_fixup_kernel<MB, NB, WM, U, OUT_HI, KC>), dim3(ntiles - a.sk_nfull),
+                       dim3(256), 0, st, a);
+    return segan_check_launch("corr_fixup_kernel");
+  }
+  return SEGAN_OK;
 }
 
-// All workgroups of a launch do the same amount of work and several are resident per CU
-// sharing its MFMA pipes, so a launch takes ceil(blocks / 256) block times; the half-size
-// tile is used when that quantisation is better (the deep layers: few, long tiles).
-static bool prefer_half_tile(int nb_full, int nb_half) {
-  static const int env = [] { const char* e = getenv("SEGAN_CORR_HALF"); return e ? atoi(e) : -1; }();
-  if (env == 0) return false;
-  if (env == 1) return true;
-  const double t_full = (double)ceil_div(nb_full, 256);
-  const double t_half = 0.5 * 1.06 * (double)ceil_div(nb_half, 256);   // 6 % tile-size penalty
-  return t_half < t_full;
+template <int MB, int NB, int WM, int U, bool IN_HI, bool OUT_HI, bool SHIFT, bool XF>
+static int launch_corr2_x(CorrArgs a, hipStream_t st, bool allow_sk) {
+  constexpr int KC = CORR2_KC;
+  constexpr int CV = KC / U;
+  constexpr int S = 32 / U;
+  constexpr int SL = 4 / CV;
+  const int nrowtiles = OUT_HI ? a.NP / (MB / S) : ceil_div(a.Rvalid, MB);
+  a.RLv = a.RLs;
+  a.RLs = round_up(a.RLs, 64 * SL);
+  a.nld = a.RLs / (64 * SL);
+  const size_t lds = (size_t)(2 * KC * MB + 2 * CV * a.RLs) * sizeof(float);
+  auto kern = corr2_kernel<MB, NB, WM, U, IN_HI, OUT_HI, SHIFT, XF>;
+  static bool attr_done[16];
+  static int occ[16];
+  static size_t occ_lds[16];
+  allow_big_lds(kern, attr_done);
+  a.rt0 = (!OUT_HI && a.out0 == nullptr) ? a.OC0 / MB : 0;
+  const int ntiles = (nrowtiles - a.rt0) * a.ncoltiles;
+  const int nch = ceil_div(a.Ktot, KC);
+  const unsigned grid = plan_streamk(a, ntiles, nch, resident_per_cu(kern, lds, occ, occ_lds),
+                                     (size_t)MB * NB, allow_sk);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
+  if (int e = segan_check_launch("corr2_kernel")) return e;
+  if (a.sk_total > 0) {
+    hipLaunchKernelGGL((corr_fixup_kernel<MB, NB, WM, U, OUT_HI, KC>), dim3(ntiles - a.sk_nfull),
+                       dim3(256), 0, st, a);
+    return segan_check_launch("corr_fixup_kernel");
+  }
+  return SEGAN_OK;
+}
+
+template <int MB, int NB, int WM, int U, bool IN_HI, bool OUT_HI, bool SHIFT>
+static int launch_corr2_t(CorrArgs& a, hipStream_t st, bool allow_sk) {
+  return a.xf_mode ? launch_corr2_x<MB, NB, WM, U, IN_HI, OUT_HI, SHIFT, true>(a, st, allow_sk)
+                   : launch_corr2_x<MB, NB, WM, U, IN_HI, OUT_HI, SHIFT, false>(a, st, allow_sk);
+}
+
+// corr2_kernel covers a launch when its window fits 4 loads per lane, a padded zero stays a
+// zero under the input transform, and both channel segments have the same sample pitch
+// wherever a tile spans several samples (corr_kernel handles the rest)
+template <int U>
+static bool corr2_ok(const CorrArgs& a, int NB) {
+  constexpr int SL = 4 / (CORR2_KC / U);
+  if (a.RLs > 64 * SL * CORR2_NLD) return false;
+  if (a.mode == SEGAN_PAD_ZERO && a.xf_mode == 2) return false;
+  if (a.in.C1 > 0 && a.in.C0 != a.in.C1 && samples_per_tile(a.Tcols, NB) > 1) return false;
+  return true;
 }
 
 // ---- F form (conv forward, deconv data gradient) ----
@@ -482,9 +868,10 @@ static int launch_corr_f(CorrArgs& a, hipStream_t st) {
   constexpr int NB = 128;
   a.ncoltiles = ceil_div(a.Ctot, NB);
   a.RLs = NB + samples_per_tile(a.Tcols, NB) * a.H;
-  bool small = a.Rvalid <= 64;
-  if (!small && !streamk_enabled())
-    small = prefer_half_tile(ceil_div(a.Rvalid, 128) * a.ncoltiles, ceil_div(a.Rvalid, 64) * a.ncoltiles);
+  const bool small = a.Rvalid <= 64;
+  if (corr2_ok<U>(a, NB))
+    return small ? launch_corr2_t<64, NB, 2, U, true, false, false>(a, st, false)
+                 : launch_corr2_t<128, NB, 2, U, true, false, false>(a, st, true);
   if (a.RLs <= 256) {
     if (!small && U <= 16)
       return launch_corr_t<128, NB, 2, U, true, false, false, 1, 32>(a, st, true);
@@ -503,30 +890,23 @@ static int launch_corr_f(CorrArgs& a, hipStream_t st) {
 // ---- T form (deconv forward, conv data gradient) ----
 template <int U, bool SHIFT>
 static int launch_corr_tt(CorrArgs& a, hipStream_t st) {
-  constexpr int S = 32 / U;
-  const int nrt = a.NP / (128 / S);
-  const int ct128 = ceil_div(a.Ctot, 128), ct64 = ceil_div(a.Ctot, 64);
-  const bool half = !streamk_enabled() && prefer_half_tile(nrt * ct128, nrt * ct64);
-  const int NB = half ? 64 : 128;
-  a.ncoltiles = half ? ct64 : ct128;
+  constexpr int NB = 128;
+  a.ncoltiles = ceil_div(a.Ctot, NB);
   a.RLs = NB + samples_per_tile(a.Tcols, NB) * a.H;
   if (a.RLs > 512) {
     segan_set_error("corr: sample length %d too short for stride %d (RLs=%d)", a.Tcols, 32 / U,
                     a.RLs);
     return SEGAN_EUNSUPPORTED;
   }
+  if (corr2_ok<U>(a, NB)) return launch_corr2_t<128, NB, 1, U, false, true, SHIFT>(a, st, true);
   constexpr int KC = U <= 16 ? 32 : KCH;
-  if (a.RLs <= 256)
-    return half ? launch_corr_t<128, 64, 2, U, false, true, SHIFT, 1, KC>(a, st, false)
-                : launch_corr_t<128, 128, 1, U, false, true, SHIFT, 1, KC>(a, st, true);
-  return half ? launch_corr_t<128, 64, 2, U, false, true, SHIFT, 2, KCH>(a, st, false)
-              : launch_corr_t<128, 128, 1, U, false, true, SHIFT, 2, KCH>(a, st, true);
+  if (a.RLs <= 256) return launch_corr_t<128, NB, 1, U, false, true, SHIFT, 1, KC>(a, st, true);
+  return launch_corr_t<128, NB, 1, U, false, true, SHIFT, 2, KCH>(a, st, true);
 }
 
 template <bool IN_HI, bool OUT_HI>
 static int launch_corr(CorrArgs& a, int U, hipStream_t st) {
-  static const int prio_env = [] { const char* e = getenv("SEGAN_PRIO"); return e ? atoi(e) : 0; }();
-  a.prio_mode = prio_env;
+  a.xf_mode = (a.in.scale || a.in.shift) ? 2 : (a.in.slope ? 1 : 0);
   if (int e = segan_src_defaults(&a.in, st, "corr")) return e;
   const long in_elems = (long)a.B * (a.in.C0 + a.in.C1) * a.Lin;
   if (in_elems >= (1L << 31)) {
@@ -551,13 +931,23 @@ static int launch_corr(CorrArgs& a, int U, hipStream_t st) {
   return SEGAN_EUNSUPPORTED;
 }
 
+static void set_scratch(CorrArgs& a, void* scratch, size_t scratch_bytes) {
+  a.sk_ws = (float*)scratch;
+  a.sk_ws_floats = scratch ? scratch_bytes / sizeof(float) : 0;
+}
 
 // ====================================================================================
 // C ABI: forward and data-gradient entry points
 // ====================================================================================
+extern "C" size_t segan_corr_scratch_bytes(void) {
+  // 256 CUs x 4 resident workgroups x 2 slabs of a 128 x 128 fp32 tile
+  return (size_t)1024 * 2 * 128 * 128 * sizeof(float);
+}
+
 extern "C" int segan_conv1d_fwd(const segan_src* x, const void* wf, const float* bias, float* out,
                                 int B, int N, int M, int L, int K, int S, int padL, int mode,
-                                int roll, int precision, void* stream) {
+                                int roll, int precision, void* scratch, size_t scratch_bytes,
+                                void* stream) {
   SEGAN_REQUIRE(precision_ok(precision), "conv1d_fwd: precision must be 0, 1 or 3");
   SEGAN_REQUIRE(stride_ok(S), "conv1d_fwd: stride %d not in {1,2,4}", S);
   SEGAN_REQUIRE(K >= 1 && K <= 32, "conv1d_fwd: kernel width %d not in [1,32]", K);
@@ -582,14 +972,15 @@ extern "C" int segan_conv1d_fwd(const segan_src* x, const void* wf, const float*
   a.OC0 = M; a.OC1 = 0; a.Lout = a.Tcols; a.act = SEGAN_ACT_NONE;
   a.out0_elems = (size_t)B * M * a.Tcols;
   if (precision) return segan_corr_bf_f(a, U, wf, precision, (hipStream_t)stream);
-  static const bool fsmall_on = [] { const char* e = getenv("SEGAN_FSMALL"); return !e || atoi(e) != 0; }();
-  if (N <= 2 && fsmall_on) return segan_launch_fsmall(a, M, N, S, (hipStream_t)stream);
+  if (N <= 2) return segan_launch_fsmall(a, M, N, S, (hipStream_t)stream);
+  set_scratch(a, scratch, scratch_bytes);
   return launch_corr<true, false>(a, U, (hipStream_t)stream);
 }
 
 extern "C" int segan_deconv1d_dgrad(const float* dy, const void* wf, float* dx0, float* dx1, int B,
                                     int M, int M0, int N, int Ls, int K, int S, int pad,
-                                    int precision, void* stream) {
+                                    int precision, void* scratch, size_t scratch_bytes,
+                                    void* stream) {
   SEGAN_REQUIRE(precision_ok(precision), "deconv1d_dgrad: precision must be 0, 1 or 3");
   SEGAN_REQUIRE(stride_ok(S), "deconv1d_dgrad: stride %d not in {1,2,4}", S);
   SEGAN_REQUIRE(K >= 1 && K <= 32, "deconv1d_dgrad: kernel width %d not in [1,32]", K);
@@ -614,12 +1005,14 @@ extern "C" int segan_deconv1d_dgrad(const float* dy, const void* wf, float* dx0,
   a.out0_elems = (size_t)B * a.OC0 * Ls;
   a.out1_elems = (size_t)B * a.OC1 * Ls;
   if (precision) return segan_corr_bf_f(a, U, wf, precision, (hipStream_t)stream);
+  set_scratch(a, scratch, scratch_bytes);
   return launch_corr<true, false>(a, U, (hipStream_t)stream);
 }
 
 extern "C" int segan_deconv1d_fwd(const segan_src* x, const void* wt, const float* w,
                                   const float* bias, float* y, int B, int M, int N, int Ls, int K,
-                                  int S, int pad, int act, int precision, void* stream) {
+                                  int S, int pad, int act, int precision, void* scratch,
+                                  size_t scratch_bytes, void* stream) {
   SEGAN_REQUIRE(precision_ok(precision), "deconv1d_fwd: precision must be 0, 1 or 3");
   SEGAN_REQUIRE(stride_ok(S), "deconv1d_fwd: stride %d not in {1,2,4}", S);
   SEGAN_REQUIRE(K >= 1 && K <= 32, "deconv1d_fwd: kernel width %d not in [1,32]", K);
@@ -654,12 +1047,14 @@ extern "C" int segan_deconv1d_fwd(const segan_src* x, const void* wt, const floa
   if (precision && act == SEGAN_ACT_NONE)
     return segan_corr_bf_t(a, U, wt, precision, (hipStream_t)stream);
   SEGAN_REQUIRE(precision == 0, "deconv1d_fwd: tanh epilogue only on the fp32 path");
+  set_scratch(a, scratch, scratch_bytes);
   return launch_corr<false, true>(a, U, (hipStream_t)stream);
 }
 
 extern "C" int segan_conv1d_dgrad(const float* da, const void* wt, const float* w, float* dx,
                                   float* halo, int B, int N, int M, int L, int K, int S, int padL,
-                                  int roll, int precision, void* stream) {
+                                  int roll, int precision, void* scratch, size_t scratch_bytes,
+                                  void* stream) {
   SEGAN_REQUIRE(precision_ok(precision), "conv1d_dgrad: precision must be 0, 1 or 3");
   SEGAN_REQUIRE(stride_ok(S), "conv1d_dgrad: stride %d not in {1,2,4}", S);
   SEGAN_REQUIRE(K >= 1 && K <= 32, "conv1d_dgrad: kernel width %d not in [1,32]", K);
@@ -689,6 +1084,7 @@ extern "C" int segan_conv1d_dgrad(const float* da, const void* wt, const float* 
   a.o_padL = padL; a.o_roll = roll; a.o_padR = padR;
   a.out0_elems = (size_t)B * N * L;
   a.halo_elems = (size_t)B * N * (padL + padR);
+  set_scratch(a, scratch, scratch_bytes);
   int e = (w && N <= 2) ? segan_launch_tsmall(a, w, K, M, N, S, 0, st)
           : precision   ? segan_corr_bf_t(a, U, wt, precision, st)
                         : launch_corr<false, true>(a, U, st);

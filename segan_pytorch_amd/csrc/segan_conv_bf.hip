@@ -580,7 +580,6 @@ static int prep(CorrArgs& a, hipStream_t st) {
   constexpr int NB = 128;
   a.ncoltiles = ceil_div(a.Ctot, NB);
   a.RLs = NB + samples_per_tile(a.Tcols, NB) * a.H;
-  a.prio_mode = 0;
   a.in_identity = (!a.in.scale && !a.in.shift && !a.in.slope) ? 1 : 0;
   if (int e = segan_src_defaults(&a.in, st, "corr_bf")) return e;
   if ((long)a.B * (a.in.C0 + a.in.C1) * a.Lin >= (1L << 30) || a.Lin >= (1 << 24) ||

@@ -59,13 +59,16 @@ struct CorrArgs {
   int NP, Nout;           // T form row decode: row = r*NP + n
   int OC0, OC1, Lout, act;
   int o_padL, o_roll, o_padR;  // HI store (conv dgrad: reflect halo)
-  int prio_mode;               // 0: none, 1: hashed static wave priority per workgroup
   int in_identity;             // bf16 kernels: the input has no per-channel transform
   int sk_nfull;                // tiles processed whole (strided over the grid)
   int sk_units;                // stream-K part: (tile, chunk) units per workgroup
   long sk_total;               // stream-K part: total units of the remaining tiles
   int rt0;                     // first row tile (rows below it have a NULL destination)
-  size_t out0_elems, out1_elems, halo_elems;   // host side: what stream-K must zero
+  size_t out0_elems, out1_elems, halo_elems;   // host side: what the bf16 stream-K zeroes
+  float* sk_ws;                // fp32 stream-K: accumulator slabs of the cut tiles (caller scratch)
+  size_t sk_ws_floats;
+  int xf_mode;                 // input transform: 0 identity, 1 slope only, 2 scale/shift/slope
+  int RLv, nld;                // corr2: valid window positions (RLs is the padded row), loads per lane
 };
 
 

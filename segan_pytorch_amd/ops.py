@@ -106,6 +106,23 @@ class Src(object):
         return s
 
 
+# stream-K scratch of the fp32 contractions (include/segan_hip.h): one buffer per device and
+# stream (launches on different streams must not share it), allocated on first use
+_corr_scratch = {}
+
+
+def _scratch():
+    """(pointer, bytes) of this device+stream's stream-K scratch."""
+    st = torch.cuda.current_stream()
+    key = (st.device.index, st.cuda_stream)
+    buf = _corr_scratch.get(key)
+    if buf is None:
+        nbytes = _lib.load().segan_corr_scratch_bytes()
+        buf = torch.empty(nbytes, device=st.device, dtype=torch.uint8)
+        _corr_scratch[key] = buf
+    return ctypes.c_void_p(buf.data_ptr()), buf.numel()
+
+
 def conv_pad(K, S):
     return layout.conv_pad(K, S)
 
@@ -211,12 +228,12 @@ def conv1d_fwd(src, w, bias, S, roll=0, pad_mode=PAD_REFLECT, padL=None, pack=No
     if _precision and pad_mode == PAD_REFLECT:
         rc = lib.segan_conv1d_fwd(ctypes.byref(cs), _ptr(pack.bf(w, S, 0, 0, _precision)),
                                   _ptr(bias), _ptr(out), B, N, M, L, K, S, padL, pad_mode, roll,
-                                  _precision, _stream())
+                                  _precision, None, 0, _stream())
         if rc != _EUNSUPPORTED:
             check(rc, 'conv1d_fwd')
             return out
     check(lib.segan_conv1d_fwd(ctypes.byref(cs), _ptr(pack.f(w, S)), _ptr(bias), _ptr(out), B, N,
-                               M, L, K, S, padL, pad_mode, roll, PREC_FP32, _stream()),
+                               M, L, K, S, padL, pad_mode, roll, PREC_FP32, *_scratch(), _stream()),
           'conv1d_fwd')
     return out
 
@@ -239,16 +256,19 @@ def conv1d_dgrad(da, w, L, S, roll=0, padL=None, pack=None):
     lib = _lib.load()
     if small:
         check(lib.segan_conv1d_dgrad(_ptr(da), None, _ptr(w.detach()), _ptr(dx), _ptr(halo), B, N,
-                                     M, L, K, S, padL, roll, PREC_FP32, _stream()), 'conv1d_dgrad')
+                                     M, L, K, S, padL, roll, PREC_FP32, None, 0, _stream()),
+              'conv1d_dgrad')
         return dx
     if _precision:
         rc = lib.segan_conv1d_dgrad(_ptr(da), _ptr(pack.bf(w, S, 0, 1, _precision)), None, _ptr(dx),
-                                    _ptr(halo), B, N, M, L, K, S, padL, roll, _precision, _stream())
+                                    _ptr(halo), B, N, M, L, K, S, padL, roll, _precision, None, 0,
+                                    _stream())
         if rc != _EUNSUPPORTED:
             check(rc, 'conv1d_dgrad')
             return dx
     check(lib.segan_conv1d_dgrad(_ptr(da), _ptr(pack.t(w, S, 0)), None, _ptr(dx), _ptr(halo), B, N,
-                                 M, L, K, S, padL, roll, PREC_FP32, _stream()), 'conv1d_dgrad')
+                                 M, L, K, S, padL, roll, PREC_FP32, *_scratch(), _stream()),
+          'conv1d_dgrad')
     return dx
 
 
@@ -292,19 +312,19 @@ def deconv1d_fwd(src, w, bias, S, act=ACT_NONE, pack=None):
     lib = _lib.load()
     if small:
         check(lib.segan_deconv1d_fwd(ctypes.byref(cs), None, _ptr(w.detach()), _ptr(bias), _ptr(y),
-                                     B, M, N, Ls, K, S, pad, act, PREC_FP32, _stream()),
+                                     B, M, N, Ls, K, S, pad, act, PREC_FP32, None, 0, _stream()),
               'deconv1d_fwd')
         return y
     if _precision and act == ACT_NONE:
         rc = lib.segan_deconv1d_fwd(ctypes.byref(cs), _ptr(pack.bf(w, S, pad, 1, _precision)), None,
                                     _ptr(bias), _ptr(y), B, M, N, Ls, K, S, pad, act, _precision,
-                                    _stream())
+                                    None, 0, _stream())
         if rc != _EUNSUPPORTED:
             check(rc, 'deconv1d_fwd')
             return y
     check(lib.segan_deconv1d_fwd(ctypes.byref(cs), _ptr(pack.t(w, S, pad)), None, _ptr(bias),
-                                 _ptr(y), B, M, N, Ls, K, S, pad, act, PREC_FP32, _stream()),
-          'deconv1d_fwd')
+                                 _ptr(y), B, M, N, Ls, K, S, pad, act, PREC_FP32, *_scratch(),
+                                 _stream()), 'deconv1d_fwd')
     return y
 
 
@@ -329,12 +349,13 @@ def deconv1d_dgrad(dy, w, S, M0=0, need0=True, need1=True, pack=None):
     lib = _lib.load()
     if _precision:
         rc = lib.segan_deconv1d_dgrad(_ptr(dy), _ptr(pack.bf(w, S, 0, 0, _precision)), _ptr(dx0),
-                                      _ptr(dx1), B, M, M0, N, Ls, K, S, pad, _precision, _stream())
+                                      _ptr(dx1), B, M, M0, N, Ls, K, S, pad, _precision, None, 0,
+                                      _stream())
         if rc != _EUNSUPPORTED:
             check(rc, 'deconv1d_dgrad')
             return dx0, dx1
     check(lib.segan_deconv1d_dgrad(_ptr(dy), _ptr(pack.f(w, S)), _ptr(dx0), _ptr(dx1), B, M, M0, N,
-                                   Ls, K, S, pad, PREC_FP32, _stream()), 'deconv1d_dgrad')
+                                   Ls, K, S, pad, PREC_FP32, *_scratch(), _stream()), 'deconv1d_dgrad')
     return dx0, dx1
 
 
