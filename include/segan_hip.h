@@ -118,16 +118,23 @@ int segan_conv1d_dgrad(const float* da, const void* wt, const float* w, float* d
  *   dw[m,n,k] += sum_{b,t} lo[b,m,t] * pad(roll(hi))[b,n,S*t+k]
  * conv:   lo = da (grad of pre-activation), hi = layer input x, reflect padding;
  * deconv: lo = layer input x (with its transform), hi = dy, zero padding.
- * Accumulates (atomically) into dw, which is how torch accumulates .grad.
+ * Accumulates into dw, which is how torch accumulates .grad.  The contraction over (b, t) is
+ * split across workgroups; by default the partial tiles are added with fp32 atomics (order
+ * varies run to run, results differ in the last bits); with SEGAN_WGRAD_DETERMINISTIC in
+ * `flags` they are written to `scratch` and added in split order by a second kernel
+ * (bit-reproducible; fp32 only).
  * `precision`: SEGAN_PREC_*; the bf16 modes contract 8 samples per MFMA operand and return
  * -3 (SEGAN_EUNSUPPORTED) for Ls % 4 != 0 or very short rows: the caller falls back to fp32.
- * `scratch` (bf16 modes; may be NULL): segan_wgrad_scratch_bytes(...) bytes in which the lo
- * operand is converted ONCE into bf16 planes laid out for the kernel (every column tile of dw
- * re-reads it); without it the conversion happens inside the kernel. */
-size_t segan_wgrad_scratch_bytes(int B, int M, int Ls, int precision);
+ * `scratch` / `scratch_bytes` (may be NULL / 0 unless deterministic): segan_wgrad_scratch_bytes
+ * (...) bytes.  fp32: a lo operand with a transform or in two segments is materialised there
+ * once per call (the fast kernel streams lo by LDS-DMA), followed by the partial tiles of the
+ * deterministic mode.  bf16 modes: the lo operand converted ONCE into bf16 planes laid out for
+ * the kernel (every column tile of dw re-reads it). */
+#define SEGAN_WGRAD_DETERMINISTIC 1
+size_t segan_wgrad_scratch_bytes(int B, int M, int N, int Ls, int S, int precision, int flags);
 int segan_wgrad(const segan_src* lo, const segan_src* hi, float* dw, int B, int M, int N, int Ls,
-                int K, int S, int padL, int mode, int roll, int precision, void* scratch,
-                void* stream);
+                int K, int S, int padL, int mode, int roll, int precision, int flags, void* scratch,
+                size_t scratch_bytes, void* stream);
 
 /* GDeconv1DBlock forward (modules.py:135-141): ConvTranspose1d(stride S, padding
  * `pad`) trimmed to S*Ls samples, + bias, optional tanh (last generator layer).
@@ -214,9 +221,12 @@ int segan_tanh_bwd(const float* y, const float* dy, const float* clean, float l1
 /* ---- dense layers of the discriminator head (discriminator.py:111-117) ------------ */
 
 /* C[M,N] (+)= op(A)[M,K] * op(B)[K,N] with explicit element strides; exact fp32 on
- * MFMA.  beta0 != 0 overwrites C (C is zeroed first), otherwise accumulates. */
+ * MFMA.  beta0 != 0 overwrites C (C is zeroed first), otherwise accumulates.  Small outputs
+ * split the contraction across workgroups (fp32 atomics); SEGAN_GEMM_DETERMINISTIC in `flags`
+ * keeps it whole (bit-reproducible). */
+#define SEGAN_GEMM_DETERMINISTIC 1
 int segan_gemm(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn,
-               float* C, int64_t ldc, int M, int N, int K, int beta0, void* stream);
+               float* C, int64_t ldc, int M, int N, int K, int beta0, int flags, void* stream);
 
 /* y[r,c] = prelu(x[r,c] + bias[c], slope[c]) (slope NULL = identity), rows x cols. */
 int segan_bias_prelu_rows(const float* x, const float* bias, const float* slope, float* y,

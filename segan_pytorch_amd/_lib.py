@@ -41,8 +41,8 @@ SIGNATURES = {
     'segan_conv1d_dgrad': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                    c_int, c_int, _P, c_size_t, _P]),
     'segan_wgrad': (c_int, [_SRC, _SRC, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-                            c_int, c_int, _P, _P]),
-    'segan_wgrad_scratch_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
+                            c_int, c_int, c_int, _P, c_size_t, _P]),
+    'segan_wgrad_scratch_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     'segan_deconv1d_fwd': (c_int, [_SRC, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                    c_int, c_int, _P, c_size_t, _P]),
     'segan_deconv1d_dgrad': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
@@ -60,7 +60,7 @@ SIGNATURES = {
     'segan_act_bwd': (c_int, [_P] * 16 + [c_int, c_int, c_int, _P]),
     'segan_tanh_bwd': (c_int, [_P, _P, _P, c_float, _P, _P, _P, c_int, c_int, c_int, _P]),
     'segan_gemm': (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int64, c_int, c_int,
-                           c_int, c_int, _P]),
+                           c_int, c_int, c_int, _P]),
     'segan_bias_prelu_rows': (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
     'segan_bias_prelu_rows_bwd': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
     'segan_mse_const': (c_int, [_P, c_float, _P, _P, _P, c_float, c_int, _P]),

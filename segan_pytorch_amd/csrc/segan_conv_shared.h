@@ -95,12 +95,18 @@ struct WgradArgs {
   int H, RLw;
   int ls_magic;           // ceil(65536 / Ls): x / Ls for small x when Ls < TK
   int per_magic;          // ceil(65536 / (Ls + H)): LDS position -> sample when Ls < TK
-  int prio_mode;
   int bf_qc;              // bf16 kernel: time chunks per sample group
   int bf_cps;             // bf16 kernel: chunks per workgroup (split of the contraction)
   void* lo_pk;            // bf16 kernel: scratch for the pre-packed lo operand (or NULL)
   size_t lo_pk_plane;     // bytes between its planes
   int Mp;                 // its row pitch (M rounded up to 128)
+  // wgrad2_kernel
+  int w2_cps, w2_nch;     // chunks per contraction split, chunks in total
+  int w2_cpsample;        // chunks per sample (Ls >= 32), 0 when a chunk holds whole samples
+  int w2_spc;             // samples per chunk (Ls < 32)
+  int w2_lsshift;         // log2(Ls) when Ls < 32, else -1
+  int w2_pw, w2_nld;      // hi window positions per virtual channel, loads per lane
+  float* w2_slabs;        // deterministic mode: partial tiles [split][row tile][col tile]
 };
 
 // packed-weight geometry (shared by the pack kernels and the launchers)

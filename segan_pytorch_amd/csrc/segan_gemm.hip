@@ -194,10 +194,13 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const float* __restrict
 
 extern "C" int segan_gemm(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk,
                           int64_t sbn, float* C, int64_t ldc, int M, int N, int K, int beta0,
-                          void* stream) {
+                          int flags, void* stream) {
   SEGAN_REQUIRE(A && B && C, "gemm: NULL pointer");
   SEGAN_REQUIRE(M > 0 && N > 0 && K > 0 && ldc >= N, "gemm: bad sizes");
   hipStream_t st = (hipStream_t)stream;
+  // split-K partials are combined with fp32 atomics; SEGAN_GEMM_DETERMINISTIC keeps the whole
+  // contraction in one workgroup per tile (bit-reproducible)
+  const bool nosplit = (flags & SEGAN_GEMM_DETERMINISTIC) != 0;
   if (beta0) {
     if (ldc == N) {
       if (hipMemsetAsync(C, 0, (size_t)M * N * sizeof(float), st) != hipSuccess) {
@@ -216,15 +219,14 @@ extern "C" int segan_gemm(const float* A, int64_t sam, int64_t sak, const float*
   {
     const bool ak = sak == 1, am = sam == 1, bk = sbk == 1, bn = sbn == 1;
     const long lda = ak ? sam : sak, ldb = bk ? sbn : sbk;
-    static const bool fast_on = [] { const char* e = getenv("SEGAN_GEMM128"); return !e || atoi(e) != 0; }();
-    if (fast_on && (ak || (am && M % 4 == 0)) && (bk || (bn && N % 4 == 0)) && K % 4 == 0 &&
+    if ((ak || (am && M % 4 == 0)) && (bk || (bn && N % 4 == 0)) && K % 4 == 0 &&
         lda % 4 == 0 && ldb % 4 == 0 &&
         ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0 && (long)M * N >= 64 * 64) {
       const int tm = ceil_div(M, G2T), tn = ceil_div(N, G2T);
       int nsplit = ceil_div(512, tm * tn);
       const int kchunks = ceil_div(K, G2K);
       if (nsplit > kchunks / 4) nsplit = kchunks / 4;
-      if (nsplit < 1) nsplit = 1;
+      if (nsplit < 1 || nosplit) nsplit = 1;
       const int kper = ceil_div(kchunks, nsplit) * G2K;
       nsplit = ceil_div(K, kper);
       const dim3 grid(tn, tm, nsplit);
@@ -239,7 +241,7 @@ extern "C" int segan_gemm(const float* A, int64_t sam, int64_t sak, const float*
   int nsplit = ceil_div(512, tm * tn);
   const int kchunks = ceil_div(K, GK);
   if (nsplit > kchunks) nsplit = kchunks;
-  if (nsplit < 1) nsplit = 1;
+  if (nsplit < 1 || nosplit) nsplit = 1;
   int kper = ceil_div(kchunks, nsplit) * GK;
   nsplit = ceil_div(K, kper);
   hipLaunchKernelGGL(gemm_kernel, dim3(tn, tm, nsplit), dim3(256), 0, st, A, (long)sam, (long)sak,

@@ -12,6 +12,71 @@ __device__ __forceinline__ int wg_sdiv(int x, int Ls, int magic) {
   return (Ls >= TK) ? (x >= Ls ? 1 : 0) : ((x * magic) >> 16);
 }
 
+// partial tile of one contraction split: [NI*NJ*4][256] float4, thread-minor
+template <int NI, int NJ>
+__device__ __forceinline__ void wgrad_slab_store(float* slab, const f32x16 (&acc)[NI][NJ], int tid) {
+  f32x4* s4 = reinterpret_cast<f32x4*>(slab);
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2],
+                         acc[i][j][4 * q + 3]};
+        s4[((i * NJ + j) * 4 + q) * 256 + tid] = v;
+      }
+}
+
+// deterministic mode: dw[m][n][k] += sum over the contraction splits, in split order
+template <int U, int MB, int NBT>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs a, int nsplit) {
+  constexpr int S = 32 / U;
+  constexpr int CVW = NBT / U, NI = MB / 64, NJ = NBT / 64;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int cv0 = blockIdx.x * CVW, m0 = blockIdx.y * MB;
+  f32x16 acc[NI][NJ];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+  for (int z = 0; z < nsplit; ++z) {
+    const f32x4* s4 = reinterpret_cast<const f32x4*>(
+        a.w2_slabs + ((size_t)(z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (MB * NBT));
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 v = s4[((i * NJ + j) * 4 + q) * 256 + tid];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] += v[e];
+        }
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int cc = wn * (NBT / 2) + 32 * j + l31;
+    const int cv = cv0 + cc / U;
+    const int u = cc % U;
+    const int n = cv / S, r = cv % S;
+    const int k = S * u + r;
+    if (cv >= a.Cv || k >= a.K) continue;
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * (MB / 2) + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (m < a.M) a.dw[((size_t)m * a.N + n) * a.K + k] += acc[i][j][e];
+      }
+  }
+}
+
 // dW[m][n][S*u+r] += sum over the flattened (sample, time) columns.  Block tile: 128 rows
 // (m) x 128 columns ((n,r),u = 128/U virtual channels x U taps), contraction chunks of TK
 // columns, double buffered.  LO_ID / HI_ID: that operand has the identity transform (the
@@ -37,13 +102,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, h = lane >> 5;
 
-  if (a.prio_mode == 1) {
-    const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-    const unsigned hsh = (lin * 2654435761u) >> 30;
-    if (hsh == 1) __builtin_amdgcn_s_setprio(1);
-    else if (hsh == 2) __builtin_amdgcn_s_setprio(2);
-    else if (hsh == 3) __builtin_amdgcn_s_setprio(3);
-  }
   const int cv0 = blockIdx.x * CVW;
   const int m0 = blockIdx.y * MB;
   const int split_beg = blockIdx.z * a.cols_per_split;
@@ -244,7 +302,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     __syncthreads();
   }
 
-  // ---- epilogue: dw[m][n][S*u + r] += acc ----
+  // ---- epilogue: dw[m][n][S*u + r] += acc (atomics), or a slab for the ordered reduction ----
+  if (a.w2_slabs) {
+    wgrad_slab_store<NI, NJ>(a.w2_slabs + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x +
+                                           blockIdx.x) * (MB * NBT), acc, tid);
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int cc = wn * (NBT / 2) + 32 * j + l31;
@@ -263,8 +326,390 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
   }
 }
 
+// ====================================================================================
+// wgrad2_kernel: the same contraction for the big layers (128 x 128 block tiles) with a
+// staging path that leaves the matrix pipe alone (cost model: head of segan_conv.hip).
+//   * lo (always identity here: the launcher materialises a transformed or two-segment lo
+//     once per call) goes HBM/L2 -> LDS by LDS-DMA, 4 instructions per wave and chunk; the
+//     tile is [128 rows][32 columns] with the 16-byte column XOR-swizzled by (row >> 1) & 7
+//     (applied on the SOURCE address — the DMA destination is lane-linear) so that the
+//     ds_read_b128 fragment reads are conflict-free without row padding;
+//   * hi: a block covers 4 real channels = one per wave, so scale / shift / slope are wave-
+//     uniform scalars; a lane's <= 4 elements (phase r, window position p) have byte offsets
+//     that depend only on the chunk's CLASS (first / middle / last chunk of a sample, or whole
+//     samples when Ls <= 32): three precomputed offset sets, everything else is the SGPR
+//     offset; padding zeros and the reflect mirror are inside the sets.
+// Preconditions (launcher): Ls % 32 == 0 or 32 % Ls == 0; tensors below 2 GiB per workgroup
+// range.  The contraction is split over blockIdx.z; partial tiles are added to dw with fp32
+// atomics, or — deterministic mode — written as slabs and added in split order by
+// wgrad_reduce_kernel.
+// ====================================================================================
+#define WG2_TK 32
+#define WG2_NLD 4
+
+template <int U, bool XF>
+__global__ __launch_bounds__(256, 2) void wgrad2_kernel(const WgradArgs a) {
+  constexpr int S = 32 / U;
+  constexpr int TK = WG2_TK;
+  constexpr int MB = 128, NBT = 128;
+  constexpr int CVW = NBT / U;        // virtual channels per block = 4 real channels x S phases
+  constexpr int NI = 2, NJ = 2;
+  constexpr int NLD = WG2_NLD;
+  static_assert(CVW / S == 4, "one real hi channel per wave");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int RLw = a.RLw;
+  float* Al0 = smem;                  // [2][MB*TK]  (swizzled 16-B columns)
+  float* Bl0 = Al0 + 2 * MB * TK;     // [2][CVW*RLw]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, h = lane >> 5;
+
+  const int cv0 = blockIdx.x * CVW;
+  const int m0 = blockIdx.y * MB;
+  const int ch_beg = blockIdx.z * a.w2_cps;
+  const int ch_end = min(ch_beg + a.w2_cps, a.w2_nch);
+  if (ch_beg >= ch_end) return;
+  const int Ls = a.Ls;
+  const int cpsm = a.w2_cpsample;     // chunks per sample (Ls >= TK) or 0 (whole samples per chunk)
+  const int spc = a.w2_spc;           // samples per chunk (Ls < TK: TK / Ls, else 1)
+
+  // first sample of this workgroup's range; descriptors are rebased to it
+  const int b_first = cpsm ? ch_beg / cpsm : ch_beg * spc;
+  int tq = cpsm ? ch_beg - b_first * cpsm : 0;     // chunk index inside the sample
+  int brel = 0;                                     // sample of the current chunk, relative
+
+  // ---- lo: LDS-DMA ----
+  const long lo_left = (long)(a.B - b_first) * a.M * Ls * 4;
+  const __amdgpu_buffer_rsrc_t lor = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.lo.p0) + (size_t)b_first * a.M * Ls, 0,
+      (int)(lo_left < 0x7fffffffL ? lo_left : 0x7fffffffL), 0x00020000);
+  // instruction q = wave + 4p moves rows 8q .. 8q+7: lane -> (row 8q + rr, physical column pc)
+  const int rr = lane >> 3, pc = lane & 7;
+  const int lc = pc ^ ((((wave & 1) << 2) + (rr >> 1)) & 7);    // logical 16-B column
+  int lo_vo;
+  if (cpsm) lo_vo = (rr * Ls + 4 * lc) * 4;
+  else {
+    const int c4 = Ls / 4;            // 16-B columns per sample
+    lo_vo = (rr * Ls + (lc / c4) * a.M * Ls + 4 * (lc % c4)) * 4;
+  }
+
+  // ---- hi: this wave's real channel ----
+  const int n_hi = cv0 / S + wave;
+  const bool n_ok = n_hi < a.N;
+  const bool hseg1 = n_ok && n_hi >= a.hi.C0;
+  const int hC = hseg1 ? a.hi.C1 : a.hi.C0;
+  const int hn = hseg1 ? n_hi - a.hi.C0 : n_hi;
+  const long hi_left = (long)(a.B - b_first) * hC * a.Lhi * 4;
+  const __amdgpu_buffer_rsrc_t hir = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(hseg1 ? a.hi.p1 : a.hi.p0) + (size_t)b_first * hC * a.Lhi, 0,
+      n_ok ? (int)(hi_left < 0x7fffffffL ? hi_left : 0x7fffffffL) : 0, 0x00020000);
+  float xsc = 1.0f, xsh = 0.0f, xsl = 1.0f;
+  if (XF) {
+    typedef const __attribute__((address_space(4))) float* cptr;
+    const int cx = n_ok ? n_hi : 0;
+    xsc = ((cptr)a.hi.scale)[cx];
+    xsh = ((cptr)a.hi.shift)[cx];
+    xsl = ((cptr)a.hi.slope)[cx];
+  }
+  // element e = lane + 64*i of the wave: phase r = e / RLw, window position p = e % RLw.
+  // Offset sets: [0] first chunk of a sample (or whole samples), [1] middle, [2] last.
+  const int nld = a.w2_nld;
+  int hvo[3][NLD];
+  int hl_w[NLD];
+  bool hok[NLD];      // the lane owns an element of the window (lanes past S*pw stage nothing)
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) {
+    const int e = lane + 64 * i;
+    const int r = e / a.w2_pw, p = e - r * a.w2_pw;
+    hok[i] = i < nld && r < S;
+    hl_w[i] = ((wave * S + (r < S ? r : 0)) * RLw + p);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) hvo[c][i] = (int)0x80000000u;
+    if (i < nld && r < S) {
+      if (cpsm) {
+        const int i0 = segan_hi_index(S * p + r, a.Lhi, a.padL, a.mode, a.roll);
+        if (i0 >= 0) hvo[0][i] = i0 * 4;
+        hvo[1][i] = (S * p + r) * 4;
+        const int i2 = segan_hi_index(S * (Ls - TK + p) + r, a.Lhi, a.padL, a.mode, a.roll);
+        if (i2 >= 0) hvo[2][i] = i2 * 4;
+      } else {
+        const int per = Ls + a.H;
+        const int sidx = p / per, tau = p - sidx * per;
+        const int i0 = segan_hi_index(S * tau + r, a.Lhi, a.padL, a.mode, a.roll);
+        if (sidx < spc && i0 >= 0) hvo[0][i] = (sidx * hC * a.Lhi + i0) * 4;
+      }
+    }
+  }
+
+  // ---- MFMA operand offsets ----
+  // lo fragment of row block i, column group j: logical 16-B column 2j + h, swizzled
+  int aoff[NI][4];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int row = wm * 64 + 32 * i + l31;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) aoff[i][j] = row * TK + 4 * ((2 * j + h) ^ ((row >> 1) & 7));
+  }
+  // hi: contraction column k = 8j + 4h + i of the chunk sits at LDS position k, plus H for
+  // every completed sample when a chunk holds several (Ls < 32, a power of two >= 8)
+  int bpos[4][NJ];
+#pragma unroll
+  for (int jj = 0; jj < NJ; ++jj) {
+    const int cc = wn * (NBT / 2) + 32 * jj + l31;
+    const int bb = (cc / U) * RLw + cc % U + 4 * h;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      bpos[j][jj] = bb + 8 * j + (a.w2_lsshift >= 0 ? ((8 * j) >> a.w2_lsshift) * a.H : 0);
+  }
+
+  f32x16 acc[NI][NJ];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+  float hreg[NLD];
+  auto load_chunk = [&](int buf) {
+    // lo: 4 DMA instructions per wave
+    const int t0 = tq * TK;
+    const int lo_s = ((brel * a.M + m0) * Ls + t0) * 4;
+    float* Al = Al0 + buf * (MB * TK);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int q = wave + 4 * p;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          lor, (__attribute__((address_space(3))) void*)(Al + q * 256), 16, lo_vo,
+          lo_s + q * 8 * Ls * 4, 0, 0);
+    }
+    // hi
+    const int rowb = (brel * hC + hn) * a.Lhi * 4;
+    if (cpsm == 0 || tq == 0) {
+#pragma unroll
+      for (int i = 0; i < NLD; ++i)
+        if (i < nld) hreg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(hir, hvo[0][i], rowb, 0));
+    } else if (tq == cpsm - 1) {
+#pragma unroll
+      for (int i = 0; i < NLD; ++i)
+        if (i < nld) hreg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(hir, hvo[2][i], rowb, 0));
+    } else {
+      const int so = rowb + (S * t0 - a.padL - a.roll) * 4;
+#pragma unroll
+      for (int i = 0; i < NLD; ++i)
+        if (i < nld) hreg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(hir, hvo[1][i], so, 0));
+    }
+    // advance to the next chunk
+    if (cpsm) { if (++tq == cpsm) { tq = 0; ++brel; } }
+    else brel += spc;
+  };
+  auto store_chunk = [&](int buf) {
+    float* Bl = Bl0 + buf * (CVW * RLw);
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      if (i < nld) {
+        float v = hreg[i];
+        if (XF) {
+          v = fmaf(v, xsc, xsh);
+          v = v > 0.0f ? v : v * xsl;
+        }
+        if (hok[i]) Bl[hl_w[i]] = v;
+      }
+    }
+  };
+
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+  for (int ch = ch_beg; ch < ch_end; ++ch) {
+    const int buf = (ch - ch_beg) & 1;
+    if (ch + 1 < ch_end) load_chunk(buf ^ 1);
+    typedef const volatile __attribute__((address_space(3))) float* ldsp;
+    const float* Al = Al0 + buf * (MB * TK);
+    ldsp Bl = (ldsp)(Bl0 + buf * (CVW * RLw));
+    f32x4 af0[NI], af1[NI];
+    float bv0[NJ], bv1[NJ];
+    auto read_a = [&](int j, f32x4 (&af)[NI]) {
+#pragma unroll
+      for (int i = 0; i < NI; ++i) af[i] = *reinterpret_cast<const f32x4*>(Al + aoff[i][j]);
+    };
+    // step s covers contraction columns k = 8*(s/4) + 4h + (s&3)
+    auto read_b = [&](int s, float (&bv)[NJ]) {
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj) bv[jj] = Bl[bpos[s / 4][jj] + (s & 3)];
+    };
+    auto mma = [&](const f32x4 (&af)[NI], int e, const float (&bv)[NJ]) {
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj)
+          acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bv[jj], acc[i][jj], 0, 0, 0);
+    };
+    read_a(0, af0);
+    read_b(0, bv0);
+#define SB __builtin_amdgcn_sched_barrier(0)
+#pragma unroll
+    for (int j = 0; j < 4; j += 2) {
+      read_a(j + 1, af1);
+      read_b(4 * j + 1, bv1); SB; mma(af0, 0, bv0); SB;
+      read_b(4 * j + 2, bv0); SB; mma(af0, 1, bv1); SB;
+      read_b(4 * j + 3, bv1); SB; mma(af0, 2, bv0); SB;
+      read_b(4 * j + 4, bv0); SB; mma(af0, 3, bv1); SB;
+      if (j + 2 < 4) read_a(j + 2, af0);
+      read_b(4 * j + 5, bv1); SB; mma(af1, 0, bv0); SB;
+      read_b(4 * j + 6, bv0); SB; mma(af1, 1, bv1); SB;
+      read_b(4 * j + 7, bv1); SB; mma(af1, 2, bv0); SB;
+      if (4 * j + 8 < TK / 2) read_b(4 * j + 8, bv0);
+      SB; mma(af1, 3, bv1); SB;
+    }
+#undef SB
+    if (ch + 1 < ch_end) store_chunk(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue ----
+  if (a.w2_slabs) {
+    wgrad_slab_store<NI, NJ>(a.w2_slabs + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x +
+                                           blockIdx.x) * (MB * NBT), acc, tid);
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int cc = wn * (NBT / 2) + 32 * j + l31;
+    const int cv = cv0 + cc / U;
+    const int u = cc % U;
+    const int n = cv / S, r = cv % S;
+    const int k = S * u + r;
+    if (cv >= a.Cv || k >= a.K) continue;
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * (MB / 2) + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (m < a.M) atomicAdd(a.dw + ((size_t)m * a.N + n) * a.K + k, acc[i][j][e]);
+      }
+  }
+}
+
+// lo with a transform (the deconv layers' input) or in two segments: materialised once per
+// call as a plain [B][M][Ls] tensor (one streaming pass; the contraction re-reads it from
+// every one of the N*S/16 column tiles)
+__global__ void wgrad_lo_materialize_kernel(const segan_src lo, float* out, int B, int M, int Ls4,
+                                            int xf) {
+  const long total = (long)B * M * Ls4;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int t4 = (int)(e % Ls4);
+    const long bm = e / Ls4;
+    const int m = (int)(bm % M);
+    const int b = (int)(bm / M);
+    const float* src = m < lo.C0 ? lo.p0 + ((size_t)b * lo.C0 + m) * (size_t)(4 * Ls4)
+                                 : lo.p1 + ((size_t)b * lo.C1 + (m - lo.C0)) * (size_t)(4 * Ls4);
+    f32x4 v = reinterpret_cast<const f32x4*>(src)[t4];
+    if (xf) {
+      const ChanXf x = segan_chan_xf(lo, m);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = segan_apply_xf(x, v[q]);
+    }
+    reinterpret_cast<f32x4*>(out)[e] = v;
+  }
+}
+
+// ---- wgrad2 launch ----
+static int wg_cur_device() {
+  int d = 0;
+  (void)hipGetDevice(&d);
+  return d & 15;
+}
+
+// scratch layout of the fp32 weight gradient: [lo materialised: B*M*Ls floats, when lo has a
+// transform or two segments][slabs: blocks * 128*128 floats, deterministic mode]
+static size_t wgrad2_slab_floats(int tiles, int nsplit) { return (size_t)tiles * nsplit * 128 * 128; }
+
+static bool wgrad2_geometry_ok(const WgradArgs& a, int U) {
+  if (a.Cv <= 64 / U) return false;                    // edge layers: small-tile kernels
+  if (a.Ls >= WG2_TK) return a.Ls % WG2_TK == 0;
+  return a.Ls >= 8 && (WG2_TK % a.Ls) == 0;
+}
+
+static void wgrad2_plan(const WgradArgs& a, int U, int occ, int& tiles, int& nsplit, int& cps,
+                        int& nch) {
+  const int ncol = ceil_div(a.Cv, 128 / U), nrow = ceil_div(a.M, 128);
+  tiles = ncol * nrow;
+  nch = ceil_div(a.Ctot, WG2_TK);
+  const int G = 256 * occ;
+  // equal work per workgroup: aim at whole rounds of resident workgroups
+  int best = 1;
+  double best_eff = 0.0;
+  const int ns_max = nch / 8 > 0 ? nch / 8 : 1;           // at least 8 chunks per workgroup
+  for (int ns = 1; ns <= ns_max && (long)tiles * ns <= 4L * G; ++ns) {
+    const long blocks = (long)tiles * ns;
+    const double eff = (double)blocks / ((double)G * ((blocks + G - 1) / G));
+    // fewer, longer workgroups win ties (one prologue / epilogue each)
+    if (eff > best_eff + 0.02) { best_eff = eff; best = ns; }
+  }
+  cps = ceil_div(nch, best);
+  nsplit = ceil_div(nch, cps);
+}
+
+template <int U, bool XF>
+static int launch_wgrad2(WgradArgs& a, hipStream_t st, bool deterministic, float* slabs,
+                         size_t slab_floats_avail) {
+  constexpr int TK = WG2_TK;
+  constexpr int S = 32 / U;
+  a.H = U - 1;
+  const bool multi = a.Ls < TK;
+  a.w2_cpsample = multi ? 0 : a.Ls / TK;
+  a.w2_spc = multi ? TK / a.Ls : 1;
+  a.w2_lsshift = -1;
+  if (multi) { int sh = 0; while ((1 << sh) < a.Ls) ++sh; a.w2_lsshift = sh; }
+  a.w2_pw = multi ? a.w2_spc * (a.Ls + a.H) : TK + a.H;
+  a.RLw = a.w2_pw + (8 - a.w2_pw % 32 + 32) % 32;       // row stride = 8 (mod 32)
+  a.w2_nld = ceil_div(S * a.w2_pw, 64);
+  if (a.w2_nld > WG2_NLD) return SEGAN_EUNSUPPORTED;
+  const size_t lds = (size_t)(2 * 128 * TK + 2 * (128 / U) * a.RLw) * sizeof(float);
+  auto kern = wgrad2_kernel<U, XF>;
+  static bool attr_done[16];
+  static int occ_c[16];
+  const int d = wg_cur_device();
+  if (!attr_done[d]) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), 256,
+                                                     lds) != hipSuccess || nb < 1)
+      nb = 2;
+    occ_c[d] = nb > 4 ? 4 : nb;
+    attr_done[d] = true;
+  }
+  int tiles, nsplit, cps, nch;
+  wgrad2_plan(a, U, occ_c[d], tiles, nsplit, cps, nch);
+  a.w2_cps = cps;
+  a.w2_nch = nch;
+  a.w2_slabs = nullptr;
+  if (deterministic) {
+    if (slabs == nullptr || slab_floats_avail < wgrad2_slab_floats(tiles, nsplit)) {
+      segan_set_error("wgrad: deterministic mode needs %zu bytes of scratch for the partial tiles",
+                      wgrad2_slab_floats(tiles, nsplit) * sizeof(float));
+      return SEGAN_EINVAL;
+    }
+    a.w2_slabs = slabs;
+  }
+  const int ncol = ceil_div(a.Cv, 128 / U), nrow = ceil_div(a.M, 128);
+  hipLaunchKernelGGL(kern, dim3(ncol, nrow, nsplit), dim3(256), lds, st, a);
+  if (int e = segan_check_launch("wgrad2_kernel")) return e;
+  if (deterministic) {
+    hipLaunchKernelGGL((wgrad_reduce_kernel<U, 128, 128>), dim3(ncol, nrow), dim3(256), 0, st, a, nsplit);
+    return segan_check_launch("wgrad_reduce_kernel");
+  }
+  return SEGAN_OK;
+}
+
 template <int U, bool LO_ID, bool HI_ID, int MB, int NBT>
-static int launch_wgrad_tile(WgradArgs& a, hipStream_t st) {
+static int launch_wgrad_tile(WgradArgs& a, hipStream_t st, float* slabs, size_t slab_floats) {
   constexpr int CVW = NBT / U;
   constexpr int TK = 32;
   int NS;
@@ -285,8 +730,6 @@ static int launch_wgrad_tile(WgradArgs& a, hipStream_t st) {
   }
   if (int e = segan_src_defaults(&a.lo, st, "wgrad(lo)")) return e;
   if (int e = segan_src_defaults(&a.hi, st, "wgrad(hi)")) return e;
-  static const int prio_env = [] { const char* e = getenv("SEGAN_PRIO"); return e ? atoi(e) : 0; }();
-  a.prio_mode = prio_env;
   a.ls_magic = (65536 + a.Ls - 1) / a.Ls;
   a.per_magic = (65536 + a.Ls + a.H - 1) / (a.Ls + a.H);
   const int ncol = ceil_div(a.Cv, CVW);
@@ -294,8 +737,7 @@ static int launch_wgrad_tile(WgradArgs& a, hipStream_t st) {
   // split the (b,t) contraction so the grid has a few workgroups per CU
   const int tiles = ncol * nrow;
   const int chunks = ceil_div(a.Ctot, TK);
-  static const int tgt_env = [] { const char* e = getenv("SEGAN_WGRAD_BLOCKS"); return e ? atoi(e) : 0; }();
-  int nsplit = ceil_div(tgt_env > 0 ? tgt_env : 1536, tiles);
+  int nsplit = ceil_div(1536, tiles);
   if (nsplit > chunks / 4) nsplit = chunks / 4;   // at least 4 chunks per workgroup
   if (nsplit < 1) nsplit = 1;
   const int chunks_per = ceil_div(chunks, nsplit);
@@ -303,49 +745,116 @@ static int launch_wgrad_tile(WgradArgs& a, hipStream_t st) {
   a.cols_per_split = chunks_per * TK;
   const size_t lds = (size_t)(2 * MB * (TK + 4) + 2 * CVW * a.RLw) * sizeof(float);
   auto kern = wgrad_kernel<U, TK, LO_ID, HI_ID, MB, NBT>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static bool attr_done[16];
+  const int d = wg_cur_device();
+  if (!attr_done[d]) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
+    attr_done[d] = true;
+  }
+  a.w2_slabs = nullptr;
+  if (slabs) {
+    if (slab_floats < (size_t)tiles * nsplit * MB * NBT) {
+      segan_set_error("wgrad: deterministic mode needs %zu bytes of scratch for the partial tiles",
+                      (size_t)tiles * nsplit * MB * NBT * sizeof(float));
+      return SEGAN_EINVAL;
+    }
+    a.w2_slabs = slabs;
   }
   hipLaunchKernelGGL(kern, dim3(ncol, nrow, nsplit), dim3(256), lds, st, a);
-  return segan_check_launch("wgrad_kernel");
+  if (int e = segan_check_launch("wgrad_kernel")) return e;
+  if (slabs) {
+    hipLaunchKernelGGL((wgrad_reduce_kernel<U, MB, NBT>), dim3(ncol, nrow), dim3(256), 0, st, a, nsplit);
+    return segan_check_launch("wgrad_reduce_kernel");
+  }
+  return SEGAN_OK;
 }
 
 template <int U, bool LO_ID, bool HI_ID>
-static int launch_wgrad_x(WgradArgs& a, hipStream_t st) {
-  static const bool small_on = [] { const char* e = getenv("SEGAN_WGRAD_SMALL"); return !e || atoi(e) != 0; }();
+static int launch_wgrad_x(WgradArgs& a, hipStream_t st, float* slabs, size_t slab_floats) {
   // edge layers (1-2 channels on the hi side: N*S <= 64/U virtual channels): 64 columns
   // suffice, and 64 rows when M <= 64
-  if (small_on && a.Cv <= 64 / U) {
-    if (a.M <= 64) return launch_wgrad_tile<U, LO_ID, HI_ID, 64, 64>(a, st);
-    return launch_wgrad_tile<U, LO_ID, HI_ID, 128, 64>(a, st);
+  if (a.Cv <= 64 / U) {
+    if (a.M <= 64) return launch_wgrad_tile<U, LO_ID, HI_ID, 64, 64>(a, st, slabs, slab_floats);
+    return launch_wgrad_tile<U, LO_ID, HI_ID, 128, 64>(a, st, slabs, slab_floats);
   }
-  return launch_wgrad_tile<U, LO_ID, HI_ID, 128, 128>(a, st);
+  return launch_wgrad_tile<U, LO_ID, HI_ID, 128, 128>(a, st, slabs, slab_floats);
 }
 
 template <int U>
-static int launch_wgrad_t(WgradArgs& a, hipStream_t st) {
+static int launch_wgrad_t(WgradArgs& a, hipStream_t st, float* slabs, size_t slab_floats) {
   const bool lo_id = !a.lo.scale && !a.lo.shift && !a.lo.slope;
   const bool hi_id = !a.hi.scale && !a.hi.shift && !a.hi.slope;
-  if (lo_id && hi_id) return launch_wgrad_x<U, true, true>(a, st);
-  if (lo_id) return launch_wgrad_x<U, true, false>(a, st);
-  if (hi_id) return launch_wgrad_x<U, false, true>(a, st);
-  return launch_wgrad_x<U, false, false>(a, st);
+  if (lo_id && hi_id) return launch_wgrad_x<U, true, true>(a, st, slabs, slab_floats);
+  if (lo_id) return launch_wgrad_x<U, true, false>(a, st, slabs, slab_floats);
+  if (hi_id) return launch_wgrad_x<U, false, true>(a, st, slabs, slab_floats);
+  return launch_wgrad_x<U, false, false>(a, st, slabs, slab_floats);
+}
+
+// the fast kernel where its preconditions hold, the general one otherwise
+template <int U>
+static int launch_wgrad_fp32(WgradArgs& a, hipStream_t st, bool deterministic, float* scratch,
+                             size_t scratch_floats) {
+  float* slabs = nullptr;
+  size_t slab_floats = 0;
+  const size_t lo_floats = (size_t)a.B * a.M * a.Ls;
+  const bool lo_plain = !a.lo.scale && !a.lo.shift && !a.lo.slope && a.lo.C1 == 0;
+  bool fast = wgrad2_geometry_ok(a, U);
+  if (fast && !lo_plain && (scratch == nullptr || scratch_floats < lo_floats)) fast = false;
+  size_t used = (fast && !lo_plain) ? lo_floats : 0;
+  if (deterministic) {
+    if (scratch == nullptr) {
+      segan_set_error("wgrad: deterministic mode needs scratch (segan_wgrad_scratch_bytes)");
+      return SEGAN_EINVAL;
+    }
+    slabs = scratch + used;
+    slab_floats = scratch_floats - used;
+  }
+  if (fast) {
+    if (!lo_plain) {
+      if (int e = segan_src_defaults(&a.lo, st, "wgrad(lo)")) return e;
+      const bool xf = true;
+      const long total = (long)lo_floats / 4;
+      const unsigned grid = (unsigned)(total / 256 > 8192 ? 8192 : (total + 255) / 256);
+      hipLaunchKernelGGL(wgrad_lo_materialize_kernel, dim3(grid), dim3(256), 0, st, a.lo, scratch,
+                         a.B, a.M, a.Ls / 4, xf ? 1 : 0);
+      if (int e = segan_check_launch("wgrad_lo_materialize_kernel")) return e;
+      a.lo.p0 = scratch; a.lo.p1 = nullptr; a.lo.C0 = a.M; a.lo.C1 = 0;
+      a.lo.scale = a.lo.shift = a.lo.slope = nullptr;
+    }
+    const bool hi_xf = a.hi.scale || a.hi.shift || a.hi.slope;
+    if (hi_xf) {
+      if (int e = segan_src_defaults(&a.hi, st, "wgrad(hi)")) return e;
+    }
+    const int rc = hi_xf ? launch_wgrad2<U, true>(a, st, deterministic, slabs, slab_floats)
+                         : launch_wgrad2<U, false>(a, st, deterministic, slabs, slab_floats);
+    if (rc != SEGAN_EUNSUPPORTED) return rc;
+  }
+  return launch_wgrad_t<U>(a, st, slabs, slab_floats);
 }
 
 // ====================================================================================
 // C ABI
 // ====================================================================================
-extern "C" size_t segan_wgrad_scratch_bytes(int B, int M, int Ls, int precision) {
-  if (precision == SEGAN_PREC_FP32 || B <= 0 || M <= 0 || Ls <= 0) return 0;
-  return segan_wgrad_bf_scratch_bytes(B, M, Ls, precision == SEGAN_PREC_BF16 ? 1 : 3);
+extern "C" size_t segan_wgrad_scratch_bytes(int B, int M, int N, int Ls, int S, int precision,
+                                            int flags) {
+  if (B <= 0 || M <= 0 || N <= 0 || Ls <= 0 || !stride_ok(S)) return 0;
+  if (precision != SEGAN_PREC_FP32)
+    return segan_wgrad_bf_scratch_bytes(B, M, Ls, precision == SEGAN_PREC_BF16 ? 1 : 3);
+  // room for a materialised lo, plus (deterministic mode) the partial tiles of every split:
+  // at most max(tiles, 4 rounds of 1024 resident workgroups) tiles of 128 x 128
+  size_t bytes = (size_t)B * M * Ls * sizeof(float);
+  if (flags & SEGAN_WGRAD_DETERMINISTIC) {
+    const int U = 32 / S;
+    const size_t tiles = (size_t)ceil_div(N * S, 128 / U) * ceil_div(M, 128);
+    bytes += (tiles > 4096 ? tiles : 4096) * 128 * 128 * sizeof(float);
+  }
+  return bytes;
 }
 
 extern "C" int segan_wgrad(const segan_src* lo, const segan_src* hi, float* dw, int B, int M, int N,
                            int Ls, int K, int S, int padL, int mode, int roll, int precision,
-                           void* scratch, void* stream) {
+                           int flags, void* scratch, size_t scratch_bytes, void* stream) {
   SEGAN_REQUIRE(precision_ok(precision), "wgrad: bad precision %d", precision);
   SEGAN_REQUIRE(stride_ok(S), "wgrad: stride %d not in {1,2,4}", S);
   SEGAN_REQUIRE(K >= 1 && K <= 32, "wgrad: kernel width %d not in [1,32]", K);
@@ -366,9 +875,12 @@ extern "C" int segan_wgrad(const segan_src* lo, const segan_src* hi, float* dw, 
     a.lo_pk = scratch;
     return segan_wgrad_bf(a, 32 / S, precision == SEGAN_PREC_BF16 ? 1 : 3, st);
   }
+  const bool det = (flags & SEGAN_WGRAD_DETERMINISTIC) != 0;
+  float* sc = (float*)scratch;
+  const size_t scf = scratch ? scratch_bytes / sizeof(float) : 0;
   switch (S) {
-    case 4: return launch_wgrad_t<8>(a, st);
-    case 2: return launch_wgrad_t<16>(a, st);
-    default: return launch_wgrad_t<32>(a, st);
+    case 4: return launch_wgrad_fp32<8>(a, st, det, sc, scf);
+    case 2: return launch_wgrad_fp32<16>(a, st, det, sc, scf);
+    default: return launch_wgrad_fp32<32>(a, st, det, sc, scf);
   }
 }

@@ -25,6 +25,22 @@ _EUNSUPPORTED = -3
 _WGRAD_PACK = _os.environ.get('SEGAN_WGRAD_PACK', '1') != '0'
 
 
+_deterministic = _os.environ.get('SEGAN_DETERMINISTIC', '0') == '1'
+
+
+def set_deterministic(on):
+    """Bit-reproducible mode.  The forward / data-gradient contractions always are (their
+    stream-K tail is reduced in a fixed order); this switch makes the weight gradients and the
+    dense-head GEMMs reduce their contraction splits in a fixed order too instead of with fp32
+    atomics (a few percent slower).  Also SEGAN_DETERMINISTIC=1."""
+    global _deterministic
+    _deterministic = bool(on)
+
+
+def get_deterministic():
+    return _deterministic
+
+
 def set_precision(mode):
     """Precision of the forward / data-gradient contractions: 'fp32' (exact fp32 MFMA, the
     default and the benchmarked configuration), 'bf16' (bf16 operands, fp32 accumulate:
@@ -284,17 +300,25 @@ def wgrad(lo, hi, dw, K, S, padL, pad_mode, roll=0):
     cl, ch = lo.c_struct(), hi.c_struct()
     lib = _lib.load()
     if _precision != PREC_FP32:
-        nbytes = lib.segan_wgrad_scratch_bytes(lo.B, M, lo.L, _precision)
+        nbytes = lib.segan_wgrad_scratch_bytes(lo.B, M, N, lo.L, S, _precision, 0)
         scratch = torch.empty(nbytes, device=dw.device, dtype=torch.uint8) if _WGRAD_PACK else None
         rc = lib.segan_wgrad(ctypes.byref(cl), ctypes.byref(ch), _ptr(dw), lo.B, M, N, lo.L, K, S,
-                             padL, pad_mode, roll, _precision,
+                             padL, pad_mode, roll, _precision, 0,
                              ctypes.c_void_p(scratch.data_ptr()) if scratch is not None else None,
-                             _stream())
+                             nbytes if scratch is not None else 0, _stream())
         if rc != -3:
             check(rc, 'wgrad')
             return
+    flags = 1 if _deterministic else 0
+    lo_plain = lo.t1 is None and lo.scale is None and lo.shift is None and lo.slope is None
+    scratch, nbytes = None, 0
+    if flags or not lo_plain:
+        nbytes = lib.segan_wgrad_scratch_bytes(lo.B, M, N, lo.L, S, PREC_FP32, flags)
+        scratch = torch.empty(nbytes, device=dw.device, dtype=torch.uint8)
     check(lib.segan_wgrad(ctypes.byref(cl), ctypes.byref(ch), _ptr(dw), lo.B, M, N, lo.L, K, S, padL,
-                          pad_mode, roll, PREC_FP32, None, _stream()), 'wgrad')
+                          pad_mode, roll, PREC_FP32, flags,
+                          ctypes.c_void_p(scratch.data_ptr()) if scratch is not None else None, nbytes,
+                          _stream()), 'wgrad')
 
 
 def deconv1d_fwd(src, w, bias, S, act=ACT_NONE, pack=None):
@@ -492,7 +516,8 @@ def tanh_bwd(y, dy, clean=None, l1_scale=0.0, dbias=None):
 # ---------------------------------------------------------------------------------
 def gemm(A, sam, sak, Bm, sbk, sbn, C, M, N, K, overwrite):
     check(_lib.load().segan_gemm(_ptr(A), sam, sak, _ptr(Bm), sbk, sbn, _ptr(C), C.stride(0), M, N,
-                                 K, 1 if overwrite else 0, _stream()), 'gemm')
+                                 K, 1 if overwrite else 0, 1 if _deterministic else 0, _stream()),
+          'gemm')
 
 
 def linear_fwd(x, w):
