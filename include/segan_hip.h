@@ -93,6 +93,10 @@ int segan_pack_weights_bf(const float* w, void* out, int M, int N, int K, int S,
  * with less (or NULL) the launch simply stays one-tile-per-workgroup.  The scratch must not be
  * shared by launches that may run concurrently (different streams). */
 size_t segan_corr_scratch_bytes(void);
+/* Diagnostics (tests): how the calling thread's last fp32 forward / data-gradient contraction
+ * was launched: {kernel (1 general, 2 fast), workgroups, tiles, tiles run whole, (tile, chunk)
+ * units per workgroup of the stream-K part or 0, input transform mode}. */
+void segan_debug_last_corr(int* out6);
 
 /* GConv1DBlock forward without norm/activation (modules.py:91-99):
  *   out[b,m,t] = bias[m] + sum_{n,k} w[m,n,k] * pad(roll(x))[b,n,S*t+k]

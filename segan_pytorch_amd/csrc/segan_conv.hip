@@ -725,6 +725,20 @@ __global__ void fold_halo_kernel(float* dx, const float* halo, int rows, int L, 
   }
 }
 
+// diagnostics: how the last forward / data-gradient contraction of this thread was launched
+static thread_local int g_last_corr[6];
+static void note_launch(int kind, unsigned grid, const CorrArgs& a, int ntiles) {
+  g_last_corr[0] = kind;             // 1 corr_kernel, 2 corr2_kernel
+  g_last_corr[1] = (int)grid;
+  g_last_corr[2] = ntiles;
+  g_last_corr[3] = a.sk_nfull;       // tiles run whole; the other ntiles - sk_nfull were cut (stream-K)
+  g_last_corr[4] = a.sk_total > 0 ? a.sk_units : 0;
+  g_last_corr[5] = a.xf_mode;
+}
+extern "C" void segan_debug_last_corr(int* out6) {
+  for (int i = 0; i < 6; ++i) out6[i] = g_last_corr[i];
+}
+
 // ---- launch plumbing ---------------------------------------------------------------------
 // One process drives one GPU, but nothing here assumes it: what is cached is cached per device.
 static int cur_device() {
@@ -803,6 +817,7 @@ static int launch_corr_t(CorrArgs a, hipStream_t st, bool allow_sk) {
   const int nch = ceil_div(a.Ktot, KC);
   const unsigned grid = plan_streamk(a, ntiles, nch, resident_per_cu(kern, lds, occ, occ_lds),
                                      (size_t)MB * NB, allow_sk);
+  note_launch(1, grid, a, ntiles);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
   if (int e = segan_check_launch("corr_kernel")) return e;
   if (a.sk_total > 0) {
@@ -834,6 +849,7 @@ static int launch_corr2_x(CorrArgs a, hipStream_t st, bool allow_sk) {
   const int nch = ceil_div(a.Ktot, KC);
   const unsigned grid = plan_streamk(a, ntiles, nch, resident_per_cu(kern, lds, occ, occ_lds),
                                      (size_t)MB * NB, allow_sk);
+  note_launch(2, grid, a, ntiles);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
   if (int e = segan_check_launch("corr2_kernel")) return e;
   if (a.sk_total > 0) {
@@ -906,7 +922,7 @@ static int launch_corr_tt(CorrArgs& a, hipStream_t st) {
 
 template <bool IN_HI, bool OUT_HI>
 static int launch_corr(CorrArgs& a, int U, hipStream_t st) {
-  a.xf_mode = (a.in.scale || a.in.shift) ? 2 : (a.in.slope ? 1 : 0);
+  a.xf_mode = a.in.shift ? 2 : ((a.in.scale || a.in.slope) ? 1 : 0);
   if (int e = segan_src_defaults(&a.in, st, "corr")) return e;
   const long in_elems = (long)a.B * (a.in.C0 + a.in.C1) * a.Lin;
   if (in_elems >= (1L << 31)) {

@@ -67,7 +67,7 @@ struct CorrArgs {
   size_t out0_elems, out1_elems, halo_elems;   // host side: what the bf16 stream-K zeroes
   float* sk_ws;                // fp32 stream-K: accumulator slabs of the cut tiles (caller scratch)
   size_t sk_ws_floats;
-  int xf_mode;                 // input transform: 0 identity, 1 slope only, 2 scale/shift/slope
+  int xf_mode;                 // input transform: 0 identity, 1 scale / slope (a zero stays zero), 2 with a shift
   int RLv, nld;                // corr2: valid window positions (RLs is the padded row), loads per lane
 };
 

@@ -176,10 +176,10 @@ class SEGAN(Model):
             raise ValueError('Unrecognized optimizer {}'.format(opts.opt))
         return Gopt, Dopt
 
-    def gan_step(self, clean, noisy, Gopt, Dopt, criterion, l1_weight, z=None):
-        """One LSGAN step, model.py:292-321 (from ``Dopt.zero_grad()`` to
-        ``Gopt.step()``).  clean / noisy: [B, 1, T] on the device.  Returns the four
-        losses as 0-dim device tensors (no host sync)."""
+    def d_phase(self, clean, noisy, Dopt, criterion, z=None):
+        """Discriminator half of the step (model.py:292-308): G forward, D on the real and on
+        the (detached) fake pair, both backward passes, gradient all-reduce, ``Dopt.step()``.
+        Returns (Genh, d_real_loss, d_fake_loss); Genh keeps its graph for ``g_phase``."""
         # (1) D real update
         Dopt.zero_grad()
         Genh = self.infer_G(noisy, clean, z=z)
@@ -192,7 +192,11 @@ class SEGAN(Model):
         d_fake_loss.backward()
         sdist.allreduce_grads(Dopt)
         Dopt.step()
-        # (3) G update through the (updated) D
+        return Genh, d_real_loss, d_fake_loss
+
+    def g_phase(self, Genh, clean, noisy, Gopt, criterion, l1_weight):
+        """Generator half (model.py:310-321): D (just updated, frozen here) on the fake pair,
+        adversarial + L1 loss, backward, gradient all-reduce, ``Gopt.step()``."""
         Gopt.zero_grad()
         with _frozen(self.D):
             d_fake_, _ = self.infer_D(Genh, noisy)
@@ -202,6 +206,14 @@ class SEGAN(Model):
             g_loss.backward()
         sdist.allreduce_grads(Gopt)
         Gopt.step()
+        return g_adv_loss, g_l1_loss
+
+    def gan_step(self, clean, noisy, Gopt, Dopt, criterion, l1_weight, z=None):
+        """One LSGAN step, model.py:292-321 (from ``Dopt.zero_grad()`` to
+        ``Gopt.step()``).  clean / noisy: [B, 1, T] on the device.  Returns the four
+        losses as 0-dim device tensors (no host sync)."""
+        Genh, d_real_loss, d_fake_loss = self.d_phase(clean, noisy, Dopt, criterion, z=z)
+        g_adv_loss, g_l1_loss = self.g_phase(Genh, clean, noisy, Gopt, criterion, l1_weight)
         return d_real_loss, d_fake_loss, g_adv_loss, g_l1_loss
 
     def train(self, opts, dloader, criterion, l1_init, l1_dec_step, l1_dec_epoch, log_freq,

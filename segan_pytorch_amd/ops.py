@@ -139,6 +139,17 @@ def _scratch():
     return ctypes.c_void_p(buf.data_ptr()), buf.numel()
 
 
+def last_corr_launch():
+    """Diagnostics: dict describing this thread's last fp32 conv / deconv forward or data
+    gradient launch (segan_debug_last_corr)."""
+    arr = (ctypes.c_int * 6)()
+    _lib.load().segan_debug_last_corr(arr)
+    k = ('kernel', 'workgroups', 'tiles', 'tiles_whole', 'streamk_units', 'xf_mode')
+    d = dict(zip(k, list(arr)))
+    d['streamk'] = d['streamk_units'] > 0
+    return d
+
+
 def conv_pad(K, S):
     return layout.conv_pad(K, S)
 

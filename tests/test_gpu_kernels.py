@@ -685,3 +685,196 @@ def test_bf16x3_is_as_accurate_as_the_fp32_path():
         errs[mode] = (max_rel(out, ref), max_rel(dx, xd.grad), max_rel(dw, wd.grad))
     for e3, e32 in zip(errs['bf16x3'], errs['fp32']):
         assert e3 < 2.0 * e32 + 1e-7, errs
+
+
+# ---------------------------------------------------------------------------------------------
+# The real layer shapes at batch sizes where the launches take the code paths of the
+# benchmarked configuration (B = 300): strided whole-tile rounds, the stream-K tail with its
+# slabs + fixed-order fixup kernel, the dead z-half tiles, the large contraction splits of the
+# weight gradients.  Reference: torch fp64 on the CPU.
+# ---------------------------------------------------------------------------------------------
+SCALE_CONV = [
+    # name, N, M, L, roll, B
+    ('enc1', 64, 128, 4096, 3, 80),
+    ('enc1', 64, 128, 4096, -5, 300),
+    ('enc2', 128, 256, 1024, -2, 80),
+    ('enc3', 256, 512, 256, 5, 80),
+    ('enc3', 256, 512, 256, 0, 300),
+    ('enc4', 512, 1024, 64, -4, 80),
+    ('enc4', 512, 1024, 64, 1, 300),
+]
+
+
+@pytest.mark.parametrize('name,N,M,L,roll,B', SCALE_CONV)
+def test_conv_layers_at_batch_scale(name, N, M, L, roll, B):
+    ops = _ops()
+    S, K = 4, 31
+    x = rnd(B, N, L, seed=11)
+    sl = rnd(N, seed=12).abs() * 0.3          # PReLU on load, as the encoders consume it
+    w = rnd(M, N, K, seed=13, scale=0.05)
+    b = rnd(M, seed=14)
+    hd = xform_ref(x, slope=sl).requires_grad_(True)      # the activated input the conv sees
+    wd = w.double().requires_grad_(True)
+    ref = conv_ref(hd, wd, b.double(), S, roll)
+    xg, wg, bg, slg = x.to(DEV), w.to(DEV), b.to(DEV), sl.to(DEV)
+    src = ops.Src(xg, slope=slg)
+    out = ops.conv1d_fwd(src, wg, bg, S, roll=roll)
+    info_f = ops.last_corr_launch()
+    assert max_rel(out, ref) < TOL
+    assert torch.equal(out, ops.conv1d_fwd(src, wg, bg, S, roll=roll))      # bit-reproducible
+    da = rnd(*ref.shape, seed=15)
+    ref.backward(da.double())
+    dag = da.to(DEV)
+    dx = ops.conv1d_dgrad(dag, wg, L, S, roll=roll)        # gradient w.r.t. the activated input
+    info_t = ops.last_corr_launch()
+    assert max_rel(dx, hd.grad) < TOL
+    assert torch.equal(dx, ops.conv1d_dgrad(dag, wg, L, S, roll=roll))
+    padL = ops.conv_pad(K, S)[0]
+    for det in (False, True):
+        ops.set_deterministic(det)
+        try:
+            dw = torch.zeros_like(wg)
+            ops.wgrad(ops.Src(dag), src, dw, K, S, padL, ops.PAD_REFLECT, roll=roll)
+            assert max_rel(dw, wd.grad) < TOL, det
+            if det:
+                dw2 = torch.zeros_like(wg)
+                ops.wgrad(ops.Src(dag), src, dw2, K, S, padL, ops.PAD_REFLECT, roll=roll)
+                assert torch.equal(dw, dw2)
+        finally:
+            ops.set_deterministic(False)
+    # the launches really took the fast kernel, and at these sizes the stream-K tail
+    assert info_f['kernel'] == 2 and info_t['kernel'] == 2
+    if B == 300 or name in ('enc3', 'enc4'):
+        assert info_f['tiles'] >= 64
+    test_conv_layers_at_batch_scale.seen = getattr(test_conv_layers_at_batch_scale, 'seen', [])
+    test_conv_layers_at_batch_scale.seen.append((name, B, info_f['streamk'], info_t['streamk']))
+
+
+def test_stream_k_paths_were_exercised():
+    """Of the batch-scale cases above, several must have run the stream-K tail in each form."""
+    seen = getattr(test_conv_layers_at_batch_scale, 'seen', [])
+    if not seen:
+        pytest.skip('batch-scale cases did not run')
+    assert sum(1 for s in seen if s[2]) >= 2, seen      # F form
+    assert sum(1 for s in seen if s[3]) >= 2, seen      # T form
+
+
+SCALE_DECONV = [
+    # name, M0 (first segment), M1 (second segment), N, Ls, B
+    ('dec0', 1024, 1024, 512, 16, 80),
+    ('dec0', 1024, 1024, 512, 16, 300),
+    ('dec1', 512, 512, 256, 64, 80),
+    ('dec2', 256, 256, 128, 256, 80),
+    ('dec3', 128, 128, 64, 1024, 80),
+    ('dec3', 128, 128, 64, 1024, 300),
+]
+
+
+@pytest.mark.parametrize('name,M0,M1,N,Ls,B', SCALE_DECONV)
+def test_deconv_layers_at_batch_scale(name, M0, M1, N, Ls, B):
+    """Decoder layers exactly as the generator runs them: two-pointer input (previous layer |
+    alpha-scaled skip) with PReLU / alpha on load, data gradient split at the segment
+    boundary (dec0: the z half is not computed), weight gradient with a transformed lo."""
+    ops = _ops()
+    S, K = 4, 31
+    M = M0 + M1
+    x0, x1 = rnd(B, M0, Ls, seed=21), rnd(B, M1, Ls, seed=22)
+    scale = torch.cat((torch.ones(M0), rnd(M1, seed=23)))           # alpha on the skip half
+    slope = torch.cat((rnd(M0, seed=24).abs() * 0.3, torch.ones(M1)))
+    w = rnd(M, N, K, seed=25, scale=0.05)
+    b = rnd(N, seed=26)
+    xin = xform_ref(torch.cat((x0, x1), 1), scale, None, slope).requires_grad_(True)
+    wd = w.double().requires_grad_(True)
+    pad = ops.deconv_pad(K, S)
+    ref = F.conv_transpose1d(xin, wd, b.double(), stride=S, padding=pad)[:, :, :S * Ls]
+    src = ops.Src(x0.to(DEV), x1.to(DEV), scale=scale.to(DEV), slope=slope.to(DEV))
+    wg = w.to(DEV)
+    y = ops.deconv1d_fwd(src, wg, b.to(DEV), S)
+    info_t = ops.last_corr_launch()
+    assert max_rel(y, ref) < TOL
+    assert torch.equal(y, ops.deconv1d_fwd(src, wg, b.to(DEV), S))
+    dy = rnd(*ref.shape, seed=27)
+    ref.backward(dy.double())
+    dyg = dy.to(DEV)
+    need0 = name != 'dec0'
+    dx0, dx1 = ops.deconv1d_dgrad(dyg, wg, S, M0, need0=need0)
+    info_f = ops.last_corr_launch()
+    assert max_rel(dx1, xin.grad[:, M0:]) < TOL
+    if need0:
+        assert max_rel(dx0, xin.grad[:, :M0]) < TOL
+    else:
+        assert dx0 is None
+    for det in (False, True):
+        ops.set_deterministic(det)
+        try:
+            dw = torch.zeros_like(wg)
+            ops.wgrad(src, ops.Src(dyg), dw, K, S, pad, ops.PAD_ZERO)
+            assert max_rel(dw, wd.grad) < TOL, det
+        finally:
+            ops.set_deterministic(False)
+    assert info_t['kernel'] == 2 and info_f['kernel'] == 2
+
+
+def l2_rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-300)).item()
+
+
+@pytest.mark.parametrize('gated', [False, True])
+def test_discriminator_batchnorm_at_batch_300(gated):
+    """One D forward + backward with BatchNorm statistics over 300 x L samples per channel
+    against the CPU oracle (segan_oracle.discriminator_forward, fp32): logits, every parameter
+    gradient, and the running statistics.
+
+    gated=False: PReLU slopes 1 (identity) — the BatchNorm / conv / dense chain alone, strict.
+    gated=True: slopes 0.05..0.3.  A PReLU gate is discontinuous in its derivative: of the
+    ~10^7 pre-activations a handful sit within fp32 roundoff of zero, the CPU and the GPU take
+    different sides there, and each such flip moves the gradients downstream by a discrete
+    amount (measured vs an fp64 oracle, tests/diag/diag_d300.py: GPU 2e-3, fp32 CPU oracle
+    2e-4..6e-4 in relative L2; the forward agrees to 4e-6).  Bound: 6e-3 relative L2."""
+    from segan_pytorch_amd.models import Discriminator
+    from segan_pytorch_amd import losses
+    B = 300
+    torch.manual_seed(5)
+    D = Discriminator(2, [64, 128, 256, 512, 1024], 31, poolings=[4] * 5, pool_type='none',
+                      pool_slen=16, norm_type='bnorm', phase_shift=5)
+    for n_, p in D.named_parameters():       # leave the symmetric initial point
+        if n_.endswith('act.weight'):
+            if gated:
+                p.data.uniform_(0.05, 0.3)
+            else:
+                p.data.fill_(1.0)
+        elif n_.endswith('conv.weight'):
+            p.data.normal_(0.0, 0.02)
+    sd0 = {k: v.detach().clone() for k, v in D.state_dict().items()}
+    D = D.to(DEV).train()
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(B, 2, 16384, generator=g) * 2 - 1
+    rolls = [2, -5, 1, -1, 4]
+    D.draw_rolls = lambda: list(rolls)
+    y, _ = D(x[:, :1].contiguous().to(DEV), x[:, 1:].contiguous().to(DEV))
+    loss = losses.MSELoss()(y.view(-1), 1.0)
+    loss.backward()
+    torch.cuda.synchronize()
+    sd = {k: (v.clone().requires_grad_(True) if torch.is_floating_point(v) and
+              k.split('.')[-1] not in O._BUFFERS else v.clone()) for k, v in sd0.items()}
+    yo = O.discriminator_forward(sd, x, rolls, [4] * 5)
+    lo = F.mse_loss(yo.view(-1), torch.ones(B))
+    keys = [k for k, v in sd.items() if torch.is_tensor(v) and v.requires_grad]
+    grads = torch.autograd.grad(lo, [sd[k] for k in keys])
+    assert max_rel(y, yo) < 5e-5
+    assert max_rel(loss, lo) < 2e-5
+    dn = dict(D.named_parameters())
+    for k, gr in zip(keys, grads):
+        if k.endswith('conv.bias'):
+            continue            # zero gradient in front of BatchNorm: roundoff on both sides
+        if gr.abs().max().item() < 1e-7:
+            # mathematically zero (identity activations: a BatchNorm bias in front of another
+            # conv + BatchNorm is cancelled like a conv bias): roundoff on both sides
+            assert dn[k].grad.abs().max().item() < 1e-6, k
+            continue
+        assert l2_rel(dn[k].grad, gr) < (6e-3 if gated else 2e-4), k
+    got = D.state_dict()
+    for k in sd0:
+        if k.endswith('running_mean') or k.endswith('running_var'):
+            assert max_rel(got[k], sd[k]) < 2e-5, k
