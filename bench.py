@@ -7,9 +7,10 @@ One "step" = one full LSGAN step of the reference's ``SEGAN.train`` inner loop
 (segan/models/model.py:292-321: G fwd, D fwd real+fake, D bwd, D step, D fwd on fake,
 G bwd + L1, G step) on a batch of 300 synthetic 16384-sample noisy/clean pairs PER GPU
 (BASELINE.json configs[1]: SEGAN+ default net, k31, batch 300, fp32), inputs resident
-in HBM before the timed region, no logging syncs inside it.  With N > 1 it is launched
-by torch.distributed.run (one rank per GPU); the batch is sharded 300/GPU (weak
-scaling) and gradients are averaged with one RCCL all-reduce per network per step.
+in HBM before the timed region, no logging syncs inside it.  With N > 1 there is one rank per
+GPU: when the driver has not launched the ranks itself (WORLD_SIZE unset) the script re-executes
+under ``python -m torch.distributed.run --nproc-per-node N``; the batch is sharded 300/GPU
+(weak scaling) and gradients are averaged by RCCL all-reduces on the flat gradient arenas.
 
 Prints ONE JSON line (rank 0):
   value       whole-job 16384-sample chunks/s
@@ -18,7 +19,10 @@ Prints ONE JSON line (rank 0):
               measured live with HIP events on the launch stream, vs the 157.3 TF/s
               fp32-MFMA peak (guides/MI355X_MICROARCH.md)
   cpu_baseline  the CPU oracle (oracle/segan_oracle.py, a port of the reference's path)
-              timed on this host's cores on a bounded sample, rank 0 at N=1 only
+              timed on this host's cores at the metric's batch (300), rank 0 at N=1 only
+  parity      BASELINE's second metric: the HIP step against that same oracle step (same
+              weights, inputs, z and phase shifts): generator-output MSE / max-abs, losses and
+              gradients
 """
 import argparse
 import json
@@ -123,51 +127,110 @@ class KernelTimer(object):
         return out
 
 
-def cpu_baseline(B=48):
-    """Time the CPU oracle's GAN step (oracle/segan_oracle.py: the reference's path restated
-    on torch CPU ops) on this host's cores: one warm-up step + one timed step at batch B with
-    oneDNN off (the numerically trustworthy setting) and the same again with
-    oneDNN on (what a stock reference run would use); the FASTER of the two is reported."""
+def cpu_baseline(B=300, steps=2, dev=None):
+    """Time the CPU oracle's GAN step (oracle/segan_oracle.py: the reference's path restated on
+    torch CPU ops; /root/reference does not exist on the GPU box, hence kind = 'port') on this
+    host's cores at the metric's batch size: per oneDNN setting one warm-up step at batch 8
+    (thread pools, allocator) and `steps` timed steps at batch B; the FASTER setting is reported
+    (oneDNN off is the numerically trustworthy one).
+
+    The first timed oneDNN-off step doubles as the parity reference: the HIP model takes the
+    same step from the same weights / inputs / z / phase shifts (deterministic kernels; the
+    generator phase runs through the oracle's post-step discriminator, see
+    tests/test_gpu_model.py) and the differences are returned as `parity`."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import segan_oracle as O
+    from segan_pytorch_amd import losses, ops
     from segan_pytorch_amd.datasets import synthetic_pairs
-    from segan_pytorch_amd.models import SEGAN, WSEGAN
+    from segan_pytorch_amd.models import SEGAN
     opts = default_opts()
     random.seed(111); np.random.seed(111); torch.manual_seed(111)
     m = SEGAN(SimpleNamespace(**opts))
-    gsd0 = {k: v.detach() for k, v in m.G.state_dict().items()}
-    dsd0 = {k: v.detach() for k, v in m.D.state_dict().items()}
+    gsd0 = {k: v.detach().clone() for k, v in m.G.state_dict().items()}
+    dsd0 = {k: v.detach().clone() for k, v in m.D.state_dict().items()}
     clean, noisy = synthetic_pairs(B, 16384, 0)
     clean, noisy = clean.unsqueeze(1), noisy.unsqueeze(1)
-    z = torch.randn(B, 1024, 16)
-    rolls = [[1, -2, 3, -4, 5]] * 3
+    z = torch.randn(B, 1024, 16, generator=torch.Generator().manual_seed(0))
+    rolls = [[1, -2, 3, -4, 5], [-3, 2, -1, 5, 4], [2, -5, 1, -1, -4]]
     st = opts['genc_poolings']
-    results = {}
+    results, ref = {}, None
     for mode in (False, True):
         torch.backends.mkldnn.enabled = mode
+        O.gan_step(gsd0, dsd0, clean[:8], noisy[:8], z[:8], rolls, st, 100.0, 5e-5)   # warm-up
         gsd, dsd, g_sq, d_sq = gsd0, dsd0, None, None
-        per = None
-        for i in range(2):
+        times = []
+        for i in range(steps):
             t0 = time.perf_counter()
-            res = O.gan_step(gsd, dsd, clean, noisy, z, rolls, st, 100.0, 5e-5, g_sq=g_sq,
-                             d_sq=d_sq)
-            per = time.perf_counter() - t0
+            res = O.gan_step(gsd, dsd, clean, noisy, z, rolls, st, 100.0, 5e-5, g_sq=g_sq, d_sq=d_sq)
+            times.append(time.perf_counter() - t0)
+            if not mode and i == 0:
+                ref = res
             gsd, dsd, g_sq, d_sq = res['G'], res['D'], res['g_sq'], res['d_sq']
-        results['onednn_on' if mode else 'onednn_off'] = per
+        results['onednn_on' if mode else 'onednn_off'] = times
     torch.backends.mkldnn.enabled = False
-    best = min(results, key=results.get)
-    per = results[best]
-    return dict(value=B / per, unit='chunks/s', cores=torch.get_num_threads(), kind='port',
-                sample='oracle GAN step (SEGAN+ default net, fp32) at batch {}: 1 warm-up + 1 timed '
-                       'step per setting; {:.2f} s/step oneDNN off, {:.2f} s/step oneDNN on; '
-                       'reported = {}'.format(B, results['onednn_off'], results['onednn_on'], best))
+    mean = {k: sum(v) / len(v) for k, v in results.items()}
+    best = min(mean, key=mean.get)
+    out = dict(value=B / mean[best], unit='chunks/s', cores=torch.get_num_threads(),
+               nproc=os.cpu_count(), kind='port',
+               sample='oracle GAN step (SEGAN+ default net, fp32) at batch {}: warm-up at batch 8, then '
+                      '{} timed steps per oneDNN setting; s/step oneDNN off {}, on {}; reported = {} '
+                      '(mean)'.format(B, steps, ['%.2f' % t for t in results['onednn_off']],
+                                      ['%.2f' % t for t in results['onednn_on']], best))
+    parity = None
+    if dev is not None and ref is not None:
+        old = ops.get_deterministic()
+        ops.set_deterministic(True)
+        try:
+            mm = SEGAN(SimpleNamespace(**opts))
+            mm.G.load_state_dict(gsd0)
+            mm.D.load_state_dict(dsd0)
+            mm = mm.to(dev)
+            Gopt, Dopt = mm.build_optimizers(SimpleNamespace(**opts))
+            mm.G.train(); mm.D.train()
+            it = iter(rolls)
+            mm.D.draw_rolls = lambda: list(next(it))
+            crit = losses.MSELoss()
+            cg, ng, zg = clean.to(dev), noisy.to(dev), z.to(dev)
+            Genh, d_real, d_fake = mm.d_phase(cg, ng, Dopt, crit, z=zg)
+
+            def rel(a, b):
+                a, b = a.detach().double().cpu(), b.detach().double().cpu()
+                return ((a - b).norm() / b.norm().clamp_min(1e-300)).item()
+            y = Genh.detach().cpu().double()
+            yr = ref['Genh'].double()
+            dn = dict(mm.D.named_parameters())
+            d_grad = max(rel(dn[k].grad, g) for k, g in ref['d_grads'].items()
+                         if not k.endswith('conv.bias'))
+            mm.D.load_state_dict({k: ref['D'].get(k, v) for k, v in dsd0.items()})
+            ops.bump_weights_epoch()
+            g_adv, g_l1 = mm.g_phase(Genh, cg, ng, Gopt, crit, 100.0)
+            torch.cuda.synchronize()
+            gn = dict(mm.G.named_parameters())
+            g_grad = max(rel(gn[k].grad, g) for k, g in ref['g_grads'].items())
+            parity = {
+                'batch': B, 'g_mse': ((y - yr) ** 2).mean().item(),
+                'g_max_abs': (y - yr).abs().max().item(),
+                'd_real_loss_rel': abs(float(d_real) - float(ref['d_real_loss'])) / abs(float(ref['d_real_loss'])),
+                'd_fake_loss_rel': abs(float(d_fake) - float(ref['d_fake_loss'])) / abs(float(ref['d_fake_loss'])),
+                'g_adv_loss_rel': abs(float(g_adv) - float(ref['g_adv_loss'])) / abs(float(ref['g_adv_loss'])),
+                'g_l1_loss_rel': abs(float(g_l1) - float(ref['g_l1_loss'])) / abs(float(ref['g_l1_loss'])),
+                'd_grad_rel_l2_worst_tensor': d_grad, 'g_grad_rel_l2_worst_tensor': g_grad,
+                'note': 'HIP step (deterministic mode) vs the CPU oracle step timed above, same weights / '
+                        'inputs / z / phase shifts; generator phase through the oracle\'s post-step D; '
+                        'gradient figures are relative L2 per tensor (ReLU-gate flips at fp32 roundoff '
+                        'bound them, tests/test_gpu_kernels.py::test_discriminator_batchnorm_at_batch_300)',
+            }
+            del mm, Gopt, Dopt
+        finally:
+            ops.set_deterministic(old)
+    return out, parity
 
 
 def pmc_traffic(kernel_prefix):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_pmc_hbm_traffic.json: FETCH_SIZE and WRITE_SIZE in separate passes over this
+    (profiles/r02_pmc_hbm_traffic.json: FETCH_SIZE and WRITE_SIZE in separate passes over this
     same command; FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md)."""
-    path = os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_traffic.json')
+    path = os.path.join(ROOT, 'profiles', 'r02_pmc_hbm_traffic.json')
     if not os.path.exists(path):
         return None
     try:
@@ -192,6 +255,11 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=300, help='chunks per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-batch', type=int, default=300, help='batch of the timed CPU oracle steps')
+    ap.add_argument('--cpu-steps', type=int, default=2, help='timed CPU oracle steps per oneDNN setting')
+    ap.add_argument('--device-z', action='store_true',
+                    help='draw z on the GPU (train.py --device_z) instead of on the host like the '
+                         'reference (generator.py:197); the default times what train.py runs')
     ap.add_argument('--no-kernel-timer', action='store_true')
     ap.add_argument('--no-modes', action='store_true', help='skip the bf16x3 / bf16 side measurements')
     ap.add_argument('--wsegan', action='store_true',
@@ -203,6 +271,20 @@ def main():
                          'bf16 = BASELINE config 5)')
     args = ap.parse_args()
 
+    # one rank per GPU: when nobody launched the ranks for us, do it ourselves
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        if args.gpus > torch.cuda.device_count():
+            raise SystemExit('--gpus {} but only {} GPU(s) visible'.format(args.gpus, torch.cuda.device_count()))
+        import socket
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+               '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+               '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        os.execvp(cmd[0], cmd)
+
     from segan_pytorch_amd import distributed as sdist
     from segan_pytorch_amd import losses
     from segan_pytorch_amd.datasets import synthetic_pairs
@@ -210,11 +292,25 @@ def main():
 
     from segan_pytorch_amd import ops as _ops
     _ops.set_precision(args.precision)
+    if args.gpus > torch.cuda.device_count():
+        raise SystemExit('--gpus {} but only {} GPU(s) visible'.format(args.gpus, torch.cuda.device_count()))
     rank, world, local = sdist.init_from_env()
-    if world != max(1, args.gpus) and world > 1:
+    if world != max(1, args.gpus):
         raise SystemExit('--gpus {} but WORLD_SIZE {}'.format(args.gpus, world))
     dev = torch.device('cuda', local if world > 1 else 0)
     torch.cuda.set_device(dev)
+    ranks_seen, devices_seen, backend = [0], [dev.index], None
+    if world > 1:
+        import torch.distributed as dist
+        backend = dist.get_backend()
+        if backend != 'nccl' and 'SEGAN_DIST_BACKEND' not in os.environ:
+            raise SystemExit('expected the RCCL (nccl) backend, got {}'.format(backend))
+        mine = torch.tensor([rank, dev.index], device=dev, dtype=torch.int64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        ranks_seen = sorted(int(t[0]) for t in allr)
+        devices_seen = [int(t[1]) for t in allr]
+        assert ranks_seen == list(range(world)), ranks_seen
 
     opts = default_opts()
     random.seed(111); np.random.seed(111); torch.manual_seed(111)
@@ -235,15 +331,17 @@ def main():
     clean, noisy = synthetic_pairs(B, 16384, seed=rank, device=dev)
     clean, noisy = clean.unsqueeze(1).contiguous(), noisy.unsqueeze(1).contiguous()
     random.seed(1000 + rank)
-    zgen = torch.Generator(device=dev).manual_seed(rank)
+    torch.manual_seed(2000 + rank)
+    if args.device_z:
+        model.G.z_generator = torch.Generator(device=dev).manual_seed(rank)
 
     names = ['utt_additive_{}'.format(i) if i % 2 == 0 else 'utt_{}'.format(i) for i in range(B)]
 
     def one_step():
-        z = torch.randn(B, 1024, 16, device=dev, generator=zgen)
+        # z=None: Generator.forward draws it, exactly as inside train.py's loop
         if args.wsegan:
-            return model.wgan_step(names, clean, noisy, Gopt, Dopt, 100.0, z=z)
-        return model.gan_step(clean, noisy, Gopt, Dopt, criterion, 100.0, z=z)
+            return model.wgan_step(names, clean, noisy, Gopt, Dopt, 100.0, z=None)
+        return model.gan_step(clean, noisy, Gopt, Dopt, criterion, 100.0, z=None)
 
     def barrier():
         if world > 1:
@@ -305,7 +403,8 @@ def main():
         ms = 1e3 * dt / args.steps
         line = {
             'metric': '16384-sample waveform chunks/sec (GAN step)', 'value': value,
-            'unit': 'chunks/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'unit': 'chunks/s', 'n_gpus': world, 'ranks_seen': ranks_seen, 'devices': devices_seen,
+            'backend': backend, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': {'fp32': 'f32', 'bf16x3': 'f32 operands as 3 bf16 planes (6 products), f32 accumulate',
                       'bf16': 'bf16 operands, f32 accumulate'}[args.precision], 'data': 'synthetic',
@@ -315,7 +414,8 @@ def main():
                                     'SEGAN+ default G+D (5+5 layers, k31, stride 4, z 1024x16), '
                                     'batch {} x 16384-sample chunks per GPU, full GAN step '
                                     '(model.py:292-321), RMSprop, fp32').format(B),
-                       'global_batch': B * world, 'parallelism': 'dp{}'.format(world)},
+                       'global_batch': B * world, 'parallelism': 'dp{}'.format(world),
+                       'z': 'device generator' if args.device_z else 'host randn + H2D per step (as train.py)'},
             'losses_finite': finite,
             'precision': args.precision,
             'step_tflops': (44.33 if args.wsegan else GFLOP_PER_CHUNK) * value / 1e3,
@@ -327,17 +427,17 @@ def main():
             c = s.get('corr')
             if c:
                 line['roofline'] = {
-                    'bound': 'mfma', 'kernel': 'corr_kernel (conv/deconv forward + data gradient)',
+                    'bound': 'mfma', 'kernel': 'corr2_kernel (conv/deconv forward + data gradient)',
                     'achieved': c['tflops'], 'peak': PEAK_F32_MFMA_TF, 'unit': 'TFLOP/s',
-                    'frac': c['tflops'] / PEAK_F32_MFMA_TF, 'traffic': pmc_traffic('corr_kernel'),
+                    'frac': c['tflops'] / PEAK_F32_MFMA_TF, 'traffic': pmc_traffic('corr'),
                     'traffic_unit': 'HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, '
-                                    'profiles/r01_pmc_hbm_traffic.json)',
+                                    'profiles/r02_pmc_hbm_traffic.json)',
                     'avg_launch_us': c['avg_us'], 'launches': c['launches'],
                     'gflop_per_launch': c['flops_per_launch'] / 1e9,
                     'share_of_step_time': c['total_ms'] / (1e3 * dt)}
             if 'wgrad' in s:
                 w = s['wgrad']
-                line['roofline_wgrad'] = {'bound': 'mfma', 'kernel': 'wgrad_kernel',
+                line['roofline_wgrad'] = {'bound': 'mfma', 'kernel': 'wgrad2_kernel',
                                           'achieved': w['tflops'], 'peak': PEAK_F32_MFMA_TF,
                                           'unit': 'TFLOP/s', 'frac': w['tflops'] / PEAK_F32_MFMA_TF,
                                           'avg_launch_us': w['avg_us'], 'launches': w['launches'],
@@ -350,8 +450,12 @@ def main():
             line['other_precisions'] = modes
         if world == 1 and not args.no_cpu_baseline:
             try:
-                line['cpu_baseline'] = cpu_baseline()
+                del model, Gopt, Dopt
+                torch.cuda.empty_cache()
+                line['cpu_baseline'], parity = cpu_baseline(args.cpu_batch, args.cpu_steps, dev)
                 line['speedup_vs_cpu_baseline'] = value / line['cpu_baseline']['value']
+                if parity is not None:
+                    line['parity'] = parity
             except Exception as e:  # the bench line must still be printed
                 line['cpu_baseline'] = {'error': repr(e)}
         print(json.dumps(line))

@@ -129,6 +129,41 @@ class Generator(Model):
         for p in poolings:
             self._total_pool *= p
 
+    def _host_z(self, shape, device):
+        """z drawn on the host from torch's global CPU generator exactly like the reference
+        (generator.py:197-199: same RNG stream), moved to the GPU without stalling the launch
+        queue: a pageable-memory ``.to(device)`` makes the host wait for everything already
+        enqueued on the stream, once per step.  Two pinned staging buffers and two device
+        buffers alternate; the copy runs on its own stream as soon as the step before the
+        previous one (the last reader of that device buffer) has finished."""
+        st = self.__dict__.get('_zstage')
+        if st is None or st['shape'] != shape or st['device'] != device:
+            st = {'shape': shape, 'device': device, 'i': 0, 'stream': torch.cuda.Stream(device=device),
+                  'pin': [torch.empty(shape, pin_memory=True) for _ in range(2)],
+                  'dev': [torch.empty(shape, device=device) for _ in range(2)],
+                  'copied': [None, None], 'main': None}
+            self.__dict__['_zstage'] = st
+        i = st['i']
+        st['i'] ^= 1
+        if st['copied'][i] is not None:
+            st['copied'][i].synchronize()          # the pinned buffer is free again (long done)
+        torch.randn(shape, out=st['pin'][i])
+        main = torch.cuda.current_stream(device)
+        if st['main'] is not None:
+            st['stream'].wait_event(st['main'])    # readers of dev[i] (two calls ago) are done
+        with torch.cuda.stream(st['stream']):
+            st['dev'][i].copy_(st['pin'][i], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(st['stream'])
+        st['copied'][i] = ev
+        main.wait_event(ev)
+        me = torch.cuda.Event()
+        me.record(main)
+        st['main'] = me
+        z = st['dev'][i]
+        z._segan_staged = True
+        return z
+
     def _fn_params(self):
         return [p for p in nn.Module.parameters(self)]
 
@@ -140,14 +175,19 @@ class Generator(Model):
                 x.shape[2], self._total_pool))
         if not self.no_z:
             if z is None:
-                # drawn on the host like the reference (generator.py:197-199)
-                z = torch.randn(x.size(0), self.z_dim, x.shape[2] // self._total_pool)
-                if x.is_cuda:
-                    z = z.to(x.device)
+                zshape = (x.size(0), self.z_dim, x.shape[2] // self._total_pool)
+                if getattr(self, 'z_generator', None) is not None and x.is_cuda:
+                    # opt-in (train.py --device_z): drawn on the GPU from a per-rank generator;
+                    # no host randn + H2D copy per step, but not the reference's RNG stream
+                    z = torch.randn(zshape, device=x.device, generator=self.z_generator)
+                elif x.is_cuda:
+                    z = self._host_z(zshape, x.device)
+                else:
+                    z = torch.randn(*zshape)
             if z.dim() != x.dim():
                 raise ValueError('len(z.size) {} != len(hi.size) {}'.format(z.dim(), x.dim()))
             if not hasattr(self, 'z'):
-                self.z = z
+                self.z = z.clone() if getattr(z, '_segan_staged', False) else z
         else:
             z = None
         out = Fn.GeneratorFn.apply(self, bool(ret_hid), x, z, *self._fn_params())
