@@ -4,10 +4,14 @@ yet"); this is the new data-parallel path SURVEY.md section 8(e) specifies:
 
 * every rank holds a full replica of G and D and its own optimizer state;
 * the batch is sharded across ranks (rank r trains on its own 1/world slice);
-* ONE all-reduce per network per step on the flat gradient arena of its optimizer
-  (D: 25.8 M floats between the D backward passes and ``Dopt.step``; G: 64.8 M floats
-  between the G backward and ``Gopt.step``), then a 1/world scale, so every rank
-  applies the gradient of the mean loss over the global batch;
+* gradients are averaged on the flat gradient arena of each optimizer (D: 25.8 M floats
+  between the D backward passes and ``Dopt.step``; G: 64.8 M floats between the G backward
+  and ``Gopt.step``) in BUCKETS of consecutive parameters: the backward pass reports every
+  layer whose gradients are final (``grad_ready``) and a bucket's all-reduce is issued — async,
+  on RCCL's own stream — as soon as its last parameter is, so the collective of the decoder /
+  the deep discriminator layers (the big weights, finished first) runs under the rest of the
+  backward pass; ``allreduce_grads`` waits for the buckets and applies the 1/world scale, so
+  every rank applies the gradient of the mean loss over the global batch;
 * BatchNorm statistics stay local to a rank (standard DDP semantics: each replica is
   the reference at its per-GPU batch size).
 
@@ -75,12 +79,127 @@ def allreduce_mean_(flat):
     return flat
 
 
-def allreduce_grads(optimizer):
-    """Average the gradients of every parameter the optimizer owns across ranks."""
+_bucket_bytes = int(float(os.environ.get('SEGAN_DP_BUCKET_MB', '32')) * (1 << 20))
+
+
+def set_bucket_bytes(n):
+    """Target size of a gradient bucket (default 32 MiB, SEGAN_DP_BUCKET_MB); a parameter is
+    never split, so the big weights form buckets of their own."""
+    global _bucket_bytes
+    _bucket_bytes = int(n)
+    _reducers.clear()
+
+
+class GradReducer(object):
+    """Bucketed gradient averaging of ONE optimizer's flat arena, overlapped with the backward
+    pass that produces the gradients (module docstring)."""
+
+    def __init__(self, optimizer, bucket_bytes):
+        self.opt = optimizer
+        self.buckets = []                 # (first float, end float)
+        self.members = []                 # number of parameters per bucket
+        self.bucket_of = {}
+        start, n, nb = None, 0, 0
+        params, offs = optimizer._params, optimizer._offsets
+        for i, p in enumerate(params):
+            if start is None:
+                start, n, nb = offs[i], 0, 0
+            self.bucket_of[id(p)] = len(self.buckets)
+            n += 1
+            nb += p.numel() * 4
+            end = offs[i + 1] if i + 1 < len(params) else optimizer._total
+            if nb >= bucket_bytes or i + 1 == len(params):
+                self.buckets.append((start, end))
+                self.members.append(n)
+                start = None
+        self.armed = False
+        self.pending, self.sent, self.works = [], [], []
+
+    def arm(self):
+        """Call before the LAST backward pass that adds to these gradients."""
+        self.opt._resync()
+        self.pending = list(self.members)
+        self.sent = [False] * len(self.buckets)
+        self.seen = set()
+        self.works = []
+        self.armed = True
+
+    def _send(self, b):
+        lo, hi = self.buckets[b]
+        self.works.append(dist.all_reduce(self.opt.flat_grad[lo:hi], op=dist.ReduceOp.SUM,
+                                          async_op=True))
+        self.sent[b] = True
+
+    def ready(self, p):
+        b = self.bucket_of.get(id(p))
+        if b is None or not self.armed or self.sent[b] or id(p) in self.seen:
+            return
+        self.seen.add(id(p))
+        self.pending[b] -= 1
+        if self.pending[b] == 0:
+            self._send(b)
+
+    def finish(self):
+        """All buckets reduced (those never reported ready are sent now), then the mean."""
+        if not self.armed:
+            self.arm()
+        for b in range(len(self.buckets)):
+            if not self.sent[b]:
+                self._send(b)
+        for w in self.works:
+            w.wait()
+        self.armed = False
+        self.works = []
+        flat = self.opt.flat_grad
+        if flat.is_cuda:
+            ops.scale_(flat, 1.0 / world_size())
+        else:
+            flat.mul_(1.0 / world_size())
+
+
+_reducers = {}
+_active = None
+
+
+def _reducer(optimizer):
+    r = _reducers.get(id(optimizer))
+    if r is None or r.opt is not optimizer:
+        r = GradReducer(optimizer, _bucket_bytes)
+        _reducers[id(optimizer)] = r
+    return r
+
+
+def arm(optimizer):
+    """Announce that the next backward pass is the last one into `optimizer`'s gradients before
+    its step: from here on ``grad_ready`` starts the all-reduce of every bucket that completes."""
+    global _active
     if world_size() <= 1:
         return
-    optimizer._resync()
-    allreduce_mean_(optimizer.flat_grad)
+    _active = _reducer(optimizer)
+    _active.arm()
+
+
+def grad_ready(*params):
+    """Called by the backward passes (functional.py) once the kernels that write the gradients
+    of `params` are enqueued and nothing later adds to them."""
+    if _active is None:
+        return
+    for p in params:
+        if p is not None:
+            _active.ready(p)
+
+
+def allreduce_grads(optimizer):
+    """Average the gradients of every parameter the optimizer owns across ranks (waits for the
+    buckets already in flight, sends the rest)."""
+    global _active
+    if world_size() <= 1:
+        return
+    r = _reducer(optimizer)
+    if _active is not None and _active is not r:
+        _active.armed = False
+    r.finish()
+    _active = None
 
 
 def broadcast_params(module, src=0):

@@ -19,39 +19,6 @@ from . import ops
 from .ops import ACT_NONE, ACT_TANH, PAD_REFLECT, PAD_ZERO, Src
 
 
-class _SideStream(object):
-    """Runs the weight-gradient kernels of a backward pass on a second HIP stream so that
-    they overlap the data-gradient chain (they only share the read-only `da`): the tail of
-    one launch (equal-size workgroups leave CUs idle at the end) is filled by the other.
-    Every tensor handed to the side stream is kept alive until `join()`.
-    Enabled with SEGAN_WGRAD_STREAM=1."""
-    _stream = None
-
-    def __init__(self):
-        import os
-        self.on = os.environ.get('SEGAN_WGRAD_STREAM', '0') == '1' and torch.cuda.is_available()
-        self.keep = []
-        if self.on and _SideStream._stream is None:
-            _SideStream._stream = torch.cuda.Stream()
-        self.used = False
-
-    def run(self, fn, *tensors):
-        if not self.on:
-            fn()
-            return
-        side = _SideStream._stream
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            fn()
-        self.keep.extend(tensors)
-        self.used = True
-
-    def join(self):
-        if self.on and self.used:
-            torch.cuda.current_stream().wait_stream(_SideStream._stream)
-        self.keep = []
-
-
 def grad_buf(p):
     """The tensor the kernels accumulate this parameter's gradient into."""
     if p.grad is None:
@@ -83,6 +50,22 @@ def _act_bwd_bn(a, dh, slope, bn, dslope, dgamma, dbeta, dbias):
         return sdist.act_bwd_bn_sync(a, dh, slope, bn, dslope, dgamma, dbeta, dbias)
     return ops.act_bwd(a, dh, slope=slope, bn=bn, dslope=dslope, dgamma=dgamma, dbeta=dbeta,
                        dbias=dbias)
+
+
+def _ready(*mods_or_params):
+    """Report the parameters of finished layers to the data-parallel gradient reducer."""
+    from . import distributed as sdist
+    if sdist._active is None:
+        return
+    ps = []
+    for m in mods_or_params:
+        if m is None:
+            continue
+        if isinstance(m, torch.nn.Module):
+            ps.extend(torch.nn.Module.parameters(m))
+        else:
+            ps.append(m)
+    sdist.grad_ready(*ps)
 
 
 def _ones(n, ref):
@@ -207,7 +190,10 @@ class GeneratorFn(torch.autograd.Function):
         ctx.gen = gen
         ctx.set_materialize_grads(False)
         ctx.x_needs = x.requires_grad
-        ctx.state = (x, z, a_enc, src_enc, a_dec, src_dec, W)
+        # the output goes through save_for_backward (no ctx -> y -> grad_fn -> ctx cycle that a
+        # never-backpropagated grad-mode forward would leak); the rest are plain intermediates
+        ctx.save_for_backward(y)
+        ctx.state = (x, z, a_enc, src_enc, a_dec[:-1], src_dec, W)
         hid = None
         if want_hid:
             hid = {}
@@ -227,13 +213,14 @@ class GeneratorFn(torch.autograd.Function):
     def backward(ctx, dy, *unused):
         gen = ctx.gen
         x, z, a_enc, src_enc, a_dec, src_dec, W = ctx.state
+        a_dec = list(a_dec) + [ctx.saved_tensors[0]]
         enc, dec = list(gen.enc_blocks), list(gen.dec_blocks)
         n_enc, n_dec = len(enc), len(dec)
         if dy is None:
+            ctx.state = None
             return (None,) * len(ctx.needs_input_grad)
         dy = dy.contiguous()
         dh = dy
-        side = _SideStream()
         dskip = {}          # enc index -> gradient w.r.t. alpha * a_enc
         dh_last_enc = None  # gradient w.r.t. h of the last encoder layer
         # ---- decoder, last to first ----
@@ -250,8 +237,9 @@ class GeneratorFn(torch.autograd.Function):
             src = src_dec[li]
             if W.needs_grad(blk.deconv):
                 gw = W.grad_target(blk.deconv)
-                side.run(lambda: (ops.wgrad(src, Src(da), gw, K, S, ops.deconv_pad(K, S), PAD_ZERO),
-                                  W.finish(blk.deconv, gw)), da)
+                ops.wgrad(src, Src(da), gw, K, S, ops.deconv_pad(K, S), PAD_ZERO)
+                W.finish(blk.deconv, gw)
+            _ready(blk)
             if li == 0:
                 if gen.no_z:
                     _d0, dh_last_enc = ops.deconv1d_dgrad(da, w, S, 0, pack=blk._pack)
@@ -284,13 +272,13 @@ class GeneratorFn(torch.autograd.Function):
             padL = ops.conv_pad(K, S)[0]
             if W.needs_grad(blk.conv):
                 gw = W.grad_target(blk.conv)
-                side.run(lambda: (ops.wgrad(Src(da), src_enc[l], gw, K, S, padL, PAD_REFLECT),
-                                  W.finish(blk.conv, gw)), da)
+                ops.wgrad(Src(da), src_enc[l], gw, K, S, padL, PAD_REFLECT)
+                W.finish(blk.conv, gw)
+            _ready(blk, alpha_p)
             if l > 0:
                 dh = ops.conv1d_dgrad(da, w, src_enc[l].L, S, pack=blk._pack)
             elif ctx.x_needs:
                 dx = ops.conv1d_dgrad(da, w, src_enc[l].L, S, pack=blk._pack)
-        side.join()
         ctx.state = None
         return (None, None, dx, None) + (None,) * (len(ctx.needs_input_grad) - 4)
 
@@ -360,7 +348,6 @@ class DiscriminatorFn(torch.autograd.Function):
         blocks = list(disc.enc_blocks)
         fc = disc.fc
         dout = dout.contiguous()
-        any_param = any(p.requires_grad for p in disc.parameters())
         # ---- dense head ----
         def lin_wgrad(mod, dy, xin):
             if W.needs_grad(mod):
@@ -384,9 +371,9 @@ class DiscriminatorFn(torch.autograd.Function):
         dy1 = prelu_bwd(y1, fc[0], fc[1], da1)
         lin_wgrad(fc[0], dy1, hf)
         dh = ops.linear_dgrad(dy1, W.get(fc[0])).view(cs[-1].shape)
+        _ready(fc)
         # ---- conv stack ----
         dx = None
-        side = _SideStream()
         for l in range(len(blocks) - 1, -1, -1):
             blk = blocks[l]
             w = W.get(blk.conv)
@@ -403,16 +390,15 @@ class DiscriminatorFn(torch.autograd.Function):
                                  dbias=_gb(blk.conv.bias))
             padL = ops.conv_pad(K, S)[0]
             if W.needs_grad(blk.conv):
-                gw, rl = W.grad_target(blk.conv), ctx.rolls[l]
-                side.run(lambda: (ops.wgrad(Src(dc), srcs[l], gw, K, S, padL, PAD_REFLECT, roll=rl),
-                                  W.finish(blk.conv, gw)), dc)
+                gw = W.grad_target(blk.conv)
+                ops.wgrad(Src(dc), srcs[l], gw, K, S, padL, PAD_REFLECT, roll=ctx.rolls[l])
+                W.finish(blk.conv, gw)
+            _ready(blk)
             if l > 0:
                 dh = ops.conv1d_dgrad(dc, w, srcs[l].L, S, roll=ctx.rolls[l], pack=blk._pack)
             elif ctx.x_needs:
                 dx = ops.conv1d_dgrad(dc, w, srcs[l].L, S, roll=ctx.rolls[l], pack=blk._pack)
-        side.join()
         ctx.state = None
-        del any_param
         dx1 = None
         if dx is not None and ctx.split is not None:
             c0, need0, need1 = ctx.split

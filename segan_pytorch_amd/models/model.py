@@ -189,6 +189,7 @@ class SEGAN(Model):
         # (2) D fake update
         d_fake, _ = self.infer_D(Genh.detach(), noisy)
         d_fake_loss = criterion(d_fake.view(-1), 0.0)
+        sdist.arm(Dopt)                 # last backward into D's gradients: all-reduce by buckets
         d_fake_loss.backward()
         sdist.allreduce_grads(Dopt)
         Dopt.step()
@@ -203,6 +204,7 @@ class SEGAN(Model):
             g_adv_loss = criterion(d_fake_.view(-1), 1.0)
             g_l1_loss = l1_weight * self.reg_loss(Genh, clean)
             g_loss = g_adv_loss + g_l1_loss
+            sdist.arm(Gopt)
             g_loss.backward()
         sdist.allreduce_grads(Gopt)
         Gopt.step()
@@ -224,6 +226,13 @@ class SEGAN(Model):
                                       '440-507) is outside the accelerated path')
         if criterion is None or isinstance(criterion, nn.MSELoss):
             criterion = losses.MSELoss()
+        elif not isinstance(criterion, (losses.MSELoss, losses.BCEWithLogitsLoss)):
+            raise NotImplementedError('criterion {}: the step runs nn.MSELoss (train.py:94) or '
+                                      'BCEWithLogitsLoss natively; other criteria are not '
+                                      'implemented'.format(type(criterion).__name__))
+        if not getattr(opts, 'no_train_gen', True):
+            print('note: the periodic sample_*.wav dumps of the reference (gen_train_samples, '
+                  'model.py:350-392) are not produced; use clean.py on a checkpoint instead')
         self.writer = SummaryWriter(os.path.join(self.save_path, 'train'))
         Gopt, Dopt = self.build_optimizers(opts)
         self.G.optim = Gopt
@@ -242,6 +251,9 @@ class SEGAN(Model):
             beg_t = timeit.default_timer()
             self.G.train()
             self.D.train()
+            sampler = getattr(dloader, 'sampler', None)
+            if hasattr(sampler, 'set_epoch'):
+                sampler.set_epoch(epoch)        # DistributedSampler: a new permutation per epoch
             for bidx, batch in enumerate(dloader, start=1):
                 if epoch >= l1_dec_epoch and l1_weight > 0:
                     l1_weight = max(0, l1_weight - l1_dec_step)
@@ -292,7 +304,13 @@ class WSEGAN(SEGAN):
         self.D.apply(wsegan_weights_init)
 
     def sample_dloader(self, dloader, device='cpu'):
-        """A fresh iterator every step, first batch only (model.py:526-535)."""
+        """A fresh iterator every step, first batch only (model.py:526-535).  The reference's
+        RandomSampler reshuffles on every iter(); a DistributedSampler only does when its epoch
+        changes, so it is bumped per call (otherwise every step would see the same batch)."""
+        sampler = getattr(dloader, 'sampler', None)
+        if hasattr(sampler, 'set_epoch'):
+            self._sample_calls = getattr(self, '_sample_calls', 0) + 1
+            sampler.set_epoch(self._sample_calls)
         uttname, clean, noisy, slice_idx = next(iter(dloader))
         return (uttname, clean.unsqueeze(1).to(device), noisy.unsqueeze(1).to(device),
                 slice_idx.to(device))
@@ -333,6 +351,7 @@ class WSEGAN(SEGAN):
             d_loss = d_loss + cost(d_fake_inter.view(-1), 0.0)
             d_weight = 1 / 4
         d_loss = d_weight * d_loss
+        sdist.arm(Dopt)
         d_loss.backward()
         sdist.allreduce_grads(Dopt)
         Dopt.step()
@@ -353,6 +372,7 @@ class WSEGAN(SEGAN):
                 G_cost = G_cost + den_loss
             else:
                 den_loss = torch.zeros((), device=Genh.device)
+            sdist.arm(Gopt)
             G_cost.backward()
         sdist.allreduce_grads(Gopt)
         Gopt.step()

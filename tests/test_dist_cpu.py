@@ -114,6 +114,9 @@ def _dp_worker(rank, world, port, q):
     torch.set_num_threads(2)
     from segan_pytorch_amd import distributed as sdist
     sdist.init_from_env(backend='gloo')
+    # tiny buckets: the tiny nets' gradients go out as many overlapped all-reduces, issued from
+    # inside the backward passes (distributed.GradReducer)
+    sdist.set_bucket_bytes(16 * 1024)
     o, fx = _dp_opts()
     g = torch.Generator().manual_seed(3)
     clean = torch.rand(4, 1, 1024, generator=g) * 2 - 1
@@ -121,6 +124,8 @@ def _dp_worker(rank, world, port, q):
     z = torch.randn(4, 32, 16, generator=g)
     sl = slice(2 * rank, 2 * rank + 2)
     out = _dp_step(o, fx, clean[sl].contiguous(), noisy[sl].contiguous(), z[sl].contiguous(), 11)
+    nb = [len(r.buckets) for r in sdist._reducers.values()]
+    assert len(nb) == 2 and min(nb) >= 3, nb
     q.put((rank, {k: v.numpy() for k, v in out.items()}))
     dist.destroy_process_group()
 
