@@ -273,8 +273,7 @@ static int launch_tsmall4(const CorrArgs& a, const float* w, int M, int pad, hip
 int segan_launch_tsmall(CorrArgs& a, const float* w, int K, int M, int N, int S, int pad,
                          hipStream_t st) {
   if (int e = segan_src_defaults(&a.in, st, "tsmall")) return e;
-  static const bool q4_on = [] { const char* e = getenv("SEGAN_TSMALL4"); return !e || atoi(e) != 0; }();
-  if (q4_on && S == 4 && K == 31 && a.Tcols >= 1024)
+  if (S == 4 && K == 31 && a.Tcols >= 1024)
     return N == 1 ? launch_tsmall4<1>(a, w, M, pad, st) : launch_tsmall4<2>(a, w, M, pad, st);
   if (N == 1) {
     if (S == 4) return launch_tsmall_sn<4, 1>(a, w, K, M, pad, st);
@@ -431,8 +430,7 @@ __global__ __launch_bounds__(256) void fsmall4_kernel(const CorrArgs a, int M) {
 
 int segan_launch_fsmall(CorrArgs& a, int M, int N, int S, hipStream_t st) {
   if (int e = segan_src_defaults(&a.in, st, "fsmall")) return e;
-  static const bool q4_on = [] { const char* e = getenv("SEGAN_FSMALL4"); return !e || atoi(e) != 0; }();
-  if (q4_on && S == 4 && a.Lout >= 1024) {
+  if (S == 4 && a.Lout >= 1024) {
     dim3 grid4(ceil_div(a.Lout, 1024), a.B);
     if (N == 1) hipLaunchKernelGGL((fsmall4_kernel<1>), grid4, dim3(256), 0, st, a, M);
     else hipLaunchKernelGGL((fsmall4_kernel<2>), grid4, dim3(256), 0, st, a, M);

@@ -450,8 +450,7 @@ static int launch_wgrad_bf_x(WgradArgs& a, hipStream_t st) {
   const int ncol = ceil_div(a.Cv, CVW);
   const int nrow = ceil_div(a.M, 128);
   const int tiles = ncol * nrow;
-  static const int tgt_env = [] { const char* e = getenv("SEGAN_WGRAD_BLOCKS"); return e ? atoi(e) : 0; }();
-  int nsplit = ceil_div(tgt_env > 0 ? tgt_env : 1536, tiles);
+  int nsplit = ceil_div(1536, tiles);
   if (nsplit > chunks / 4) nsplit = chunks / 4;
   if (nsplit < 1) nsplit = 1;
   a.bf_cps = ceil_div(chunks, nsplit);

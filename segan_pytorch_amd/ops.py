@@ -20,9 +20,6 @@ PREC_FP32, PREC_BF16, PREC_BF16X3 = 0, 1, 3
 _PREC_NAMES = {'fp32': PREC_FP32, 'bf16': PREC_BF16, 'bf16x3': PREC_BF16X3}
 _precision = _PREC_NAMES[_os.environ.get('SEGAN_PRECISION', 'fp32')]
 _EUNSUPPORTED = -3
-# bf16 modes: convert the lo operand of the weight gradients once per call into a scratch
-# buffer (SEGAN_WGRAD_PACK=0 keeps the conversion inside the kernel; for A/B measurements)
-_WGRAD_PACK = _os.environ.get('SEGAN_WGRAD_PACK', '1') != '0'
 
 
 _deterministic = _os.environ.get('SEGAN_DETERMINISTIC', '0') == '1'
@@ -42,10 +39,11 @@ def get_deterministic():
 
 
 def set_precision(mode):
-    """Precision of the forward / data-gradient contractions: 'fp32' (exact fp32 MFMA, the
-    default and the benchmarked configuration), 'bf16' (bf16 operands, fp32 accumulate:
-    BASELINE config 5) or 'bf16x3' (exact 3-way bf16 split of every fp32 operand, six
-    partial products: fp32-class accuracy on the bf16 matrix cores).  Weight gradients,
+    """Precision of ALL contractions (conv / deconv forward, data gradients and weight
+    gradients): 'fp32' (exact fp32 MFMA, the default and the benchmarked configuration), 'bf16'
+    (bf16 operands, fp32 accumulate: BASELINE config 5) or 'bf16x3' (exact 3-way bf16 split of
+    every fp32 operand, six partial products: fp32-class accuracy on the bf16 matrix cores).
+    A geometry the bf16 kernels do not cover falls back to fp32 per call.  The dense head,
     BatchNorm, activations, losses and optimizers always run in fp32."""
     global _precision
     if mode not in _PREC_NAMES:
@@ -312,7 +310,7 @@ def wgrad(lo, hi, dw, K, S, padL, pad_mode, roll=0):
     lib = _lib.load()
     if _precision != PREC_FP32:
         nbytes = lib.segan_wgrad_scratch_bytes(lo.B, M, N, lo.L, S, _precision, 0)
-        scratch = torch.empty(nbytes, device=dw.device, dtype=torch.uint8) if _WGRAD_PACK else None
+        scratch = torch.empty(nbytes, device=dw.device, dtype=torch.uint8)
         rc = lib.segan_wgrad(ctypes.byref(cl), ctypes.byref(ch), _ptr(dw), lo.B, M, N, lo.L, K, S,
                              padL, pad_mode, roll, _precision, 0,
                              ctypes.c_void_p(scratch.data_ptr()) if scratch is not None else None,
