@@ -303,6 +303,18 @@ int segan_stft_overlap_add(const float* dframes, float* dx, int B, int T, int n_
 int segan_pcm16_prep(const int16_t* pcm, const unsigned char* first, float* clean, float* noisy,
                      int B, int T, double coef, void* stream);
 
+/* ---- output side and validation --------------------------------------
+ * De-emphasis x[n] = coef*x[n-1] + y[n] per row of y[rows][T] (se_dataset.py:119-126: the
+ * reference's per-sample python loop at the end of SEGAN.generate, model.py:154-156) as a
+ * blocked scan; coef <= 0 copies.  x may alias y. */
+int segan_deemphasis(const float* y, float* x, int rows, int T, double coef, void* stream);
+/* Segmental SNR of utils.py:350-395 for rows of ref / deg [rows][T]: seg[rows][nframes] (nframes
+ * = segan_ssnr_frames(T, srate)) holds the clamped per-frame values, out[rows][2] = (overall
+ * SNR in dB, mean segmental SNR). */
+int segan_ssnr_frames(int T, int srate);
+int segan_ssnr(const float* ref, const float* deg, float* seg, float* out, int rows, int T,
+               int srate, double eps, void* stream);
+
 /* ---- optimizers (model.py:219-228) ---------------------------------------------------- */
 /* torch.optim.RMSprop (no momentum, not centered): sq = alpha*sq + (1-alpha)*g*g;
  * p -= lr * g / (sqrt(sq) + eps), over a flat arena of n floats. */

@@ -1,0 +1,132 @@
+"""Fixtures that pin the rows NEXT to the training step to the REAL
+reference, generated in the build container:  python oracle/make_golden_frows.py
+-> tests/golden/frows.pt, tests/golden/ref_saver_ckpt/ (a checkpoint written by the reference's
+own Saver).
+
+f1  SEGAN.generate (model.py:116-157) and WSEGAN.generate (model.py:755-766) of the tiny net on
+    a 2.3-chunk utterance, including the reference's python-loop de_emphasize
+    (se_dataset.py:119-126); plus de_emphasize alone on a long random signal.
+f2  normalize_wave_minmax + pre_emphasize (se_dataset.py:108-117) on int16 PCM, and the
+    slices SEDataset would cut from it.
+f3  a checkpoint written by the reference's Saver (core.py:21-67), and — asserted here, at
+    generation time — a checkpoint written by OUR Saver loaded back by the reference's.
+f4  SSNR (utils.py:350-395) on noisy/clean pairs.
+"""
+import os
+import shutil
+import sys
+import tempfile
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+import ref_harness  # noqa: E402
+from make_golden import clone_sd, seed_all, tiny_opts  # noqa: E402
+
+OUT = os.path.join(ROOT, 'tests', 'golden')
+
+
+def main():
+    ref = ref_harness.import_reference()
+    import importlib
+    ref_ds = importlib.import_module('segan.datasets.se_dataset')
+    ref_utils = importlib.import_module('segan.utils')
+    ref_core = importlib.import_module('segan.models.core')
+    fx = {}
+
+    # ---------------- f1: inference ----------------
+    o = tiny_opts()
+    seed_all(111)
+    segan = ref.SEGAN(SimpleNamespace(**o))
+    T = int(2.3 * 16384)
+    g = torch.Generator().manual_seed(21)
+    wav = (torch.rand(1, 1, T, generator=g) * 2 - 1) * 0.5
+    z = torch.randn(1, o['z_dim'], 16384 // 64, generator=g)
+    with torch.no_grad():
+        c_res, g_c = segan.generate(wav.clone(), z=z.clone())
+    fx['generate'] = {'opts': o, 'G0': clone_sd(segan.G), 'wav': wav, 'z': z,
+                      'c_res': torch.from_numpy(np.asarray(c_res, dtype=np.float32)),
+                      'g_c': g_c.detach().clone()}
+    ow = tiny_opts()
+    ow.update(dict(wsegan=True, misalign_pair=False, interf_pair=False, pow_weight=0.001,
+                   vanilla_gan=False, n_fft=2048))
+    seed_all(112)
+    wseg = ref.WSEGAN(SimpleNamespace(**ow))
+    Tw = 5000                                   # not a multiple of 1024: make_divN pads
+    wavw = (torch.rand(1, 1, Tw, generator=g) * 2 - 1) * 0.5
+    zw = torch.randn(1, ow['z_dim'], (Tw + 1023) // 1024 * 1024 // 64, generator=g)
+    with torch.no_grad():
+        cw, _ = wseg.generate(wavw.clone(), z=zw.clone())
+    fx['wgenerate'] = {'opts': ow, 'G0': clone_sd(wseg.G), 'wav': wavw, 'z': zw,
+                       'c_res': torch.from_numpy(np.asarray(cw, dtype=np.float32))}
+    y = (np.random.RandomState(5).rand(50000).astype(np.float32) * 2 - 1) * 0.3
+    fx['deemph'] = {'y': torch.from_numpy(y), 'coef': 0.95,
+                    'x': torch.from_numpy(ref_ds.de_emphasize(y, 0.95).astype(np.float32))}
+
+    # ---------------- f2: input pipeline ----------------
+    rs = np.random.RandomState(7)
+    pcm = rs.randint(-32768, 32768, size=40000).astype(np.int16)
+    norm = ref_ds.normalize_wave_minmax(pcm)
+    pre = ref_ds.pre_emphasize(norm, 0.95)
+    fx['pcm'] = {'pcm': torch.from_numpy(pcm), 'coef': 0.95,
+                 'normalized': torch.from_numpy(np.asarray(norm, dtype=np.float64)),
+                 'pre_emphasized': torch.from_numpy(np.asarray(pre, dtype=np.float64))}
+
+    # ---------------- f4: SSNR ----------------
+    rs = np.random.RandomState(9)
+    clean = (rs.rand(3, 16384) * 2 - 1).astype(np.float32) * 0.4
+    deg = (clean + rs.randn(3, 16384).astype(np.float32) * np.array([[0.01], [0.1], [1.0]], dtype=np.float32))
+    ov, seg = [], []
+    for i in range(3):
+        a, b = ref_utils.SSNR(clean[i], deg[i])
+        ov.append(a)
+        seg.append(np.asarray(b))
+    fx['ssnr'] = {'clean': torch.from_numpy(clean), 'deg': torch.from_numpy(deg.astype(np.float32)),
+                  'overall': torch.tensor(ov, dtype=torch.float64),
+                  'segmental': torch.from_numpy(np.stack(seg)).double()}
+
+    # ---------------- f3: checkpoints ----------------
+    ck = os.path.join(OUT, 'ref_saver_ckpt')
+    shutil.rmtree(ck, ignore_errors=True)
+    os.makedirs(ck)
+    Gopt = torch.optim.RMSprop(segan.G.parameters(), lr=5e-5)
+    # one optimizer step so that the saved optimizer state is not empty
+    for p in segan.G.parameters():
+        p.grad = torch.full_like(p, 1e-3)
+    Gopt.step()
+    saver = ref_core.Saver(segan.G, ck, max_ckpts=3, optimizer=Gopt, prefix='EOE_G-')
+    segan.G.save(ck, 7, saver=saver)
+    fx['ckpt'] = {'opts': o, 'G_saved': clone_sd(segan.G), 'step': 7,
+                  'files': sorted(os.listdir(ck))}
+    # ours -> reference
+    saved = {k: v for k, v in sys.modules.items() if k == 'segan' or k.startswith('segan.')}
+    for k in saved:
+        del sys.modules[k]
+    sys.path.insert(0, ROOT)
+    from segan_pytorch_amd.models import SEGAN as OurSEGAN
+    from segan_pytorch_amd.models.core import Saver as OurSaver
+    seed_all(5)
+    ours = OurSEGAN(SimpleNamespace(**o))
+    tmp = tempfile.mkdtemp()
+    osaver = OurSaver(ours.G, tmp, max_ckpts=3, optimizer=None, prefix='EOE_G-')
+    ours.G.save(tmp, 11, saver=osaver)
+    for k, v in saved.items():
+        sys.modules[k] = v
+    seed_all(6)
+    ref2 = ref.SEGAN(SimpleNamespace(**o))
+    rsaver = ref_core.Saver(ref2.G, tmp, max_ckpts=3, optimizer=None, prefix='EOE_G-')
+    assert rsaver.load_weights() is True
+    for k, v in ours.G.state_dict().items():
+        assert torch.equal(ref2.G.state_dict()[k], v), k
+    fx['ckpt']['ours_loaded_by_reference'] = True
+    shutil.rmtree(tmp, ignore_errors=True)
+    torch.save(fx, os.path.join(OUT, 'frows.pt'))
+    print('frows.pt done:', {k: list(v.keys()) for k, v in fx.items()})
+
+
+if __name__ == '__main__':
+    main()

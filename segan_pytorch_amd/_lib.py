@@ -77,6 +77,9 @@ SIGNATURES = {
     'segan_powdb': (c_int, [_P, _P, c_int64, c_int, c_int, c_float, _P]),
     'segan_powdb_bwd': (c_int, [_P, _P, _P, c_int64, c_int, c_int, c_float, _P]),
     'segan_stft_overlap_add': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    'segan_deemphasis': (c_int, [_P, _P, c_int, c_int, c_double, _P]),
+    'segan_ssnr_frames': (c_int, [c_int, c_int]),
+    'segan_ssnr': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_double, _P]),
     'segan_rmsprop_step': (c_int, [_P, _P, _P, c_float, c_float, c_float, c_int64, _P]),
     'segan_adam_step': (c_int, [_P, _P, _P, _P, c_float, c_float, c_float, c_float, c_int, c_int64,
                                 _P]),

@@ -65,6 +65,15 @@ def wsegan_weights_init(m):
         nn.init.xavier_uniform_(m.weight.data)
 
 
+def _de_emphasize_any(x, coef):
+    """1-D tensor -> de-emphasised float32 numpy array (what generate returns): the scan kernel
+    for a GPU tensor, the host filter otherwise."""
+    if x.is_cuda:
+        from .. import ops
+        return ops.de_emphasize(x.float(), coef).cpu().numpy() if coef > 0 else x.cpu().numpy()
+    return de_emphasize(x.numpy(), coef)
+
+
 class _frozen(object):
     """Context manager: parameters of `module` do not require grad inside."""
 
@@ -147,8 +156,9 @@ class SEGAN(Model):
                 beg = end
         nums = [int(k.split('_')[1]) for k in hall.keys() if 'enc' in k and 'zc' not in k]
         g_c = hall['enc_{}'.format(max(nums))][-1:]
-        c_res = torch.cat(outs, 0).reshape(-1)[:T].cpu().numpy()
-        c_res = de_emphasize(c_res, self.preemph)
+        c_res = torch.cat(outs, 0).reshape(-1)[:T].contiguous()
+        # de-emphasis (model.py:154-156) as a scan on the GPU instead of the per-sample loop
+        c_res = _de_emphasize_any(c_res, self.preemph)
         return c_res, g_c
 
     def discriminate(self, cwav, nwav):
@@ -221,9 +231,6 @@ class SEGAN(Model):
     def train(self, opts, dloader, criterion, l1_init, l1_dec_step, l1_dec_epoch, log_freq,
               va_dloader=None, device='cpu'):
         """Train the SEGAN (model.py:230-437)."""
-        if va_dloader is not None:
-            raise NotImplementedError('validation with CompositeEval (PESQ binary, model.py:'
-                                      '440-507) is outside the accelerated path')
         if criterion is None or isinstance(criterion, nn.MSELoss):
             criterion = losses.MSELoss()
         elif not isinstance(criterion, (losses.MSELoss, losses.BCEWithLogitsLoss)):
@@ -247,6 +254,7 @@ class SEGAN(Model):
         l1_weight = l1_init
         iteration = 1
         timings = []
+        best_val_obj, patience = None, getattr(opts, 'patience', 100)
         for epoch in range(1, opts.epoch + 1):
             beg_t = timeit.default_timer()
             self.G.train()
@@ -278,9 +286,63 @@ class SEGAN(Model):
                     for k, v in zip(('D_real', 'D_fake', 'G_adv', 'G_l1'), vals):
                         self.writer.add_scalar(k, v, iteration)
                 iteration += 1
+            if va_dloader is not None:
+                # validation (model.py:394-433).  The reference's objective adds COVL and PESQ,
+                # which need the external `pesqmain` binary; here the objective is the
+                # segmental SNR, computed on the GPU
+                evals = self.evaluate(opts, va_dloader, log_freq, device=device)
+                val_obj = float(np.mean(evals['ssnr']))
+                self.writer.add_scalar('Genh-ssnr', val_obj, epoch)
+                if best_val_obj is None or val_obj > best_val_obj:
+                    if is_main:
+                        print('Val obj (SSNR) improved {} -> {}'.format(best_val_obj, val_obj))
+                        self.G.save(self.save_path, iteration, True)
+                        self.D.save(self.save_path, iteration, True)
+                    best_val_obj, patience = val_obj, getattr(opts, 'patience', 100)
+                else:
+                    patience -= 1
+                    if is_main:
+                        print('Val loss did not improve. Patience {}/{}'.format(
+                            patience, getattr(opts, 'patience', 100)))
+                    if patience <= 0:
+                        if is_main:
+                            print('STOPPING SEGAN TRAIN: OUT OF PATIENCE.')
+                        break
             if is_main:
                 self.G.save(self.save_path, iteration, saver=eoe_g_saver)
                 self.D.save(self.save_path, iteration, saver=eoe_d_saver)
+
+    def evaluate(self, opts, dloader, log_freq, do_noisy=False, max_samples=1, device='cpu'):
+        """Objective evaluation on a validation loader (model.py:440-507), on the GPU: G in eval
+        mode on up to `max_samples` batches, de-emphasis, segmental SNR (utils.py:350-395) of the
+        enhanced — and with `do_noisy` of the noisy — signal against the clean one.  Returns
+        {'ssnr': [...], 'snr': [...]} per utterance (and the same for the noisy input).  PESQ /
+        CSIG / CBAK / COVL of the reference need its external `pesqmain` binary and are not
+        computed.  De-emphasis runs along time (the reference applies it along axis 0 of the
+        [B, T] batch, model.py:474-477)."""
+        from .. import ops
+        self.G.eval()
+        self.D.eval()
+        evals = {'ssnr': [], 'snr': []}
+        noisy_evals = {'ssnr': [], 'snr': []}
+        with torch.no_grad():
+            for bidx, batch in enumerate(dloader, start=1):
+                if len(batch) != 4:
+                    raise ValueError('Returned {} elements per sample?'.format(len(batch)))
+                uttname, clean, noisy, slice_idx = batch
+                clean = clean.to(device).float().contiguous()
+                noisy = noisy.to(device).float().contiguous()
+                Genh = self.infer_G(noisy.unsqueeze(1)).squeeze(1).contiguous()
+                c = ops.de_emphasize(clean, self.preemph)
+                for sig, dst in ((Genh, evals),) + (((noisy, noisy_evals),) if do_noisy else ()):
+                    snr, ssnr, _ = ops.ssnr(c, ops.de_emphasize(sig, self.preemph))
+                    dst['ssnr'] += ssnr.cpu().tolist()
+                    dst['snr'] += snr.cpu().tolist()
+                if bidx >= max_samples:
+                    break
+        self.G.train()
+        self.D.train()
+        return (evals, noisy_evals) if do_noisy else evals
 
 
 class WSEGAN(SEGAN):
@@ -418,5 +480,4 @@ class WSEGAN(SEGAN):
         p_wav = torch.nn.functional.pad(inwav, (0, pad)) if pad else inwav
         with torch.no_grad():
             c_res, hall = self.infer_G(p_wav.contiguous(), z=z, ret_hid=True)
-        c_res = c_res[0, 0, :ori_len].cpu().data.numpy()
-        return de_emphasize(c_res, self.preemph), hall
+        return _de_emphasize_any(c_res[0, 0, :ori_len].contiguous(), self.preemph), hall

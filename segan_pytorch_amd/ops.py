@@ -762,6 +762,34 @@ def pcm16_prep(pcm, first, coef):
     return clean, noisy
 
 
+def de_emphasize(y, coef):
+    """x[n] = coef*x[n-1] + y[n] along the last axis of a CUDA tensor [..., T] (se_dataset.py:
+    119-126 on the device)."""
+    _chk(y, 'y')
+    T = y.shape[-1]
+    x = torch.empty_like(y)
+    check(_lib.load().segan_deemphasis(_ptr(y), _ptr(x), y.numel() // T, T, float(coef), _stream()),
+          'deemphasis')
+    return x
+
+
+def ssnr(ref, deg, srate=16000, eps=1e-10):
+    """Segmental SNR of utils.py:350-395 per row of ref / deg [rows, T] on the device.  Returns
+    (overall_snr[rows], mean_segmental_snr[rows], segmental[rows, nframes])."""
+    _chk(ref, 'ref', 2)
+    _chk(deg, 'deg', 2)
+    if ref.shape != deg.shape:
+        raise ValueError('ssnr: shapes differ {} vs {}'.format(tuple(ref.shape), tuple(deg.shape)))
+    rows, T = ref.shape
+    lib = _lib.load()
+    nf = lib.segan_ssnr_frames(T, srate)
+    seg = torch.empty((rows, max(nf, 1)), device=ref.device, dtype=torch.float32)
+    out = torch.empty((rows, 2), device=ref.device, dtype=torch.float32)
+    check(lib.segan_ssnr(_ptr(ref), _ptr(deg), _ptr(seg), _ptr(out), rows, T, srate, float(eps),
+                         _stream()), 'ssnr')
+    return out[:, 0], out[:, 1], seg[:, :nf]
+
+
 def rmsprop_step(p, g, sq, lr, alpha, eps):
     check(_lib.load().segan_rmsprop_step(_ptr(p), _ptr(g), _ptr(sq), lr, alpha, eps, p.numel(),
                                          _stream()), 'rmsprop_step')
