@@ -18,6 +18,8 @@ tiny_wsegan2.pt  the tiny net as WSEGAN with --misalign_pair through the referen
 segan_plus_b2.pt the default SEGAN+ net (ckpt_segan+/train.opts, seed 111) at B=2:
                  per-tensor init checksums, G output, D logits, losses, and
                  checksums/samples of every gradient.
+vanilla11_b8.pt  (python oracle/make_golden.py vanilla11) the original 11-layer stride-2 SEGAN
+                 shape, one step at B=8, same content as segan_plus_b2.pt.
 """
 import json
 import os
@@ -192,6 +194,40 @@ def make_wsegan_snorm(ref):
         torch.optim.Adam = _Adam
 
 
+VANILLA11 = dict(genc_fmaps=[16, 32, 32, 64, 64, 128, 128, 256, 256, 512, 1024],
+                 denc_fmaps=[16, 32, 32, 64, 64, 128, 128, 256, 256, 512, 1024],
+                 genc_poolings=[2] * 11, denc_poolings=[2] * 11, dpool_slen=8)
+
+
+def make_vanilla11(ref):
+    """vanilla11_b8.pt: the original 11-layer stride-2 SEGAN shape (train.py:199-205 flags
+    --genc_fmaps 16 32 32 64 64 128 128 256 256 512 1024 --genc_poolings 2 x11, same for D) at
+    B=8 (at B=2 the deepest BatchNorm sees 16 values per channel and the step is ill-conditioned), one GAN step: like segan_plus_b2.pt (checksums of the big tensors)."""
+    ob = base_opts()
+    ob.update(VANILLA11)
+    ob['save_path'] = '/tmp/segan_golden_ckpt'
+    seed_all(111)
+    segan = ref.SEGAN(SimpleNamespace(**ob))
+    clean, noisy = synth(8, 16384, 0)
+    clean, noisy = clean.unsqueeze(1), noisy.unsqueeze(1)
+    z = torch.randn(8, 1024, 8, generator=torch.Generator().manual_seed(0))
+    fx = {'opts': ob, 'batch': 8, 'seed': 111, 'roll_seed': 3, 'z_seed': 0, 'data_seed': 0,
+          'rolls': ref_harness.ReplayRandom(3).rolls(11, ob['phase_shift'], 3),
+          'init_G': {k: checksum(v) for k, v in segan.G.state_dict().items()},
+          'init_D': {k: checksum(v) for k, v in segan.D.state_dict().items()}}
+    res = manual_step(ref, segan, clean, noisy, z, 3)
+    for k in ('Genh', 'd_real', 'd_fake', 'd_fake_', 'd_real_loss', 'd_fake_loss', 'g_adv_loss',
+              'g_l1_loss'):
+        fx[k] = res[k]
+    fx['d_grads'] = {k: checksum(v) for k, v in res['d_grads'].items()}
+    fx['g_grads'] = {k: checksum(v) for k, v in res['g_grads'].items()}
+    fx['small_d_grads'] = {k: v for k, v in res['d_grads'].items() if v.numel() <= 4096}
+    fx['small_g_grads'] = {k: v for k, v in res['g_grads'].items() if v.numel() <= 4096}
+    torch.save(fx, os.path.join(OUT, 'vanilla11_b8.pt'))
+    print('vanilla11_b8.pt done', res['Genh'].shape, res['g_l1_loss'],
+          sum(p.numel() for p in segan.G.parameters()), sum(p.numel() for p in segan.D.parameters()))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = ref_harness.import_reference()
@@ -199,6 +235,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'snorm':     # only the spectral-norm fixtures
         make_snorm(ref)
         make_wsegan_snorm(ref)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == 'vanilla11':
+        make_vanilla11(ref)
         return
 
     # ---------------- tiny_step ----------------

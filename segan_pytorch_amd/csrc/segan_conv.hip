@@ -971,7 +971,8 @@ extern "C" int segan_conv1d_fwd(const segan_src* x, const void* wf, const float*
   SEGAN_REQUIRE(L % S == 0, "conv1d_fwd: length %d not divisible by stride %d", L, S);
   SEGAN_REQUIRE(wf && out, "conv1d_fwd: NULL pointer");
   SEGAN_REQUIRE(mode == SEGAN_PAD_REFLECT || mode == SEGAN_PAD_ZERO, "conv1d_fwd: bad pad mode");
-  SEGAN_REQUIRE(mode != SEGAN_PAD_REFLECT || (padL < L && K - 1 - padL < L),
+  // right over-run of the last output's window: L - S + K - 1 - padL - (L - 1) = K - S - padL
+  SEGAN_REQUIRE(mode != SEGAN_PAD_REFLECT || (padL < L && K - S - padL < L),
                 "conv1d_fwd: reflect padding %d needs length > pad (L=%d)", padL, L);
   SEGAN_REQUIRE(roll > -L && roll < L, "conv1d_fwd: |roll| must be < L");
   if (int e = check_src(x, N, "conv1d_fwd")) return e;
@@ -1078,7 +1079,8 @@ extern "C" int segan_conv1d_dgrad(const float* da, const void* wt, const float* 
   SEGAN_REQUIRE(da && dx && halo && (wt || (w && N <= 2)), "conv1d_dgrad: NULL pointer");
   SEGAN_REQUIRE(roll > -L && roll < L, "conv1d_dgrad: |roll| must be < L");
   const int padR = K - 1 - padL;
-  SEGAN_REQUIRE(padL >= 0 && padR >= 0 && padL < L && padR < L, "conv1d_dgrad: bad padding");
+  // the halo spans K-1 positions; with stride S the last S-1 of them are never written
+  SEGAN_REQUIRE(padL >= 0 && padR >= 0 && padL < L && K - S - padL < L, "conv1d_dgrad: bad padding");
   const int U = 32 / S;
   const int Ls = L / S;
   hipStream_t st = (hipStream_t)stream;

@@ -60,6 +60,11 @@ def segan_plus_b2():
     return load_golden('segan_plus_b2.pt')
 
 
+@pytest.fixture(scope='session')
+def vanilla11_b8():
+    return load_golden('vanilla11_b8.pt')
+
+
 def max_rel(a, b):
     """max |a-b| / max(|b|) — scale-aware error for tensors."""
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
