@@ -57,6 +57,37 @@ def default_opts(save_path='/tmp/segan_bench_ckpt'):
                 dnorm_type='bnorm', phase_shift=5, sinc_conv=False, bias=True, seed=111)
 
 
+VANILLA11 = dict(genc_fmaps=[16, 32, 32, 64, 64, 128, 128, 256, 256, 512, 1024],
+                 denc_fmaps=[16, 32, 32, 64, 64, 128, 128, 256, 256, 512, 1024],
+                 genc_poolings=[2] * 11, denc_poolings=[2] * 11, dpool_slen=8)
+
+
+def gflop_per_chunk(o, T=16384, wsegan=False):
+    """Algorithmic FLOPs of one GAN step per chunk, SURVEY.md 8(d) accounting: 2 * (3 * G forward
+    MACs + 9 * D forward MACs) (12 * D with the WSEGAN misalign pair), from the layer shapes."""
+    K = o['gkwidth']
+    g, cin, L = 0, 1, T
+    for c, s in zip(o['genc_fmaps'], o['genc_poolings']):
+        L //= s
+        g += c * cin * K * L
+        cin = c
+    dec = o['genc_fmaps'][::-1][1:] + [1]
+    cin = o['genc_fmaps'][-1] + (0 if o['no_z'] else o['z_dim'])
+    for i, (c, s) in enumerate(zip(dec, o['genc_poolings'][::-1])):
+        if i > 0 and not o['no_skip']:
+            cin *= 2
+        g += cin * c * K * L
+        L *= s
+        cin = c
+    d, cin, L = 0, 2, T
+    for c, s in zip(o['denc_fmaps'], o['denc_poolings']):
+        L //= s
+        d += c * cin * K * L
+        cin = c
+    d += cin * L * 256 + 256 * 128 + 128
+    return 2.0 * (3 * g + (12 if wsegan else 9) * d) / 1e9
+
+
 class KernelTimer(object):
     """Brackets every launch of the contraction entry points with HIP events on torch's
     current stream (the stream the kernels are launched on) and books the algorithmic
@@ -265,6 +296,10 @@ def main():
     ap.add_argument('--wsegan', action='store_true',
                     help='time the WSEGAN step of BASELINE config 4 (--wsegan --misalign_pair) instead '
                          'of the SEGAN+ step; a side measurement, not the headline metric')
+    ap.add_argument('--shape', default='segan_plus', choices=['segan_plus', 'vanilla11'],
+                    help='segan_plus: the SEGAN+ default net (the headline configuration); vanilla11: '
+                         'the original 11-layer stride-2 SEGAN (train.py:199-205 flags) — a side line '
+                         'with its own FLOP count')
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16x3', 'bf16'],
                     help='forward/data-gradient contraction precision (default: exact fp32, the '
                          'BASELINE configuration; bf16x3 = exact 3-way bf16 split of fp32 operands; '
@@ -313,6 +348,9 @@ def main():
         assert ranks_seen == list(range(world)), ranks_seen
 
     opts = default_opts()
+    if args.shape == 'vanilla11':
+        opts.update(VANILLA11)
+    gflop = gflop_per_chunk(opts, wsegan=args.wsegan)
     random.seed(111); np.random.seed(111); torch.manual_seed(111)
     if args.wsegan:
         opts.update(dict(misalign_pair=True, interf_pair=False, pow_weight=0.001, vanilla_gan=False,
@@ -411,6 +449,10 @@ def main():
             'config': {'workload': ('WSEGAN step with --misalign_pair (model.py:577-669; BASELINE '
                                     'config 4), same nets, batch {} x 16384-sample chunks per GPU'
                                     if args.wsegan else
+                                    'original SEGAN shape: 11+11 layers of stride 2, k31 (train.py:'
+                                    '199-205 flags), batch {} x 16384-sample chunks per GPU, full GAN '
+                                    'step, RMSprop, fp32 (side line, not the headline configuration)'
+                                    if args.shape == 'vanilla11' else
                                     'SEGAN+ default G+D (5+5 layers, k31, stride 4, z 1024x16), '
                                     'batch {} x 16384-sample chunks per GPU, full GAN step '
                                     '(model.py:292-321), RMSprop, fp32').format(B),
@@ -418,8 +460,9 @@ def main():
                        'z': 'device generator' if args.device_z else 'host randn + H2D per step (as train.py)'},
             'losses_finite': finite,
             'precision': args.precision,
-            'step_tflops': (44.33 if args.wsegan else GFLOP_PER_CHUNK) * value / 1e3,
-            'step_frac_of_f32_mfma_peak': (44.33 if args.wsegan else GFLOP_PER_CHUNK) * value / 1e3 / PEAK_F32_MFMA_TF / world,
+            'gflop_per_chunk': gflop,
+            'step_tflops': gflop * value / 1e3,
+            'step_frac_of_f32_mfma_peak': gflop * value / 1e3 / PEAK_F32_MFMA_TF / world,
             'step_hbm_gbs_algorithmic': MB_PER_CHUNK * value / 1e3 / world,
         }
         if timer is not None:
@@ -448,7 +491,7 @@ def main():
                              '(parity tolerance 5e-5, tests/test_gpu_kernels.py); bf16 = BASELINE '
                              'config 5 (tolerance 2e-2).  `value` above is the exact-fp32 run.')
             line['other_precisions'] = modes
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.shape == 'segan_plus' and not args.wsegan:
             try:
                 del model, Gopt, Dopt
                 torch.cuda.empty_cache()

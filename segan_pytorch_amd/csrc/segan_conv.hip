@@ -689,9 +689,34 @@ __global__ __launch_bounds__(256) void corr_fixup_kernel(const CorrArgs a) {
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-  for (int g = g_first; g <= g_last; ++g) {
+  // two pieces in flight at a time (the kernel is a pure stream: more loads outstanding per
+  // lane), always ADDED in chunk order
+  auto slab_of = [&](int g) {
     const int piece = t - (int)(((long)g * a.sk_units) / nch);
-    slab_add<NI, NJ>(a.sk_ws + (size_t)(g * 2 + piece) * (MB * NB), acc, tid);
+    return reinterpret_cast<const f32x4*>(a.sk_ws + (size_t)(g * 2 + piece) * (MB * NB));
+  };
+  constexpr int NV = NI * NJ * 4;
+  for (int g = g_first; g <= g_last; g += 2) {
+    const bool two = g + 1 <= g_last;
+    const f32x4* s0 = slab_of(g);
+    const f32x4* s1 = slab_of(two ? g + 1 : g);
+    f32x4 v0[NV], v1[NV];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) v0[q] = s0[q * 256 + tid];
+    if (two) {
+#pragma unroll
+      for (int q = 0; q < NV; ++q) v1[q] = s1[q * 256 + tid];
+    }
+#pragma unroll
+    for (int q = 0; q < NV; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[q / (NJ * 4)][(q / 4) % NJ][4 * (q % 4) + e] += v0[q][e];
+    if (two) {
+#pragma unroll
+      for (int q = 0; q < NV; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[q / (NJ * 4)][(q / 4) % NJ][4 * (q % 4) + e] += v1[q][e];
+    }
   }
   corr_store_tile<MB, NB, WM, U, OUT_HI>(a, acc, m0, n0, wm, h, col_b, col_t);
 }
