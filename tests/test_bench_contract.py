@@ -1,4 +1,4 @@
-"""The committed bench line (profiles/r01_bench_line.json, the stdout of `python bench.py` on
+"""The committed bench line (profiles/r02_bench_line.json, the stdout of `python bench.py` on
 an MI355X) carries every field of the driver's contract."""
 import json
 import os
@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    d = json.load(open(os.path.join(ROOT, 'profiles', 'r01_bench_line.json')))
+    d = json.load(open(os.path.join(ROOT, 'profiles', 'r02_bench_line.json')))
     for k, typ in (('metric', str), ('value', float), ('unit', str), ('n_gpus', int), ('steps', int),
                    ('warmup', int), ('ms_per_step', float), ('higher_is_better', bool),
                    ('scaling', str), ('dtype', str), ('data', str), ('config', dict)):
@@ -21,4 +21,9 @@ def test_committed_bench_line_has_the_contract_fields():
     assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9 and r['traffic'] > 0
     c = d['cpu_baseline']
     assert c['kind'] in ('reference', 'port') and c['cores'] >= 1 and c['value'] > 0 and c['sample']
+    assert 'batch 300' in c['sample'] and c['cores'] >= 1
     assert set(d['other_precisions']) >= {'bf16x3', 'bf16'}
+    # BASELINE's second metric, at the benchmarked batch: generator output MSE vs the oracle
+    pr = d['parity']
+    assert pr['batch'] == 300 and pr['g_mse'] < 1e-4 and pr['g_max_abs'] < 1e-5
+    assert max(pr['d_real_loss_rel'], pr['d_fake_loss_rel'], pr['g_adv_loss_rel'], pr['g_l1_loss_rel']) < 1e-4
