@@ -100,6 +100,13 @@ FLAGS = [
     ('--sync_bn', dict(action='store_true', default=False,
                        help='data parallel: take D\'s BatchNorm statistics over the global batch '
                             '(N ranks of batch b behave like one process at batch N*b)')),
+    ('--device_z', dict(action='store_true', default=False,
+                        help='draw the generator\'s z on the GPU (per-rank generator) instead of on the '
+                             'host like the reference (generator.py:197): no host randn + copy per step, '
+                             'but not the reference\'s RNG stream')),
+    ('--deterministic', dict(action='store_true', default=False,
+                             help='bit-reproducible kernels: ordered reductions instead of fp32 atomics '
+                                  'in the weight gradients (a few percent slower)')),
     ('--pcm_shard', dict(type=str, default=None,
                          help='prefix of a pre-sliced int16 shard (scripts/make_pcm_shard.py): batches '
                               'are normalised and pre-emphasised on the GPU')),
@@ -133,6 +140,11 @@ def main(opts):
         raise NotImplementedError('AEWSEGAN is broken in the reference (model.py:823) and is '
                                   'not implemented')
     segan = (WSEGAN if opts.wsegan else SEGAN)(opts)
+    if getattr(opts, 'device_z', False):
+        segan.G.z_generator = torch.Generator(device=device).manual_seed(opts.seed + rank)
+    if getattr(opts, 'deterministic', False):
+        from segan_pytorch_amd import ops as _ops
+        _ops.set_deterministic(True)
     segan.to(device)
     print('Total model parameters: ', segan.get_n_params())
     if opts.g_pretrained_ckpt is not None:
