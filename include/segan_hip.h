@@ -97,6 +97,9 @@ size_t segan_corr_scratch_bytes(void);
  * was launched: {kernel (1 general, 2 fast), workgroups, tiles, tiles run whole, (tile, chunk)
  * units per workgroup of the stream-K part or 0, input transform mode}. */
 void segan_debug_last_corr(int* out6);
+/* The same for the last fp32 weight gradient: {kernel (1 general, 2 fast), tiles, contraction
+ * splits, chunks per split, resident workgroups per CU assumed, hi loads per lane}. */
+void segan_debug_last_wgrad(int* out6);
 
 /* GConv1DBlock forward without norm/activation (modules.py:91-99):
  *   out[b,m,t] = bias[m] + sum_{n,k} w[m,n,k] * pad(roll(x))[b,n,S*t+k]

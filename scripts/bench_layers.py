@@ -11,6 +11,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--batch', type=int, default=300)
 ap.add_argument('--iters', type=int, default=5)
 ap.add_argument('--only', default='')
+ap.add_argument('--verbose', action='store_true')
 args = ap.parse_args()
 B, K, S = args.batch, 31, 4
 dev = 'cuda'
@@ -30,7 +31,8 @@ def timeit(fn, iters=args.iters):
 rows = []
 def report(name, flops, ms):
     rows.append((name, flops / 1e9, ms, flops / ms / 1e9))
-    print('%-28s %9.2f GFLOP %8.3f ms %7.1f TF/s' % (name, flops / 1e9, ms, flops / ms / 1e9), flush=True)
+    info = ops.last_wgrad_launch() if 'wgrad' in name else ops.last_corr_launch()
+    print('%-28s %9.2f GFLOP %8.3f ms %7.1f TF/s  %s' % (name, flops / 1e9, ms, flops / ms / 1e9, info if args.verbose else ''), flush=True)
 
 enc = [(1, 64, 16384), (64, 128, 4096), (128, 256, 1024), (256, 512, 256), (512, 1024, 64)]
 dec = [(2048, 512, 16), (1024, 256, 64), (512, 128, 256), (256, 64, 1024), (128, 1, 4096)]

@@ -37,6 +37,7 @@ SIGNATURES = {
     'segan_pack_weights_bf': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     'segan_corr_scratch_bytes': (c_size_t, []),
     'segan_debug_last_corr': (None, [POINTER(c_int)]),
+    'segan_debug_last_wgrad': (None, [POINTER(c_int)]),
     'segan_conv1d_fwd': (c_int, [_SRC, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                  c_int, c_int, c_int, _P, c_size_t, _P]),
     'segan_conv1d_dgrad': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,

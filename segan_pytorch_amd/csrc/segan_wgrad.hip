@@ -618,6 +618,12 @@ __global__ void wgrad_lo_materialize_kernel(const segan_src lo, float* out, int 
   }
 }
 
+// diagnostics: how the last fp32 weight gradient of this thread was launched
+static thread_local int g_last_wgrad[6];
+extern "C" void segan_debug_last_wgrad(int* out6) {
+  for (int i = 0; i < 6; ++i) out6[i] = g_last_wgrad[i];
+}
+
 // ---- wgrad2 launch ----
 static int wg_cur_device() {
   int d = 0;
@@ -667,23 +673,32 @@ static int launch_wgrad2(WgradArgs& a, hipStream_t st, bool deterministic, float
   a.w2_lsshift = -1;
   if (multi) { int sh = 0; while ((1 << sh) < a.Ls) ++sh; a.w2_lsshift = sh; }
   a.w2_pw = multi ? a.w2_spc * (a.Ls + a.H) : TK + a.H;
-  a.RLw = a.w2_pw + (8 - a.w2_pw % 32 + 32) % 32;       // row stride = 8 (mod 32)
+  // row stride = 8 or 24 (mod 32): the 4 channels x 8 taps a half-wave reads hit 32 distinct
+  // banks either way; the smaller one keeps 4 workgroups per CU when a chunk holds two samples
+  {
+    const int r8 = a.w2_pw + (8 - a.w2_pw % 32 + 32) % 32, r24 = a.w2_pw + (24 - a.w2_pw % 32 + 32) % 32;
+    a.RLw = U == 8 ? (r8 < r24 ? r8 : r24) : r8;
+  }
   a.w2_nld = ceil_div(S * a.w2_pw, 64);
   if (a.w2_nld > WG2_NLD) return SEGAN_EUNSUPPORTED;
   const size_t lds = (size_t)(2 * 128 * TK + 2 * (128 / U) * a.RLw) * sizeof(float);
   auto kern = wgrad2_kernel<U, XF>;
   static bool attr_done[16];
   static int occ_c[16];
+  static size_t occ_lds[16];
   const int d = wg_cur_device();
   if (!attr_done[d]) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done[d] = true;
+  }
+  if (occ_c[d] == 0 || occ_lds[d] != lds) {
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), 256,
                                                      lds) != hipSuccess || nb < 1)
       nb = 2;
     occ_c[d] = nb > 4 ? 4 : nb;
-    attr_done[d] = true;
+    occ_lds[d] = lds;
   }
   int tiles, nsplit, cps, nch;
   wgrad2_plan(a, U, occ_c[d], tiles, nsplit, cps, nch);
@@ -699,6 +714,8 @@ static int launch_wgrad2(WgradArgs& a, hipStream_t st, bool deterministic, float
     a.w2_slabs = slabs;
   }
   const int ncol = ceil_div(a.Cv, 128 / U), nrow = ceil_div(a.M, 128);
+  g_last_wgrad[0] = 2; g_last_wgrad[1] = tiles; g_last_wgrad[2] = nsplit; g_last_wgrad[3] = cps;
+  g_last_wgrad[4] = occ_c[d]; g_last_wgrad[5] = a.w2_nld;
   hipLaunchKernelGGL(kern, dim3(ncol, nrow, nsplit), dim3(256), lds, st, a);
   if (int e = segan_check_launch("wgrad2_kernel")) return e;
   if (deterministic) {
@@ -761,6 +778,8 @@ static int launch_wgrad_tile(WgradArgs& a, hipStream_t st, float* slabs, size_t 
     }
     a.w2_slabs = slabs;
   }
+  g_last_wgrad[0] = 1; g_last_wgrad[1] = tiles; g_last_wgrad[2] = nsplit; g_last_wgrad[3] = chunks_per;
+  g_last_wgrad[4] = 0; g_last_wgrad[5] = 0;
   hipLaunchKernelGGL(kern, dim3(ncol, nrow, nsplit), dim3(256), lds, st, a);
   if (int e = segan_check_launch("wgrad_kernel")) return e;
   if (slabs) {

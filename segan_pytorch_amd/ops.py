@@ -148,6 +148,14 @@ def last_corr_launch():
     return d
 
 
+def last_wgrad_launch():
+    """Diagnostics: how this thread's last fp32 weight gradient was launched."""
+    arr = (ctypes.c_int * 6)()
+    _lib.load().segan_debug_last_wgrad(arr)
+    return dict(zip(('kernel', 'tiles', 'splits', 'chunks_per_split', 'resident_per_cu', 'hi_loads'),
+                    list(arr)))
+
+
 def conv_pad(K, S):
     return layout.conv_pad(K, S)
 
