@@ -308,7 +308,7 @@ def main():
 
     # one rank per GPU: when nobody launched the ranks for us, do it ourselves
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
-        if args.gpus > torch.cuda.device_count():
+        if args.gpus > torch.cuda.device_count() and 'SEGAN_LOCAL_DEVICE' not in os.environ:
             raise SystemExit('--gpus {} but only {} GPU(s) visible'.format(args.gpus, torch.cuda.device_count()))
         import socket
         with socket.socket() as sk:
@@ -327,9 +327,11 @@ def main():
 
     from segan_pytorch_amd import ops as _ops
     _ops.set_precision(args.precision)
-    if args.gpus > torch.cuda.device_count():
+    if args.gpus > torch.cuda.device_count() and 'SEGAN_LOCAL_DEVICE' not in os.environ:
         raise SystemExit('--gpus {} but only {} GPU(s) visible'.format(args.gpus, torch.cuda.device_count()))
     rank, world, local = sdist.init_from_env()
+    if 'SEGAN_LOCAL_DEVICE' in os.environ:      # test hook: several ranks share one GPU (gloo)
+        local = int(os.environ['SEGAN_LOCAL_DEVICE'])
     if world != max(1, args.gpus):
         raise SystemExit('--gpus {} but WORLD_SIZE {}'.format(args.gpus, world))
     dev = torch.device('cuda', local if world > 1 else 0)

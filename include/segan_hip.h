@@ -261,6 +261,13 @@ int segan_l1_mean(const float* x, const float* y, float* loss, float* ws, int64_
 int segan_l1_bwd(const float* x, const float* y, const float* gout, float gscale, float* grad,
                  int64_t n, void* stream);
 
+/* F.mse_loss between two tensors (--reg_loss mse_loss, train.py:179, model.py:79): loss[0] =
+ * mean((x - y)^2) (ws: 1024 floats); grad = 2*(x - y)/n * gscale * (gout ? gout[0] : 1). */
+int segan_mse_mean(const float* x, const float* y, float* loss, float* ws, int64_t n,
+                   void* stream);
+int segan_mse_bwd(const float* x, const float* y, const float* gout, float gscale, float* grad,
+                  int64_t n, void* stream);
+
 /* ---- spectral normalisation ('snorm', modules.py:12-14, discriminator.py:118-121) -------
  * torch.nn.utils.spectral_norm with its defaults (one power iteration in training mode,
  * eps 1e-12) on a weight [A][Bd][K] viewed as a matrix with rows = dim 0 (Conv1d, Linear,

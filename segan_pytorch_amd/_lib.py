@@ -68,6 +68,8 @@ SIGNATURES = {
     'segan_mse_const': (c_int, [_P, c_float, _P, _P, _P, c_float, c_int, _P]),
     'segan_l1_bwd': (c_int, [_P, _P, _P, c_float, _P, c_int64, _P]),
     'segan_l1_mean': (c_int, [_P, _P, _P, _P, c_int64, _P]),
+    'segan_mse_mean': (c_int, [_P, _P, _P, _P, c_int64, _P]),
+    'segan_mse_bwd': (c_int, [_P, _P, _P, c_float, _P, c_int64, _P]),
     'segan_snorm_ws_floats': (c_size_t, [c_int, c_int, c_int, c_int]),
     'segan_snorm_fwd': (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, _P]),
     'segan_snorm_bwd': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
@@ -101,6 +103,14 @@ def load():
             'segan_pytorch_amd: {} not found. Build it with `make` (or '
             '`python -c "import __graft_entry__ as g; g.build()"`) at the repo root. '
             'There is no non-HIP fallback.'.format(LIB_PATH))
+    # torch bundles its own HIP runtime; it has to be up before this library (linked against
+    # /opt/rocm's) is mapped, otherwise the library's first launch finds no device
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:     # pragma: no cover
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)      # AttributeError if the symbol is missing

@@ -643,13 +643,17 @@ extern "C" int segan_bce_logits_const(const float* x, float target, float* loss,
   return segan_check_launch("bce_logits_const");
 }
 
+// SQ = false: sum |x - y| (F.l1_loss); SQ = true: sum (x - y)^2 (F.mse_loss, --reg_loss mse_loss)
+template <bool SQ>
 __global__ void l1_partial_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                   float* ws, size_t n) {
   __shared__ float sm[16];
   float r[1] = {0.f};
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
-       i += (size_t)gridDim.x * blockDim.x)
-    r[0] += fabsf(x[i] - y[i]);
+       i += (size_t)gridDim.x * blockDim.x) {
+    const float d = x[i] - y[i];
+    r[0] += SQ ? d * d : fabsf(d);
+  }
   block_sum<1>(r, sm);
   if (threadIdx.x == 0) ws[blockIdx.x] = r[0];
 }
@@ -666,10 +670,38 @@ extern "C" int segan_l1_mean(const float* x, const float* y, float* loss, float*
   SEGAN_REQUIRE(x && y && loss && ws && n > 0, "l1_mean: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   int blocks = (int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256);
-  hipLaunchKernelGGL(l1_partial_kernel, dim3(blocks), dim3(PW_THREADS), 0, st, x, y, ws, (size_t)n);
+  hipLaunchKernelGGL(l1_partial_kernel<false>, dim3(blocks), dim3(PW_THREADS), 0, st, x, y, ws, (size_t)n);
   hipLaunchKernelGGL(l1_final_kernel, dim3(1), dim3(PW_THREADS), 0, st, ws, loss, blocks,
                      1.0f / (float)n);
   return segan_check_launch("l1_mean");
+}
+
+extern "C" int segan_mse_mean(const float* x, const float* y, float* loss, float* ws, int64_t n,
+                              void* stream) {
+  SEGAN_REQUIRE(x && y && loss && ws && n > 0, "mse_mean: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  int blocks = (int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256);
+  hipLaunchKernelGGL(l1_partial_kernel<true>, dim3(blocks), dim3(PW_THREADS), 0, st, x, y, ws, (size_t)n);
+  hipLaunchKernelGGL(l1_final_kernel, dim3(1), dim3(PW_THREADS), 0, st, ws, loss, blocks,
+                     1.0f / (float)n);
+  return segan_check_launch("mse_mean");
+}
+
+__global__ void mse_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                               const float* gout, float gscale, float* __restrict__ grad, size_t n) {
+  const float g = 2.0f * gscale * (gout ? gout[0] : 1.0f) / (float)n;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x)
+    grad[i] = g * (x[i] - y[i]);
+}
+
+extern "C" int segan_mse_bwd(const float* x, const float* y, const float* gout, float gscale,
+                             float* grad, int64_t n, void* stream) {
+  SEGAN_REQUIRE(x && y && grad && n > 0, "mse_bwd: bad arguments");
+  int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+  hipLaunchKernelGGL(mse_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, gout,
+                     gscale, grad, (size_t)n);
+  return segan_check_launch("mse_bwd");
 }
 
 __global__ void l1_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,

@@ -570,6 +570,26 @@ class L1MeanFn(torch.autograd.Function):
         return gx, gy
 
 
+class MSEMeanFn(torch.autograd.Function):
+    """F.mse_loss(x, y) between two tensors (--reg_loss mse_loss; train.py:179, model.py:79)."""
+
+    @staticmethod
+    def forward(ctx, x, y):
+        x, y = x.contiguous(), y.contiguous()
+        ctx.save_for_backward(x, y)
+        return ops.mse_mean(x, y)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y = ctx.saved_tensors
+        gx = gy = None
+        if ctx.needs_input_grad[0]:
+            gx = ops.mse_bwd(x, y, gout=g.contiguous())
+        if ctx.needs_input_grad[1]:
+            gy = ops.mse_bwd(y, x, gout=g.contiguous())
+        return gx, gy
+
+
 class STFTPowL1Fn(torch.autograd.Function):
     """F.l1_loss(pow_db(STFT(x)), pow_db(STFT(y))) of the WSEGAN step (model.py:640-653):
     rectangular window `win` centred in n_fft, hop `hop`, normalized, reflect centre padding;

@@ -28,6 +28,10 @@ class BCEWithLogitsLoss(nn.Module):
 
 
 def mse_loss(input, target):
+    """F.mse_loss: against a constant label (number, or a filled label tensor of another
+    shape), or between two tensors of the same shape (--reg_loss mse_loss)."""
+    if torch.is_tensor(target) and target.shape == input.shape and target.numel() > 1:
+        return Fn.MSEMeanFn.apply(input, target)
     return MSELoss()(input, target)
 
 

@@ -96,9 +96,9 @@ class SEGAN(Model):
         self.save_path = opts.save_path
         self.preemph = opts.preemph
         reg = getattr(opts, 'reg_loss', 'l1_loss')
-        if reg != 'l1_loss':
-            raise NotImplementedError("reg_loss {!r}: only 'l1_loss' is implemented".format(reg))
-        self.reg_loss = losses.l1_loss
+        if reg not in ('l1_loss', 'mse_loss'):        # getattr(F, opts.reg_loss), model.py:79
+            raise NotImplementedError("reg_loss {!r}: 'l1_loss' and 'mse_loss' are implemented".format(reg))
+        self.reg_loss = losses.l1_loss if reg == 'l1_loss' else losses.mse_loss
         if generator is None:
             self.G = Generator(1, opts.genc_fmaps, opts.gkwidth, opts.genc_poolings,
                                opts.gdec_fmaps, opts.gdec_kwidth, opts.gdec_poolings,

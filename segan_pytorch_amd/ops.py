@@ -638,6 +638,27 @@ def l1_mean(x, y):
     return loss
 
 
+def mse_mean(x, y):
+    """mean((x - y)^2) of two tensors (F.mse_loss; --reg_loss mse_loss)."""
+    _chk(x, 'x')
+    _chk(y, 'y')
+    if x.shape != y.shape:
+        raise ValueError('mse_mean: shapes differ {} vs {}'.format(tuple(x.shape), tuple(y.shape)))
+    loss = torch.empty((), device=x.device, dtype=torch.float32)
+    ws = torch.empty(1024, device=x.device, dtype=torch.float32)
+    check(_lib.load().segan_mse_mean(_ptr(x), _ptr(y), _ptr(loss), _ptr(ws), x.numel(), _stream()),
+          'mse_mean')
+    return loss
+
+
+def mse_bwd(x, y, gout=None, gscale=1.0):
+    _chk(x, 'x')
+    grad = torch.empty_like(x)
+    check(_lib.load().segan_mse_bwd(_ptr(x), _ptr(y), _ptr(gout), float(gscale), _ptr(grad),
+                                    x.numel(), _stream()), 'mse_bwd')
+    return grad
+
+
 # ---- STFT power loss (model.py:640-653) ----------------------------------------------------
 _stft_basis_cache = {}
 
