@@ -257,6 +257,17 @@ def cpu_baseline(B=300, steps=2, dev=None):
     return out, parity
 
 
+def pmc_mfma_busy(family):
+    """MFMA-pipe busy fraction of a kernel family from the committed SQ counter passes
+    (profiles/r02_sq_counters.json, scripts/pmc_sq.sh): MFMA instructions x 64 cycles over the
+    SIMD-cycles of the launch."""
+    try:
+        d = json.load(open(os.path.join(ROOT, 'profiles', 'r02_sq_counters.json')))
+        return d['_summary'][family + '_mfma_pipe_busy_mean']
+    except Exception:
+        return None
+
+
 def pmc_traffic(kernel_prefix):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/r02_pmc_hbm_traffic.json: FETCH_SIZE and WRITE_SIZE in separate passes over this
@@ -466,6 +477,7 @@ def main():
             'step_tflops': gflop * value / 1e3,
             'step_frac_of_f32_mfma_peak': gflop * value / 1e3 / PEAK_F32_MFMA_TF / world,
             'step_hbm_gbs_algorithmic': MB_PER_CHUNK * value / 1e3 / world,
+            'step_frac_of_hbm_roofline': MB_PER_CHUNK * value / 1e3 / world / PEAK_HBM_GBS,
         }
         if timer is not None:
             s = timer.summary()
@@ -479,14 +491,16 @@ def main():
                                     'profiles/r02_pmc_hbm_traffic.json)',
                     'avg_launch_us': c['avg_us'], 'launches': c['launches'],
                     'gflop_per_launch': c['flops_per_launch'] / 1e9,
-                    'share_of_step_time': c['total_ms'] / (1e3 * dt)}
+                    'share_of_step_time': c['total_ms'] / (1e3 * dt),
+                    'mfma_pipe_busy_pmc': pmc_mfma_busy('corr2')}
             if 'wgrad' in s:
                 w = s['wgrad']
                 line['roofline_wgrad'] = {'bound': 'mfma', 'kernel': 'wgrad2_kernel',
                                           'achieved': w['tflops'], 'peak': PEAK_F32_MFMA_TF,
                                           'unit': 'TFLOP/s', 'frac': w['tflops'] / PEAK_F32_MFMA_TF,
                                           'avg_launch_us': w['avg_us'], 'launches': w['launches'],
-                                          'share_of_step_time': w['total_ms'] / (1e3 * dt)}
+                                          'share_of_step_time': w['total_ms'] / (1e3 * dt),
+                                          'mfma_pipe_busy_pmc': pmc_mfma_busy('wgrad2')}
         if modes:
             modes['note'] = ('same workload, contractions on the bf16 MFMA: bf16x3 = fp32 operands '
                              'split exactly into 3 bf16 planes, 6 partial products, fp32 accumulate '

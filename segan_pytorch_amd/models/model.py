@@ -426,10 +426,10 @@ class WSEGAN(SEGAN):
                 Genh, clean, min(Genh.size(-1), self.n_fft), 160, 320)
             G_cost = g_adv_loss + pow_loss
             if l1_weight > 0:
-                mask = torch.zeros(bsz, 1, Genh.size(2), device=Genh.device)
-                for utt_i, uttn in enumerate(uttname):
-                    if 'additive' in uttn:
-                        mask[utt_i, 0, :] = 1.
+                # model.py:655-662 builds the mask row by row on the device (one fill per
+                # utterance); here: one host vector, one copy, broadcast in the products
+                mask = torch.tensor([1.0 if 'additive' in uttn else 0.0 for uttn in uttname],
+                                    dtype=torch.float32).to(Genh.device, non_blocking=True).view(bsz, 1, 1)
                 den_loss = l1_weight * losses.l1_loss(Genh * mask, clean * mask)
                 G_cost = G_cost + den_loss
             else:
