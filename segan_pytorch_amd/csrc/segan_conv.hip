@@ -254,8 +254,8 @@ __device__ __forceinline__ bool tile_is_dead(const CorrArgs& a, int m0) {
   return false;
 }
 
-// The MFMA loop over one staged chunk, shared by both kernels.  Operands of step s+1 are read
-// from LDS before the MFMAs of step s are issued (two named register sets; everything is
+// The MFMA loop over one staged chunk, shared by both kernels.  Operands of step s+2 are read
+// from LDS before the MFMAs of step s are issued (three named register sets; everything is
 // unrolled so all indices are static); sched_barrier pins that order so the LDS latency of the
 // next operands is covered by the MFMAs instead of being exposed.
 template <int MB, int U, int KC, int NI, int NJ, bool SHIFT>
@@ -287,16 +287,24 @@ __device__ __forceinline__ void corr_mma_chunk(const float* Wl, const float* Il,
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[SHIFT ? i : 0][j], acc[i][j],
                                                          0, 0, 0);
   };
+  // operands are read TWO steps ahead of the MFMAs that use them (three register sets)
+  float av2[NI], bv2[NBI][NJ];
+  constexpr int NS = KC / 2;
   read_step(0, av0, bv0);
+  read_step(1, av1, bv1);
 #pragma unroll
-  for (int s = 0; s < KC / 2; s += 2) {
-    read_step(s + 1, av1, bv1);
+  for (int s = 0; s < NS; s += 3) {
+    if (s + 2 < NS) read_step(s + 2, av2, bv2);
     __builtin_amdgcn_sched_barrier(0);
     mma_step(av0, bv0);
     __builtin_amdgcn_sched_barrier(0);
-    if (s + 2 < KC / 2) read_step(s + 2, av0, bv0);
+    if (s + 3 < NS) read_step(s + 3, av0, bv0);
     __builtin_amdgcn_sched_barrier(0);
-    mma_step(av1, bv1);
+    if (s + 1 < NS) mma_step(av1, bv1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (s + 4 < NS) read_step(s + 4, av1, bv1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (s + 2 < NS) mma_step(av2, bv2);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
