@@ -34,6 +34,16 @@ def world_size():
     return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
 
 
+def _collectives_on():
+    """Do the gradient collectives run?  Yes with more than one rank; SEGAN_DP_SINGLE=1 (a test
+    hook) also issues them in an initialised ONE-rank group, which is how the RCCL code path —
+    async bucket all-reduces from inside the backward, the waits, the scale — is exercised on a
+    one-GPU box (tests/test_gpu_dist.py)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get('SEGAN_DP_SINGLE') == '1'
+
+
 def rank():
     return dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
 
@@ -45,7 +55,7 @@ def init_from_env(backend=None):
     ws = int(os.environ.get('WORLD_SIZE', '1'))
     rk = int(os.environ.get('RANK', '0'))
     lr = int(os.environ.get('LOCAL_RANK', '0'))
-    if ws <= 1:
+    if ws <= 1 and os.environ.get('SEGAN_DP_SINGLE') != '1':
         return 0, 1, lr
     # testing hooks: SEGAN_DIST_BACKEND=gloo and SEGAN_LOCAL_DEVICE=<i> let several ranks share
     # one GPU (RCCL refuses duplicate devices); never set in production
@@ -173,7 +183,7 @@ def arm(optimizer):
     """Announce that the next backward pass is the last one into `optimizer`'s gradients before
     its step: from here on ``grad_ready`` starts the all-reduce of every bucket that completes."""
     global _active
-    if world_size() <= 1:
+    if not _collectives_on():
         return
     _active = _reducer(optimizer)
     _active.arm()
@@ -193,7 +203,7 @@ def allreduce_grads(optimizer):
     """Average the gradients of every parameter the optimizer owns across ranks (waits for the
     buckets already in flight, sends the rest)."""
     global _active
-    if world_size() <= 1:
+    if not _collectives_on():
         return
     r = _reducer(optimizer)
     if _active is not None and _active is not r:
@@ -204,7 +214,7 @@ def allreduce_grads(optimizer):
 
 def broadcast_params(module, src=0):
     """Make every replica start from rank `src`'s weights and buffers."""
-    if world_size() <= 1:
+    if not _collectives_on():
         return
     with torch.no_grad():
         for t in list(module.parameters()) + list(module.buffers()):
@@ -230,7 +240,7 @@ def sync_bn_enabled():
     per-channel gradient sums (backward) are taken over the GLOBAL batch, so N ranks of batch
     b reproduce one process at batch N*b.  Default off: every replica normalises with its own
     batch, like the reference at its per-GPU batch size."""
-    return is_dist() and os.environ.get('SEGAN_SYNC_BN', '0') == '1'
+    return _collectives_on() and os.environ.get("SEGAN_SYNC_BN", "0") == "1"
 
 
 def bn_stats_sync(x, gamma, beta, eps, momentum, running_mean, running_var):
