@@ -20,6 +20,11 @@ segan_plus_b2.pt the default SEGAN+ net (ckpt_segan+/train.opts, seed 111) at B=
                  checksums/samples of every gradient.
 vanilla11_b8.pt  (python oracle/make_golden.py vanilla11) the original 11-layer stride-2 SEGAN
                  shape, one step at B=8, same content as segan_plus_b2.pt.
+tiny_variants.pt (python oracle/make_golden.py variants) one GAN step of the tiny net for every
+                 architecture switch train.py can reach that the headline nets do not use:
+                 --skip_type conv (concat and sum merges), stride-1 (pooling 1) layers in the
+                 encoder and the decoder (generator.py:171-176), a conv block as last decoder
+                 layer, --dpool_type conv / gmax / gavg (discriminator.py:122-137).
 """
 import json
 import os
@@ -228,6 +233,49 @@ def make_vanilla11(ref):
           sum(p.numel() for p in segan.G.parameters()), sum(p.numel() for p in segan.D.parameters()))
 
 
+VARIANTS = {
+    # GSkip with a k=11 conv on the skip path (generator.py:42-49), both merges
+    'skipconv_concat': dict(skip_type='conv', skip_merge='concat'),
+    'skipconv_sum': dict(skip_type='conv', skip_merge='sum'),
+    # stride-1 layers: GConv1DBlock pads (k//2, k//2) (modules.py:96-98); in the decoder a
+    # pooling of 1 builds a GConv1DBlock instead of a transposed conv (generator.py:171-176)
+    # and drops that level's skip (generator.py:212-213)
+    'pool1_mid': dict(genc_poolings=[4, 1, 4], z_len=64),
+    # a 4th decoder layer with pooling 1: the LAST block is a conv + PReLU, no Tanh
+    'pool1_last': dict(gdec_fmaps=[8, 4, 2, 1], gdec_poolings=[4, 4, 4, 1], gdec_kwidth=31),
+    # discriminator heads other than the dense one
+    'dpool_conv': dict(dpool_type='conv'),
+    'dpool_gmax': dict(dpool_type='gmax'),
+    'dpool_gavg': dict(dpool_type='gavg'),
+}
+
+
+def make_variants(ref):
+    out = {}
+    for i, (name, delta) in enumerate(VARIANTS.items()):
+        o = tiny_opts()
+        delta = dict(delta)
+        z_len = delta.pop('z_len', 16)
+        o.update(dict(genc_fmaps=[4, 8, 16], denc_fmaps=[4, 8, 16], z_dim=16))   # small fixture
+        o.update(delta)
+        seed_all(200 + i)
+        segan = ref.SEGAN(SimpleNamespace(**o))
+        clean, noisy = synth(3, 1024, 40 + i)
+        clean, noisy = clean.unsqueeze(1), noisy.unsqueeze(1)
+        z = torch.randn(3, 16, z_len, generator=torch.Generator().manual_seed(60 + i))
+        rs = 80 + i
+        fx = {'opts': o, 'G0': clone_sd(segan.G), 'D0': clone_sd(segan.D), 'clean': clean,
+              'noisy': noisy, 'z': z, 'roll_seed': rs,
+              'rolls': ref_harness.ReplayRandom(rs).rolls(3, o['phase_shift'], 3)}
+        fx.update(manual_step(ref, segan, clean, noisy, z, rs))
+        out[name] = fx
+        print(name, 'Genh', tuple(fx['Genh'].shape), 'd_real', tuple(fx['d_real'].shape),
+              float(fx['g_l1_loss']), sorted(k for k in fx['G0'] if 'alpha' in k)[:2],
+              sorted(k for k in fx['D0'] if not k.startswith('enc_blocks')))
+    torch.save(out, os.path.join(OUT, 'tiny_variants.pt'))
+    print('tiny_variants.pt done')
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = ref_harness.import_reference()
@@ -238,6 +286,9 @@ def main():
         return
     if len(sys.argv) > 1 and sys.argv[1] == 'vanilla11':
         make_vanilla11(ref)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == 'variants':
+        make_variants(ref)
         return
 
     # ---------------- tiny_step ----------------

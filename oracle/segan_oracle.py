@@ -9,9 +9,12 @@ it can be fed the weights of the reference modules or of the HIP modules alike:
 
 * ``gconv_block``        segan/models/modules.py:91-105   (reflect pad, Conv1d, norm, PReLU)
 * ``gdeconv_block``      segan/models/modules.py:135-141  (ConvTranspose1d, trim, PReLU/Tanh)
-* ``generator_forward``  segan/models/generator.py:180-230 (+ GSkip.forward 64-78)
+* ``generator_forward``  segan/models/generator.py:180-230 (+ GSkip.forward 64-78, incl. the
+                         conv skip of :42-49, the sum merge and pooling-1 conv decoder blocks
+                         of :171-176)
 * ``roll``               segan/models/discriminator.py:160-172 (phase shift)
-* ``discriminator_forward`` segan/models/discriminator.py:150-194
+* ``discriminator_forward`` segan/models/discriminator.py:150-194 (heads 'none', 'conv', 'gmax',
+                         'gavg' of :107-137)
 * ``spectral_weight``    torch.nn.utils.spectral_norm as used by modules.py:12-14 and
                          discriminator.py:118-121 ('snorm')
 * ``gan_step``           segan/models/model.py:292-321 with nn.MSELoss (train.py:94),
@@ -105,8 +108,12 @@ def _count(sd, prefix):
     return n
 
 
-def generator_forward(sd, x, z, strides, dec_strides=None, ret_hid=False, training=True):
-    """generator.py:180-230 with skip_type alpha, skip_merge concat."""
+def generator_forward(sd, x, z, strides, dec_strides=None, ret_hid=False, training=True,
+                      skip_merge='concat'):
+    """generator.py:180-230.  The architecture is read off the state_dict: a level has a skip
+    when ``alpha_<l>.skip_k`` (alpha / constant) or ``alpha_<l>.skip_k.weight`` (conv skip,
+    generator.py:42-49) exists; a decoder block is a transposed conv (``deconv``) or, for a
+    pooling of 1, a GConv1DBlock (``conv``, generator.py:171-176)."""
     n_enc = _count(sd, 'enc_blocks')
     n_dec = _count(sd, 'dec_blocks')
     dec_strides = dec_strides or list(strides)
@@ -117,7 +124,8 @@ def generator_forward(sd, x, z, strides, dec_strides=None, ret_hid=False, traini
         p = 'enc_blocks.{}.'.format(l)
         hi, lin = gconv_block(hi, _weight(sd, p + 'conv.', 0, training), sd.get(p + 'conv.bias'),
                               sd[p + 'act.weight'], strides[l])
-        if l < n_enc - 1 and 'alpha_{}.skip_k'.format(l) in sd:
+        if l < n_enc - 1 and ('alpha_{}.skip_k'.format(l) in sd or
+                              'alpha_{}.skip_k.weight'.format(l) in sd):
             skips[l] = lin                       # the PRE-activation (generator.py:185,191)
         hall['enc_{}'.format(l)] = hi
     if z is not None:
@@ -126,21 +134,34 @@ def generator_forward(sd, x, z, strides, dec_strides=None, ret_hid=False, traini
     enc_idx = n_enc - 1
     for l in range(n_dec):
         if enc_idx in skips and dec_strides[l] > 1:
-            alpha = sd['alpha_{}.skip_k'.format(enc_idx)]
-            sk = alpha.repeat(hi.size(0), 1, skips[enc_idx].size(2)) * skips[enc_idx]
-            hi = torch.cat((hi, sk), dim=1)      # GSkip concat, generator.py:64-76
+            hj = skips[enc_idx]
+            if 'alpha_{}.skip_k.weight'.format(enc_idx) in sd:      # GSkip 'conv'
+                wk = sd['alpha_{}.skip_k.weight'.format(enc_idx)]
+                kw = wk.shape[2]
+                sk = F.conv1d(hj, wk, sd.get('alpha_{}.skip_k.bias'.format(enc_idx)), stride=1,
+                              padding=kw // 2 if kw > 1 else 0)
+            else:
+                alpha = sd['alpha_{}.skip_k'.format(enc_idx)]
+                sk = alpha.repeat(hi.size(0), 1, hj.size(2)) * hj
+            # GSkip merge, generator.py:64-76
+            hi = torch.cat((hi, sk), dim=1) if skip_merge == 'concat' else sk + hi
         p = 'dec_blocks.{}.'.format(l)
-        last = (p + 'act.weight') not in sd
-        hi = gdeconv_block(hi, _weight(sd, p + 'deconv.', 1, training), sd[p + 'deconv.bias'],
-                           sd.get(p + 'act.weight'), dec_strides[l], tanh=last)
+        if p + 'conv.weight' in sd or p + 'conv.weight_orig' in sd:
+            hi, _ = gconv_block(hi, _weight(sd, p + 'conv.', 0, training), sd.get(p + 'conv.bias'),
+                                sd[p + 'act.weight'], dec_strides[l])
+        else:
+            last = (p + 'act.weight') not in sd
+            hi = gdeconv_block(hi, _weight(sd, p + 'deconv.', 1, training), sd[p + 'deconv.bias'],
+                               sd.get(p + 'act.weight'), dec_strides[l], tanh=last)
         enc_idx -= 1
         hall['dec_{}'.format(l)] = hi
     return (hi, hall) if ret_hid else hi
 
 
-def discriminator_forward(sd, x, rolls, strides, training=True, ret_act=False):
-    """discriminator.py:150-194 (pool_type 'none', norm 'bnorm' or none).  `sd` must hold
-    the BN running buffers when bnorm; they are updated in place like nn.BatchNorm1d."""
+def discriminator_forward(sd, x, rolls, strides, training=True, ret_act=False, pool_type='none'):
+    """discriminator.py:150-194 (norm 'bnorm', 'snorm' or none; heads 'none', 'conv', 'gmax',
+    'gavg').  `sd` must hold the BN running buffers when bnorm; they are updated in place like
+    nn.BatchNorm1d."""
     n = _count(sd, 'enc_blocks')
     h = x
     acts = {}
@@ -155,12 +176,25 @@ def discriminator_forward(sd, x, rolls, strides, training=True, ret_act=False):
         h, _ = gconv_block(h, _weight(sd, p + 'conv.', 0, training), sd.get(p + 'conv.bias'),
                            sd[p + 'act.weight'], strides[l], bn=bn, training=training)
         acts['h_{}'.format(l)] = h
-    h = h.view(h.size(0), -1)
-    h = F.prelu(F.linear(h, _weight(sd, 'fc.0.', 0, training), sd['fc.0.bias']),
-                _weight(sd, 'fc.1.', 0, training))
-    h = F.prelu(F.linear(h, _weight(sd, 'fc.2.', 0, training), sd['fc.2.bias']),
-                _weight(sd, 'fc.3.', 0, training))
-    y = F.linear(h, _weight(sd, 'fc.4.', 0, training), sd['fc.4.bias'])
+    if pool_type == 'none':
+        h = h.view(h.size(0), -1)
+        h = F.prelu(F.linear(h, _weight(sd, 'fc.0.', 0, training), sd['fc.0.bias']),
+                    _weight(sd, 'fc.1.', 0, training))
+        h = F.prelu(F.linear(h, _weight(sd, 'fc.2.', 0, training), sd['fc.2.bias']),
+                    _weight(sd, 'fc.3.', 0, training))
+        y = F.linear(h, _weight(sd, 'fc.4.', 0, training), sd['fc.4.bias'])
+    else:
+        if pool_type == 'conv':                  # discriminator.py:122-127,175-179
+            h = F.conv1d(h, _weight(sd, 'pool_conv.', 0, training), sd['pool_conv.bias'])
+            h = h.view(h.size(0), -1)
+            acts['avg_conv_h'] = h
+        elif pool_type == 'gmax':                # AdaptiveMaxPool1d(1), :128-132,183-186
+            h = h.max(dim=2)[0]
+        elif pool_type == 'gavg':                # AdaptiveAvgPool1d(1), :133-137,187-190
+            h = h.mean(dim=2)
+        else:
+            raise ValueError('pool_type {!r}'.format(pool_type))
+        y = F.linear(h, _weight(sd, 'fc.', 0, training), sd['fc.bias'])
     acts['logit'] = y
     return (y, acts) if ret_act else y
 
@@ -189,18 +223,22 @@ def rmsprop_update(p, g, sq, lr, alpha=0.99, eps=1e-8):
 
 
 def gan_step(g_sd, d_sd, clean, noisy, z, rolls3, strides, l1_weight=100.0, lr=5e-5,
-             g_sq=None, d_sq=None, update=True):
+             g_sq=None, d_sq=None, update=True, dec_strides=None, d_strides=None,
+             skip_merge='concat', pool_type='none'):
     """One SEGAN step, model.py:292-321.  rolls3 = three roll lists (D real, D fake,
     D fake-for-G).  Returns a dict with outputs, losses, gradients and (when `update`)
     the updated parameters / RMSprop state."""
     G = _leafs(g_sd)
     D = _leafs(d_sd)
     out = {}
+    gen = lambda: generator_forward(G, noisy, z, strides, dec_strides, skip_merge=skip_merge)
+    ds = d_strides or strides
+    disc = lambda x, r: discriminator_forward(D, x, r, ds, pool_type=pool_type)
     # (1)+(2) discriminator update
-    Genh = generator_forward(G, noisy, z, strides)
-    d_real = discriminator_forward(D, torch.cat((clean, noisy), 1), rolls3[0], strides)
+    Genh = gen()
+    d_real = disc(torch.cat((clean, noisy), 1), rolls3[0])
     d_real_loss = F.mse_loss(d_real.view(-1), torch.ones(clean.size(0), dtype=clean.dtype))
-    d_fake = discriminator_forward(D, torch.cat((Genh.detach(), noisy), 1), rolls3[1], strides)
+    d_fake = disc(torch.cat((Genh.detach(), noisy), 1), rolls3[1])
     d_fake_loss = F.mse_loss(d_fake.view(-1), torch.zeros(clean.size(0), dtype=clean.dtype))
     dkeys = [k for k in D if _is_param(k)]
     dgr = torch.autograd.grad(d_real_loss + d_fake_loss, [D[k] for k in dkeys])
@@ -216,11 +254,15 @@ def gan_step(g_sd, d_sd, clean, noisy, z, rolls3, strides, l1_weight=100.0, lr=5
             for k, g in zip(dkeys, dgr):
                 rmsprop_update(D[k], g, d_sq[k], lr)
     # (3) generator update through the updated D
-    d_fake_ = discriminator_forward(D, torch.cat((Genh, noisy), 1), rolls3[2], strides)
+    d_fake_ = disc(torch.cat((Genh, noisy), 1), rolls3[2])
     g_adv = F.mse_loss(d_fake_.view(-1), torch.ones(clean.size(0), dtype=clean.dtype))
     g_l1 = l1_weight * F.l1_loss(Genh, clean)
     gkeys = [k for k in G if G[k].requires_grad]
-    ggr = torch.autograd.grad(g_adv + g_l1, [G[k] for k in gkeys])
+    ggr = torch.autograd.grad(g_adv + g_l1, [G[k] for k in gkeys], allow_unused=True)
+    # a skip the forward never takes (pooling-1 decoder level) has no gradient: like
+    # torch.optim, which skips parameters whose .grad is None
+    gkeys = [k for k, g in zip(gkeys, ggr) if g is not None]
+    ggr = [g for g in ggr if g is not None]
     out['d_fake_'] = d_fake_.detach()
     out['g_adv_loss'] = g_adv.detach()
     out['g_l1_loss'] = g_l1.detach()

@@ -45,6 +45,21 @@ def tiny_wsegan2():
     return load_golden('tiny_wsegan2.pt')
 
 
+@pytest.fixture(scope='session')
+def tiny_variants():
+    return load_golden('tiny_variants.pt')
+
+
+VARIANT_NAMES = ('skipconv_concat', 'skipconv_sum', 'pool1_mid', 'pool1_last', 'dpool_conv',
+                 'dpool_gmax', 'dpool_gavg')
+
+
+def oracle_kwargs(opts):
+    """oracle.gan_step / generator_forward keyword arguments for a train.py option dict."""
+    return dict(dec_strides=opts.get('gdec_poolings') or None, d_strides=opts['denc_poolings'],
+                skip_merge=opts['skip_merge'], pool_type=opts['dpool_type'])
+
+
 def draw_rolls(n_layers, phase_shift):
     """The python-`random` draws of one Discriminator.forward (discriminator.py:159-163)."""
     import random

@@ -68,3 +68,35 @@ def test_train_wsegan_snorm_from_a_pcm_shard(tmp_path):
     assert out.returncode == 0, out.stderr[-2000:]
     names = os.listdir(ck)
     assert any(n_.startswith('weights_EOE_G-Generator-') for n_ in names)
+
+
+def test_train_from_wav_dirs_with_a_validation_set(tmp_path):
+    """train.py --clean_trainset/--noisy_trainset + --clean_valset/--noisy_valset (reference
+    train.py:70-98): the per-epoch validation runs on the device (segmental SNR) and the best
+    checkpoint is saved."""
+    rng = np.random.default_rng(2)
+    dirs = {}
+    for split in ('tr', 'va'):
+        cd, nd = tmp_path / (split + '_clean'), tmp_path / (split + '_noisy')
+        cd.mkdir()
+        nd.mkdir()
+        for i in range(3):
+            c = (rng.standard_normal(5000) * 4000).astype(np.int16)
+            wavfile.write(str(cd / 'u{}.wav'.format(i)), 16000, c)
+            wavfile.write(str(nd / 'u{}.wav'.format(i)), 16000,
+                          (c + rng.standard_normal(5000) * 500).astype(np.int16))
+        dirs[split] = (str(cd), str(nd))
+    ck = str(tmp_path / 'ckpt')
+    cmd = [sys.executable, os.path.join(ROOT, 'train.py'), '--save_path', ck,
+           '--clean_trainset', dirs['tr'][0], '--noisy_trainset', dirs['tr'][1],
+           '--clean_valset', dirs['va'][0], '--noisy_valset', dirs['va'][1],
+           '--cache_dir', str(tmp_path / 'cache'),
+           '--batch_size', '4', '--epoch', '2', '--save_freq', '50', '--no_train_gen',
+           '--genc_fmaps', '8', '16', '32', '--denc_fmaps', '8', '16', '32', '--genc_poolings',
+           '4', '4', '4', '--denc_poolings', '4', '4', '4', '--z_dim', '32', '--slice_size', '1024',
+           '--num_workers', '0']
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-1000:] + out.stderr[-2000:]
+    assert 'Val obj (SSNR) improved' in out.stdout
+    names = os.listdir(ck)
+    assert any('best' in n_.lower() for n_ in names), names

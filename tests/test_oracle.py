@@ -6,7 +6,9 @@ from types import SimpleNamespace
 import torch
 
 import segan_oracle as O
-from conftest import max_rel
+import pytest
+
+from conftest import VARIANT_NAMES, max_rel, oracle_kwargs
 
 TOL = 2e-5   # fp32 restatement vs fp32 reference modules: same ops, same order
 
@@ -34,7 +36,7 @@ def test_tiny_forward_hidden(tiny_step):
 def _check_step(fx, tol=TOL, step_tol=2e-6):
     st = fx['opts']['genc_poolings']
     res = O.gan_step(fx['G0'], fx['D0'], fx['clean'], fx['noisy'], fx['z'], fx['rolls'], st,
-                     l1_weight=100.0, lr=5e-5)
+                     l1_weight=100.0, lr=5e-5, **oracle_kwargs(fx['opts']))
     for k in ('Genh', 'd_real', 'd_fake', 'd_fake_', 'd_real_loss', 'd_fake_loss', 'g_adv_loss',
               'g_l1_loss'):
         assert max_rel(res[k], fx[k]) < tol, k
@@ -59,6 +61,14 @@ def test_tiny_step(tiny_step):
 
 def test_tiny_stride2_step(tiny_s2):
     _check_step(tiny_s2)
+
+
+@pytest.mark.parametrize('name', VARIANT_NAMES)
+def test_tiny_architecture_variants(tiny_variants, name):
+    """--skip_type conv, pooling-1 layers, a conv block as last decoder layer, --dpool_type
+    conv / gmax / gavg: one step of the real reference each (oracle/make_golden.py variants).
+    The small heads leave more of the first RMSprop step in the ill-conditioned regime."""
+    _check_step(tiny_variants[name], step_tol=1e-5)
 
 
 def test_tiny_spectral_norm_step(tiny_snorm):

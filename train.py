@@ -176,14 +176,23 @@ def main(opts):
     dloader = DataLoader(dset, batch_size=opts.batch_size, shuffle=(sampler is None),
                          sampler=sampler, num_workers=workers, pin_memory=pin,
                          collate_fn=collate, drop_last=(world > 1))
+    va_dloader = None
     if opts.clean_valset is not None:
-        raise NotImplementedError('validation (CompositeEval / PESQ binary) is outside the '
-                                  'accelerated path')
+        # reference train.py:70-91: one pass over a batch of 300 validation slices per epoch.  The
+        # objective here is the segmental SNR, computed on the device (segan_ssnr); the reference's
+        # COVL / PESQ terms need the external PESQ binary and are outside the accelerated path.
+        va_dset = SEDataset(opts.clean_valset, opts.noisy_valset, opts.preemph,
+                            cache_dir=opts.cache_dir, split='valid', stride=opts.data_stride,
+                            slice_size=opts.slice_size, max_samples=opts.max_samples, verbose=True,
+                            preemph_norm=opts.preemph_norm)
+        va_dloader = DataLoader(va_dset, batch_size=300, shuffle=False,
+                                num_workers=opts.num_workers, pin_memory=True,
+                                collate_fn=collate_fn)
     # per-rank host RNG streams for z and the phase shifts
     random.seed(opts.seed + rank)
     torch.manual_seed(opts.seed + rank)
     segan.train(opts, dloader, losses.MSELoss(), opts.l1_weight, opts.l1_dec_step,
-                opts.l1_dec_epoch, opts.save_freq, va_dloader=None, device=device)
+                opts.l1_dec_epoch, opts.save_freq, va_dloader=va_dloader, device=device)
 
 
 if __name__ == '__main__':
