@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SEGAN_ABI_VERSION 7
+#define SEGAN_ABI_VERSION 8
 
 #define SEGAN_PAD_REFLECT 0
 #define SEGAN_PAD_ZERO 1
@@ -260,6 +260,15 @@ int segan_l1_mean(const float* x, const float* y, float* loss, float* ws, int64_
 /* grad = sign(x - y) / n * gscale * (gout ? gout[0] : 1)   (torch.sign: sign(0) = 0). */
 int segan_l1_bwd(const float* x, const float* y, const float* gout, float gscale, float* grad,
                  int64_t n, void* stream);
+
+/* Global pooling over time of x[rows][L] (rows = B*C), the 'gmax' / 'gavg' discriminator heads
+ * (discriminator.py:128-137,183-190).  mode 0: y[row] = max, idx[row] = the FIRST position
+ * attaining it; mode 1: y[row] = mean (idx unused, may be NULL).  bwd: dx[row][t] =
+ * (t == idx[row]) ? dy[row] : 0, or dy[row] / L. */
+int segan_pool_time_fwd(const float* x, float* y, int* idx, int rows, int L, int mode,
+                        void* stream);
+int segan_pool_time_bwd(const float* dy, const int* idx, float* dx, int rows, int L, int mode,
+                        void* stream);
 
 /* F.mse_loss between two tensors (--reg_loss mse_loss, train.py:179, model.py:79): loss[0] =
  * mean((x - y)^2) (ws: 1024 floats); grad = 2*(x - y)/n * gscale * (gout ? gout[0] : 1). */

@@ -14,7 +14,7 @@ PAD_REFLECT = 0
 PAD_ZERO = 1
 ACT_NONE = 0
 ACT_TANH = 1
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class SeganSrc(Structure):
@@ -68,6 +68,8 @@ SIGNATURES = {
     'segan_mse_const': (c_int, [_P, c_float, _P, _P, _P, c_float, c_int, _P]),
     'segan_l1_bwd': (c_int, [_P, _P, _P, c_float, _P, c_int64, _P]),
     'segan_l1_mean': (c_int, [_P, _P, _P, _P, c_int64, _P]),
+    'segan_pool_time_fwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
+    'segan_pool_time_bwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
     'segan_mse_mean': (c_int, [_P, _P, _P, _P, c_int64, _P]),
     'segan_mse_bwd': (c_int, [_P, _P, _P, c_float, _P, c_int64, _P]),
     'segan_snorm_ws_floats': (c_size_t, [c_int, c_int, c_int, c_int]),

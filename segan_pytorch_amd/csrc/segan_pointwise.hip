@@ -794,6 +794,92 @@ extern "C" int segan_adam_step(float* p, const float* g, float* m, float* v, flo
   return segan_check_launch("adam_step");
 }
 
+// ---------------------------------------------------------------------------------
+// global pooling over time: the 'gmax' / 'gavg' discriminator heads
+// (discriminator.py:128-137,183-190: AdaptiveMaxPool1d(1) / AdaptiveAvgPool1d(1))
+// ---------------------------------------------------------------------------------
+// one wavefront per row of [rows][L]; MODE 0: max and the FIRST position that attains it
+// (where the gradient goes), MODE 1: mean
+template <int MODE>
+__global__ void pool_time_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                 int* __restrict__ idx, int rows, int L) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + (size_t)row * L;
+  if (MODE == 0) {
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int t = lane; t < L; t += 64) {
+      const float v = xr[t];
+      if (v > best || bi == 0x7fffffff) { best = v; bi = t; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(best, o);
+      const int oi = __shfl_xor(bi, o);
+      if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > best || (ov == best && oi < bi))) {
+        best = ov;
+        bi = oi;
+      }
+    }
+    if (lane == 0) {
+      y[row] = best;
+      idx[row] = bi;
+    }
+  } else {
+    float s = 0.0f;
+    for (int t = lane; t < L; t += 64) s += xr[t];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) y[row] = s / (float)L;
+  }
+}
+
+template <int MODE>
+__global__ void pool_time_bwd_kernel(const float* __restrict__ dy, const int* __restrict__ idx,
+                                     float* __restrict__ dx, int rows, int L) {
+  const size_t n = (size_t)rows * L;
+  const float invL = 1.0f / (float)L;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int row = (int)(i / L);
+    const int t = (int)(i - (size_t)row * L);
+    dx[i] = MODE == 0 ? (t == idx[row] ? dy[row] : 0.0f) : dy[row] * invL;
+  }
+}
+
+extern "C" int segan_pool_time_fwd(const float* x, float* y, int* idx, int rows, int L, int mode,
+                                   void* stream) {
+  SEGAN_REQUIRE(x && y && rows > 0 && L > 0, "pool_time_fwd: bad arguments");
+  SEGAN_REQUIRE(mode == 0 || mode == 1, "pool_time_fwd: mode must be 0 (max) or 1 (mean)");
+  SEGAN_REQUIRE(mode == 1 || idx, "pool_time_fwd: max pooling needs idx");
+  const dim3 grid(ceil_div(rows, 4));
+  if (mode == 0)
+    hipLaunchKernelGGL(pool_time_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, x, y, idx,
+                       rows, L);
+  else
+    hipLaunchKernelGGL(pool_time_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, x, y, idx,
+                       rows, L);
+  return segan_check_launch("pool_time_fwd");
+}
+
+extern "C" int segan_pool_time_bwd(const float* dy, const int* idx, float* dx, int rows, int L,
+                                   int mode, void* stream) {
+  SEGAN_REQUIRE(dy && dx && rows > 0 && L > 0, "pool_time_bwd: bad arguments");
+  SEGAN_REQUIRE(mode == 0 || mode == 1, "pool_time_bwd: mode must be 0 (max) or 1 (mean)");
+  SEGAN_REQUIRE(mode == 1 || idx, "pool_time_bwd: max pooling needs idx");
+  const size_t n = (size_t)rows * L;
+  const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+  if (mode == 0)
+    hipLaunchKernelGGL(pool_time_bwd_kernel<0>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       dy, idx, dx, rows, L);
+  else
+    hipLaunchKernelGGL(pool_time_bwd_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       dy, idx, dx, rows, L);
+  return segan_check_launch("pool_time_bwd");
+}
+
 __global__ void fill_kernel(float* p, float value, size_t n) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
        i += (size_t)gridDim.x * blockDim.x)

@@ -135,6 +135,21 @@ class _Weights(object):
         ops.snorm_bwd(tmp, mod.weight_orig.detach(), u, v, sigma, dim, grad_buf(mod.weight_orig))
 
 
+def _skip_conv_bwd(gskip, dsk, aj):
+    """Backward of GSkip 'conv' (generator.py:42-49,65-66), sk = conv1d(aj, Wk, bk, stride 1,
+    zero padding kw//2): accumulates dWk / dbk, returns the gradient w.r.t. aj.  The data
+    gradient of a stride-1 zero-padded conv is the same kernel run with the weight transposed
+    and flipped (padding kw - 1 - kw//2)."""
+    mod = gskip.skip_k
+    kw = mod.kernel_size[0]
+    if mod.bias is not None and mod.bias.requires_grad:
+        ops.act_bwd(dsk, dsk, dbias=grad_buf(mod.bias))          # dbk += sum over (b, t)
+    if mod.weight.requires_grad:
+        ops.wgrad(Src(dsk), Src(aj), grad_buf(mod.weight), kw, 1, kw // 2, PAD_ZERO)
+    wt = mod.weight.detach().transpose(0, 1).flip(2).contiguous()
+    return ops.conv1d_fwd(Src(dsk), wt, None, 1, pad_mode=PAD_ZERO, padL=kw - 1 - kw // 2)
+
+
 # =====================================================================================
 # Generator
 # =====================================================================================
@@ -164,36 +179,54 @@ class GeneratorFn(torch.autograd.Function):
         a_dec, src_dec = [], []
         enc_idx = n_enc - 1
         for li, blk in enumerate(dec):
+            is_conv = hasattr(blk, 'conv')       # pooling 1: a GConv1DBlock (generator.py:171-176)
             if li > 0:
                 prev = a_dec[-1]
                 s_prev = dec[li - 1].act.weight
                 if gen.skip and enc_idx in gen.skips and gen.dec_poolings[li] > 1:
                     gskip = gen.skips[enc_idx]['alpha']
-                    alpha = gskip.skip_k
                     aj = a_enc[enc_idx]
+                    ones_j = _ones(aj.shape[1], aj)
+                    if gskip.skip_type == 'conv':
+                        # GSkip 'conv' (generator.py:42-49,65-66): a stride-1 zero-padded conv of
+                        # the encoder's pre-activation, materialised; the merge stays fused
+                        kw = gskip.skip_k.kernel_size[0]
+                        sk = ops.conv1d_fwd(Src(aj), W.get(gskip.skip_k), gskip.skip_k.bias, 1,
+                                            pad_mode=PAD_ZERO, padL=kw // 2, pack=gskip._pack)
+                        scale_j = ones_j
+                    else:
+                        sk = aj
+                        scale_j = gskip.skip_k
                     if gskip.merge_mode == 'concat':
-                        src = Src(prev, aj,
-                                  scale=_cat(_ones(prev.shape[1], prev), alpha),
-                                  slope=_cat(s_prev, _ones(aj.shape[1], aj)))
+                        src = Src(prev, sk,
+                                  scale=_cat(_ones(prev.shape[1], prev), scale_j),
+                                  slope=_cat(s_prev, ones_j))
                     else:   # 'sum' (generator.py:71-73): prelu(prev) + alpha*a_j, materialised
-                        src = Src(ops.sum_skip(prev, s_prev, aj, alpha.detach().reshape(-1)))
+                        src = Src(ops.sum_skip(prev, s_prev, sk, scale_j.detach().reshape(-1)))
                         src.sum_of = True
                 else:
                     src = Src(prev, slope=s_prev)
-            act = ACT_TANH if blk.is_tanh else ACT_NONE
-            a = ops.deconv1d_fwd(src, W.get(blk.deconv), blk.deconv.bias, blk.stride, act,
-                                 pack=blk._pack)
+            if is_conv:
+                a = ops.conv1d_fwd(src, W.get(blk.conv), blk.conv.bias, blk.stride,
+                                   pack=blk._pack)
+            else:
+                act = ACT_TANH if blk.is_tanh else ACT_NONE
+                a = ops.deconv1d_fwd(src, W.get(blk.deconv), blk.deconv.bias, blk.stride, act,
+                                     pack=blk._pack)
             src_dec.append(src)
             a_dec.append(a)
             enc_idx -= 1
-        y = a_dec[-1]
+        last_conv = hasattr(dec[-1], 'conv')
+        # a conv block as last layer ends in its PReLU, not in a Tanh
+        y = ops.affine_prelu(a_dec[-1], slope=dec[-1].act.weight) if last_conv else a_dec[-1]
         ctx.gen = gen
         ctx.set_materialize_grads(False)
         ctx.x_needs = x.requires_grad
         # the output goes through save_for_backward (no ctx -> y -> grad_fn -> ctx cycle that a
         # never-backpropagated grad-mode forward would leak); the rest are plain intermediates
         ctx.save_for_backward(y)
-        ctx.state = (x, z, a_enc, src_enc, a_dec[:-1], src_dec, W)
+        ctx.last_conv = last_conv
+        ctx.state = (x, z, a_enc, src_enc, a_dec if last_conv else a_dec[:-1], src_dec, W)
         hid = None
         if want_hid:
             hid = {}
@@ -202,7 +235,7 @@ class GeneratorFn(torch.autograd.Function):
             if not gen.no_z:
                 hid['enc_zc'] = torch.cat((z, hid['enc_{}'.format(n_enc - 1)]), dim=1)
             for i, blk in enumerate(dec):
-                hid['dec_{}'.format(i)] = (a_dec[i] if blk.is_tanh else
+                hid['dec_{}'.format(i)] = (a_dec[i] if getattr(blk, 'is_tanh', False) else
                                            ops.affine_prelu(a_dec[i], slope=blk.act.weight))
         ctx.mark_non_differentiable(*([] if hid is None else list(hid.values())))
         if hid is None:
@@ -213,7 +246,7 @@ class GeneratorFn(torch.autograd.Function):
     def backward(ctx, dy, *unused):
         gen = ctx.gen
         x, z, a_enc, src_enc, a_dec, src_dec, W = ctx.state
-        a_dec = list(a_dec) + [ctx.saved_tensors[0]]
+        a_dec = list(a_dec) if ctx.last_conv else list(a_dec) + [ctx.saved_tensors[0]]
         enc, dec = list(gen.enc_blocks), list(gen.dec_blocks)
         n_enc, n_dec = len(enc), len(dec)
         if dy is None:
@@ -221,26 +254,39 @@ class GeneratorFn(torch.autograd.Function):
             return (None,) * len(ctx.needs_input_grad)
         dy = dy.contiguous()
         dh = dy
-        dskip = {}          # enc index -> gradient w.r.t. alpha * a_enc
+        dskip = {}          # enc index -> gradient w.r.t. the skip tensor (alpha*a_enc or conv(a_enc))
         dh_last_enc = None  # gradient w.r.t. h of the last encoder layer
         # ---- decoder, last to first ----
         da = None
         for li in range(n_dec - 1, -1, -1):
             blk = dec[li]
-            w = W.get(blk.deconv)
+            is_conv = hasattr(blk, 'conv')
+            mod = blk.conv if is_conv else blk.deconv
+            w = W.get(mod)
             K, S = blk.kwidth, blk.stride
-            if blk.is_tanh:
-                da = ops.tanh_bwd(a_dec[li], dy, dbias=_gb(blk.deconv.bias))
+            if not is_conv and blk.is_tanh:
+                da = ops.tanh_bwd(a_dec[li], dy, dbias=_gb(mod.bias))
             else:
                 da = ops.act_bwd(a_dec[li], dh, slope=blk.act.weight,
-                                 dslope=_gb(blk.act.weight), dbias=_gb(blk.deconv.bias))
+                                 dslope=_gb(blk.act.weight), dbias=_gb(mod.bias))
             src = src_dec[li]
-            if W.needs_grad(blk.deconv):
-                gw = W.grad_target(blk.deconv)
-                ops.wgrad(src, Src(da), gw, K, S, ops.deconv_pad(K, S), PAD_ZERO)
-                W.finish(blk.deconv, gw)
+            if W.needs_grad(mod):
+                gw = W.grad_target(mod)
+                if is_conv:
+                    ops.wgrad(Src(da), src, gw, K, S, ops.conv_pad(K, S)[0], PAD_REFLECT)
+                else:
+                    ops.wgrad(src, Src(da), gw, K, S, ops.deconv_pad(K, S), PAD_ZERO)
+                W.finish(mod, gw)
             _ready(blk)
-            if li == 0:
+            if is_conv:
+                # a conv decoder level never takes a skip (generator.py:212-213); its input is
+                # one tensor, or (z, h_last) for the first layer
+                d_in = ops.conv1d_dgrad(da, w, src.L, S, pack=blk._pack)
+                if li == 0:
+                    dh_last_enc = d_in if gen.no_z else d_in[:, src.C0:].contiguous()
+                else:
+                    dh = d_in
+            elif li == 0:
                 if gen.no_z:
                     _d0, dh_last_enc = ops.deconv1d_dgrad(da, w, S, 0, pack=blk._pack)
                 else:
@@ -254,7 +300,7 @@ class GeneratorFn(torch.autograd.Function):
                 else:
                     _d0, dh = ops.deconv1d_dgrad(da, w, S, 0, pack=blk._pack)
                     if getattr(src, 'sum_of', False):
-                        dskip[n_enc - 1 - li] = dh    # d(prelu(prev) + alpha*a_j): same gradient
+                        dskip[n_enc - 1 - li] = dh    # d(prelu(prev) + skip): same gradient
         # ---- encoder, last to first ----
         dh = dh_last_enc
         dx = None
@@ -262,10 +308,19 @@ class GeneratorFn(torch.autograd.Function):
             blk = enc[l]
             w = W.get(blk.conv)
             K, S = blk.kwidth, blk.stride
-            alpha_p = gen.skips[l]['alpha'].skip_k if (gen.skip and l in gen.skips) else None
+            gskip = gen.skips[l]['alpha'] if (gen.skip and l in gen.skips) else None
             dsk = dskip.get(l)
-            da = ops.act_bwd(a_enc[l], dh, dskip=dsk, slope=blk.act.weight,
-                             alpha=alpha_p if dsk is not None else None,
+            alpha_p = None
+            if gskip is not None and gskip.skip_type == 'conv':
+                if dsk is not None:
+                    dsk = _skip_conv_bwd(gskip, dsk, a_enc[l])     # -> gradient w.r.t. a_enc[l]
+                alpha_v = _ones(a_enc[l].shape[1], a_enc[l]) if dsk is not None else None
+                ready_extra = gskip.skip_k
+            else:
+                alpha_p = gskip.skip_k if gskip is not None else None
+                alpha_v = alpha_p if dsk is not None else None
+                ready_extra = alpha_p
+            da = ops.act_bwd(a_enc[l], dh, dskip=dsk, slope=blk.act.weight, alpha=alpha_v,
                              dslope=_gb(blk.act.weight),
                              dalpha=_gb(alpha_p, dsk is not None),
                              dbias=_gb(blk.conv.bias))
@@ -274,7 +329,7 @@ class GeneratorFn(torch.autograd.Function):
                 gw = W.grad_target(blk.conv)
                 ops.wgrad(Src(da), src_enc[l], gw, K, S, padL, PAD_REFLECT)
                 W.finish(blk.conv, gw)
-            _ready(blk, alpha_p)
+            _ready(blk, ready_extra)
             if l > 0:
                 dh = ops.conv1d_dgrad(da, w, src_enc[l].L, S, pack=blk._pack)
             elif ctx.x_needs:
@@ -322,33 +377,49 @@ class DiscriminatorFn(torch.autograd.Function):
                 bns.append(None)
                 xfs.append((None, None))
                 src = Src(c, slope=blk.act.weight)
-        # dense head on h.view(B, -1) (discriminator.py:180-182)
+        # head (discriminator.py:175-191) on the last activation
         h = ops.affine_prelu(cs[-1], xfs[-1][0], xfs[-1][1], blocks[-1].act.weight)
         B = h.shape[0]
-        hf = h.view(B, -1)
         fc = disc.fc
-        y1 = ops.linear_fwd(hf, W.get(fc[0]))
-        a1 = ops.bias_prelu_rows(y1, fc[0].bias, W.get(fc[1]))
-        y2 = ops.linear_fwd(a1, W.get(fc[2]))
-        a2 = ops.bias_prelu_rows(y2, fc[2].bias, W.get(fc[3]))
-        y3 = ops.linear_fwd(a2, W.get(fc[4]))
-        out = ops.bias_prelu_rows(y3, fc[4].bias, None)
+        pt = disc.pool_type
+        extra = {}
+        if pt == 'none':        # dense head on h.view(B, -1) (discriminator.py:180-182)
+            hf = h.view(B, -1)
+            y1 = ops.linear_fwd(hf, W.get(fc[0]))
+            a1 = ops.bias_prelu_rows(y1, fc[0].bias, W.get(fc[1]))
+            y2 = ops.linear_fwd(a1, W.get(fc[2]))
+            a2 = ops.bias_prelu_rows(y2, fc[2].bias, W.get(fc[3]))
+            y3 = ops.linear_fwd(a2, W.get(fc[4]))
+            out = ops.bias_prelu_rows(y3, fc[4].bias, None)
+            head = (hf, y1, a1, y2, a2, y3)
+        else:
+            if pt == 'conv':    # 1x1 conv to one channel, Linear over time (:175-179)
+                pc = ops.conv1d_fwd(Src(h), W.get(disc.pool_conv), disc.pool_conv.bias, 1,
+                                    pad_mode=PAD_ZERO, padL=0, pack=disc._pool_pack)
+                hp, idx = pc.view(B, -1), None
+                extra['avg_conv_h'] = hp
+            else:               # global max / mean over time, Linear over channels (:183-190)
+                hp, idx = ops.pool_time_fwd(h, 'max' if pt == 'gmax' else 'avg')
+            y3 = ops.linear_fwd(hp, W.get(fc))
+            out = ops.bias_prelu_rows(y3, fc.bias, None)
+            head = (h, hp, idx, y3)
         ctx.disc = disc
         ctx.rolls = tuple(rolls)
         ctx.x_needs = x.requires_grad or (x1 is not None and x1.requires_grad)
         ctx.split = None if x1 is None else (x.shape[1], x.requires_grad, x1.requires_grad)
-        ctx.state = (cs, srcs, bns, hf, y1, a1, y2, a2, y3, W)
+        ctx.state = (cs, srcs, bns, head, W)
         disc._last_fwd = (cs, xfs)      # for the lazy int_act dict
+        disc._last_extra = extra
         return out
 
     @staticmethod
     def backward(ctx, dout):
         disc = ctx.disc
-        cs, srcs, bns, hf, y1, a1, y2, a2, y3, W = ctx.state
+        cs, srcs, bns, head, W = ctx.state
         blocks = list(disc.enc_blocks)
         fc = disc.fc
         dout = dout.contiguous()
-        # ---- dense head ----
+        # ---- head ----
         def lin_wgrad(mod, dy, xin):
             if W.needs_grad(mod):
                 gw = W.grad_target(mod)
@@ -362,16 +433,38 @@ class DiscriminatorFn(torch.autograd.Function):
                 W.finish(act, gs)
             return d
 
-        dy3 = ops.bias_prelu_rows_bwd(y3, fc[4].bias, None, dout, None, _gb(fc[4].bias))
-        lin_wgrad(fc[4], dy3, a2)
-        da2 = ops.linear_dgrad(dy3, W.get(fc[4]))
-        dy2 = prelu_bwd(y2, fc[2], fc[3], da2)
-        lin_wgrad(fc[2], dy2, a1)
-        da1 = ops.linear_dgrad(dy2, W.get(fc[2]))
-        dy1 = prelu_bwd(y1, fc[0], fc[1], da1)
-        lin_wgrad(fc[0], dy1, hf)
-        dh = ops.linear_dgrad(dy1, W.get(fc[0])).view(cs[-1].shape)
-        _ready(fc)
+        if disc.pool_type == 'none':
+            hf, y1, a1, y2, a2, y3 = head
+            dy3 = ops.bias_prelu_rows_bwd(y3, fc[4].bias, None, dout, None, _gb(fc[4].bias))
+            lin_wgrad(fc[4], dy3, a2)
+            da2 = ops.linear_dgrad(dy3, W.get(fc[4]))
+            dy2 = prelu_bwd(y2, fc[2], fc[3], da2)
+            lin_wgrad(fc[2], dy2, a1)
+            da1 = ops.linear_dgrad(dy2, W.get(fc[2]))
+            dy1 = prelu_bwd(y1, fc[0], fc[1], da1)
+            lin_wgrad(fc[0], dy1, hf)
+            dh = ops.linear_dgrad(dy1, W.get(fc[0])).view(cs[-1].shape)
+            _ready(fc)
+        else:
+            h, hp, idx, y3 = head
+            Lh = h.shape[2]
+            dy3 = ops.bias_prelu_rows_bwd(y3, fc.bias, None, dout, None, _gb(fc.bias))
+            lin_wgrad(fc, dy3, hp)
+            dhp = ops.linear_dgrad(dy3, W.get(fc))
+            if disc.pool_type == 'conv':
+                pcm = disc.pool_conv
+                dpc = dhp.view(h.shape[0], 1, Lh)
+                if pcm.bias is not None and pcm.bias.requires_grad:
+                    ops.act_bwd(dpc, dpc, dbias=grad_buf(pcm.bias))      # sum over (b, t)
+                if W.needs_grad(pcm):
+                    gw = W.grad_target(pcm)
+                    ops.wgrad(Src(dpc), Src(h), gw, 1, 1, 0, PAD_ZERO)
+                    W.finish(pcm, gw)
+                dh = ops.conv1d_dgrad(dpc, W.get(pcm), Lh, 1, padL=0, pack=disc._pool_pack)
+                _ready(fc, pcm)
+            else:
+                dh = ops.pool_time_bwd(dhp, idx, Lh, 'max' if disc.pool_type == 'gmax' else 'avg')
+                _ready(fc)
         # ---- conv stack ----
         dx = None
         for l in range(len(blocks) - 1, -1, -1):

@@ -27,6 +27,8 @@ class _LazyIntAct(dict):
         self._cs, self._xfs = disc._last_fwd
         self._slopes = [blk.act.weight.detach() for blk in disc.enc_blocks]
         dict.__setitem__(self, 'logit', logit)
+        for k, v in getattr(disc, '_last_extra', {}).items():      # 'avg_conv_h' of the conv head
+            dict.__setitem__(self, k, v.detach())
         self._pending = set('h_{}'.format(i) for i in range(len(self._cs)))
 
     def __missing__(self, key):
@@ -80,9 +82,30 @@ class Discriminator(Model):
                 torch.nn.utils.spectral_norm(self.fc[0])
                 torch.nn.utils.spectral_norm(self.fc[2])
                 torch.nn.utils.spectral_norm(self.fc[3])
+        elif pool_type == 'conv':
+            # discriminator.py:122-127: 1x1 conv to one channel, then a Linear over time
+            self.pool_conv = nn.Conv1d(fmaps[-1], 1, 1)
+            self.fc = nn.Linear(pool_slen, 1)
+            self._pool_pack = ops.WeightPack()
+            if norm_type == 'snorm':
+                torch.nn.utils.spectral_norm(self.pool_conv)
+                torch.nn.utils.spectral_norm(self.fc)
+        elif pool_type in ('gmax', 'gavg'):
+            # discriminator.py:128-137: global max / mean over time, then a Linear over channels
+            if pool_type == 'gmax':
+                self.gmax = nn.AdaptiveMaxPool1d(1)
+            else:
+                self.gavg = nn.AdaptiveAvgPool1d(1)
+            self.fc = nn.Linear(fmaps[-1], 1, 1)
+            if norm_type == 'snorm':
+                torch.nn.utils.spectral_norm(self.fc)
+        elif pool_type == 'mlp':
+            raise NotImplementedError("Discriminator pool_type 'mlp' (discriminator.py:138-146) "
+                                      "gives one logit per time step, which the reference's own "
+                                      "training steps cannot consume (model.py:297: a [B*T] "
+                                      "logit against a [B] label); not implemented")
         else:
-            raise NotImplementedError("Discriminator pool_type {!r} is not implemented (only "
-                                      "'none', the SEGAN+/WSEGAN setting)".format(pool_type))
+            raise TypeError('Unrecognized pool type: ', pool_type)
         self._total_pool = 1
         for p in poolings:
             self._total_pool *= p
@@ -112,11 +135,16 @@ class Discriminator(Model):
             raise ValueError('Discriminator expects [B, {}, L], got {}'.format(
                 self.enc_blocks[0].conv.in_channels, tuple(x.shape)))
         L = x.shape[2]
-        if L % self._total_pool != 0 or \
-                (L // self._total_pool) * self.enc_blocks[-1].conv.out_channels != \
-                self.fc[0].in_features:
-            raise ValueError('input length {} does not match the dense head ({} features after '
-                             'pooling by {})'.format(L, self.fc[0].in_features, self._total_pool))
+        if L % self._total_pool != 0:
+            raise ValueError('input length {} is not divisible by the total pooling {}'.format(
+                L, self._total_pool))
+        Lo, Co = L // self._total_pool, self.enc_blocks[-1].conv.out_channels
+        want = {'none': Lo * Co, 'conv': Lo}.get(self.pool_type, Co)
+        fc_in = self.fc[0].in_features if self.pool_type == 'none' else self.fc.in_features
+        if want != fc_in:
+            raise ValueError('input length {} does not match the {!r} head ({} features expected, '
+                             '{} after pooling by {})'.format(L, self.pool_type, fc_in, want,
+                                                              self._total_pool))
         rolls = self.draw_rolls()
         y = Fn.DiscriminatorFn.apply(self, rolls, x, x1, *self._fn_params())
         return y, _LazyIntAct(self, y)

@@ -583,6 +583,29 @@ def bias_prelu_rows_bwd(x, bias, slope, dy, dslope, dbias):
 # ---------------------------------------------------------------------------------
 # losses / optimizers / utilities
 # ---------------------------------------------------------------------------------
+def pool_time_fwd(x, mode):
+    """Global pooling over time of x [B, C, L] -> ([B, C], idx): mode 'max' (idx = first argmax,
+    int32 [B, C]) or 'avg' (idx None).  AdaptiveMaxPool1d(1) / AdaptiveAvgPool1d(1) of the
+    'gmax' / 'gavg' discriminator heads (discriminator.py:128-137)."""
+    _chk(x, 'x', 3)
+    B, C, L = x.shape
+    y = torch.empty((B, C), device=x.device, dtype=torch.float32)
+    idx = torch.empty((B, C), device=x.device, dtype=torch.int32) if mode == 'max' else None
+    check(_lib.load().segan_pool_time_fwd(_ptr(x), _ptr(y), _ptr(idx), B * C, L,
+                                          0 if mode == 'max' else 1, _stream()), 'pool_time_fwd')
+    return y, idx
+
+
+def pool_time_bwd(dy, idx, L, mode):
+    """Gradient of pool_time_fwd w.r.t. x: [B, C, L]."""
+    _chk(dy, 'dy', 2)
+    B, C = dy.shape
+    dx = torch.empty((B, C, L), device=dy.device, dtype=torch.float32)
+    check(_lib.load().segan_pool_time_bwd(_ptr(dy), _ptr(idx), _ptr(dx), B * C, L,
+                                          0 if mode == 'max' else 1, _stream()), 'pool_time_bwd')
+    return dx
+
+
 def mse_const(x, target):
     """mean((x - target)^2) for a constant target (LSGAN labels, model.py:298,305,316)."""
     _chk(x, 'x')

@@ -108,9 +108,19 @@ def test_argument_validation_mirrors_reference_errors():
         g(torch.zeros(1, 1, 30))             # not divisible by the pooling
     with pytest.raises(ValueError):          # generator.py:200-202
         g(torch.zeros(1, 1, 32), z=torch.zeros(1, 8))
-    for bad in (dict(sinc_conv=True), dict(pool_type='gmax')):
+    for bad in (dict(sinc_conv=True), dict(pool_type='mlp')):
         with pytest.raises(NotImplementedError):
             Discriminator(2, [8, 16], 31, [4, 4], pool_slen=2, **bad)
+    with pytest.raises(TypeError):           # discriminator.py:147-148
+        Discriminator(2, [8, 16], 31, [4, 4], pool_slen=2, pool_type='bogus')
+    # the other heads build with the reference's state_dict keys (discriminator.py:122-137)
+    for pt, keys in (('conv', {'pool_conv.weight', 'pool_conv.bias', 'fc.weight', 'fc.bias'}),
+                     ('gmax', {'fc.weight', 'fc.bias'}), ('gavg', {'fc.weight', 'fc.bias'})):
+        dd = Discriminator(2, [8, 16], 31, [4, 4], pool_slen=2, pool_type=pt)
+        assert {k for k in dd.state_dict() if not k.startswith('enc_blocks')} == keys, pt
+    gc = Generator(1, [8, 16, 32], 31, [4, 1, 4], z_dim=8, skip_type='conv', skip_merge='concat',
+                   bias=True)
+    assert 'alpha_0.skip_k.weight' in gc.state_dict() and 'dec_blocks.1.conv.weight' in gc.state_dict()
     d = Discriminator(2, [8, 16], 31, [4, 4], pool_slen=2, norm_type='snorm')
     assert 'enc_blocks.0.conv.weight_orig' in d.state_dict() and 'fc.3.weight_u' in d.state_dict()
 

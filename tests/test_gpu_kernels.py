@@ -893,3 +893,23 @@ def test_mse_between_tensors_matches_torch():
     (3.0 * got).backward()
     assert max_rel(got, ref) < 1e-5
     assert max_rel(xg.grad, xd.grad) < 1e-5
+
+
+@pytest.mark.parametrize('L', [1, 16, 100])
+def test_global_pooling_over_time(L):
+    """segan_pool_time_fwd / bwd against torch's AdaptiveMaxPool1d(1) / AdaptiveAvgPool1d(1)
+    (the 'gmax' / 'gavg' heads, discriminator.py:128-137), ties included."""
+    from segan_pytorch_amd import ops
+    torch.manual_seed(L)
+    x = torch.randn(5, 7, L)
+    if L > 2:
+        x[0, 0, 1] = x[0, 0, 2] = 9.0            # a tie: the first position gets the gradient
+    dy = torch.randn(5, 7)
+    for mode, pool in (('max', torch.nn.AdaptiveMaxPool1d(1)), ('avg', torch.nn.AdaptiveAvgPool1d(1))):
+        xr = x.clone().requires_grad_(True)
+        yr = pool(xr).squeeze(2)
+        yr.backward(dy)
+        y, idx = ops.pool_time_fwd(x.to(DEV), mode)
+        dx = ops.pool_time_bwd(dy.to(DEV), idx, L, mode)
+        assert torch.equal(y.cpu(), yr.detach()) or max_rel(y, yr.detach()) < 1e-6
+        assert max_rel(dx, xr.grad) < 1e-6, mode

@@ -13,7 +13,7 @@ import pytest
 import torch
 
 import segan_oracle as O
-from conftest import max_rel
+from conftest import VARIANT_NAMES, max_rel, oracle_kwargs
 
 # RMSprop's first step moves every weight by lr*g/(0.1|g|+1e-8) = +-10*lr = 5e-4 wherever
 # |g| >> 1e-7 and is ill-conditioned where the gradient is at roundoff level (|g| ~ 1e-8):
@@ -80,9 +80,11 @@ def check_step_against_golden(fx):
     m = build(fx)
     (d_real_loss, d_fake_loss, g_adv, g_l1), Gopt, Dopt = run_step(
         m, fx, fx['clean'], fx['noisy'], fx['z'])
-    for got, key in ((d_real_loss, 'd_real_loss'), (d_fake_loss, 'd_fake_loss'),
-                     (g_adv, 'g_adv_loss'), (g_l1, 'g_l1_loss')):
-        assert max_rel(got, fx[key]) < ACT_TOL, key
+    # g_adv is taken through D AFTER its first RMSprop step, whose +-10*lr moves amplify fp32
+    # roundoff in the gradients (assert_weights_after_step): looser than the pre-step losses
+    for got, key, tol in ((d_real_loss, 'd_real_loss', ACT_TOL), (d_fake_loss, 'd_fake_loss', ACT_TOL),
+                          (g_adv, 'g_adv_loss', 1e-4), (g_l1, 'g_l1_loss', ACT_TOL)):
+        assert max_rel(got, fx[key]) < tol, key
     dn, gn = dict(m.D.named_parameters()), dict(m.G.named_parameters())
     for k, g in fx['d_grads'].items():
         if not k.endswith('conv.bias'):   # zero-gradient biases in front of BatchNorm: roundoff
@@ -93,14 +95,20 @@ def check_step_against_golden(fx):
         assert max_rel(gn[k].grad, g) < 1e-2, ('G', k)
     import torch.nn.functional as F
     st = fx['opts']['genc_poolings']
+    kw = oracle_kwargs(fx['opts'])
     G = {k: v.clone().requires_grad_(True) for k, v in fx['G0'].items()}
     d_after = {k: v.detach().cpu().clone() for k, v in m.D.state_dict().items()}
-    genh = O.generator_forward(G, fx['noisy'], fx['z'], st)
-    d = O.discriminator_forward(d_after, torch.cat((genh, fx['noisy']), 1), fx['rolls'][2], st)
+    genh = O.generator_forward(G, fx['noisy'], fx['z'], st, kw['dec_strides'],
+                               skip_merge=kw['skip_merge'])
+    d = O.discriminator_forward(d_after, torch.cat((genh, fx['noisy']), 1), fx['rolls'][2],
+                                kw['d_strides'], pool_type=kw['pool_type'])
     B = fx['clean'].size(0)
     loss = F.mse_loss(d.view(-1), torch.ones(B)) + 100.0 * F.l1_loss(genh, fx['clean'])
     keys = list(G.keys())
-    for k, g in zip(keys, torch.autograd.grad(loss, [G[k] for k in keys])):
+    for k, g in zip(keys, torch.autograd.grad(loss, [G[k] for k in keys], allow_unused=True)):
+        if g is None:       # a skip the forward never takes (pooling-1 decoder level)
+            assert gn[k].grad is None or float(gn[k].grad.abs().max()) == 0.0, k
+            continue
         assert max_rel(gn[k].grad, g) < GRAD_TOL, ('G vs oracle', k)
     assert_weights_after_step(m.G.state_dict(), fx['G_after'], fx['g_grads'])
     assert_weights_after_step(m.D.state_dict(), fx['D_after'], fx['d_grads'], skip=NOISE_KEYS)
@@ -112,6 +120,14 @@ def test_tiny_gan_step_matches_reference(tiny_step):
 
 def test_tiny_stride2_gan_step_matches_reference(tiny_s2):
     check_step_against_golden(tiny_s2)
+
+
+@pytest.mark.parametrize('name', VARIANT_NAMES)
+def test_architecture_variants_match_reference(tiny_variants, name):
+    """The switches train.py reaches beyond the headline nets, one reference step each
+    (oracle/make_golden.py variants): --skip_type conv with both merges, pooling-1 layers in
+    encoder and decoder, a conv block as last decoder layer, --dpool_type conv / gmax / gavg."""
+    check_step_against_golden(tiny_variants[name])
 
 
 def test_tiny_forward_hidden_and_int_act(tiny_step):
