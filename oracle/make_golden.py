@@ -247,6 +247,8 @@ VARIANTS = {
     'dpool_conv': dict(dpool_type='conv'),
     'dpool_gmax': dict(dpool_type='gmax'),
     'dpool_gavg': dict(dpool_type='gavg'),
+    # spectral norm on the conv head's pool_conv and fc (discriminator.py:125-127)
+    'dpool_conv_snorm': dict(dpool_type='conv', dnorm_type='snorm'),
 }
 
 

@@ -51,7 +51,7 @@ def tiny_variants():
 
 
 VARIANT_NAMES = ('skipconv_concat', 'skipconv_sum', 'pool1_mid', 'pool1_last', 'dpool_conv',
-                 'dpool_gmax', 'dpool_gavg')
+                 'dpool_gmax', 'dpool_gavg', 'dpool_conv_snorm')
 
 
 def oracle_kwargs(opts):
