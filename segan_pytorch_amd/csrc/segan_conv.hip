@@ -1111,8 +1111,10 @@ extern "C" int segan_conv1d_dgrad(const float* da, const void* wt, const float* 
   SEGAN_REQUIRE(B > 0 && N > 0 && M > 0 && L > 0 && L % S == 0, "conv1d_dgrad: bad sizes");
   SEGAN_REQUIRE(da && dx && halo && (wt || (w && N <= 2)), "conv1d_dgrad: NULL pointer");
   SEGAN_REQUIRE(roll > -L && roll < L, "conv1d_dgrad: |roll| must be < L");
-  const int padR = K - 1 - padL;
-  // the halo spans K-1 positions; with stride S the last S-1 of them are never written
+  // the padded input spans K-1 halo positions, but the last S-1 of the right halo are beyond the
+  // window of the last output (P <= S*(Ls-1) + K-1): they get no gradient, are neither computed
+  // nor folded, and the column range of the contraction ends one phase block earlier
+  const int padR = K - 1 - padL >= 0 ? (K - S - padL > 0 ? K - S - padL : 0) : -1;
   SEGAN_REQUIRE(padL >= 0 && padR >= 0 && padL < L && K - S - padL < L, "conv1d_dgrad: bad padding");
   const int U = 32 / S;
   const int Ls = L / S;
