@@ -186,6 +186,24 @@ def sum_skip(x0, slope0, x1, alpha):
     return (v + alpha.detach().double().view(1, -1, 1) * x1.double()).float()
 
 
+def pool_time_fwd(x, mode):
+    if mode == 'max':
+        y, idx = x.max(dim=2)
+        # first position attaining the maximum (segan_pool_time_fwd's tie rule)
+        first = (x == y.unsqueeze(2)).float().argmax(dim=2)
+        return y, first.to(torch.int32)
+    return x.mean(dim=2), None
+
+
+def pool_time_bwd(dy, idx, L, mode):
+    B, C = dy.shape
+    if mode == 'max':
+        dx = torch.zeros(B, C, L)
+        dx.scatter_(2, idx.long().unsqueeze(2), dy.unsqueeze(2))
+        return dx
+    return (dy / L).unsqueeze(2).expand(B, C, L).contiguous()
+
+
 def bce_logits_const(x, target):
     t = torch.full_like(x.double(), target)
     return F.binary_cross_entropy_with_logits(x.double(), t).float()
@@ -409,7 +427,7 @@ def _chk(t, name, ndim=None):
 
 
 _NAMES = ['conv1d_fwd', 'conv1d_dgrad', 'wgrad', 'deconv1d_fwd', 'deconv1d_dgrad', 'bn_stats',
-          'affine_prelu', 'sum_skip', 'bce_logits_const', 'bce_logits_const_bwd', 'act_bwd', 'tanh_bwd', 'linear_fwd', 'linear_dgrad', 'linear_wgrad',
+          'affine_prelu', 'sum_skip', 'pool_time_fwd', 'pool_time_bwd', 'bce_logits_const', 'bce_logits_const_bwd', 'act_bwd', 'tanh_bwd', 'linear_fwd', 'linear_dgrad', 'linear_wgrad',
           'bias_prelu_rows', 'bias_prelu_rows_bwd', 'mse_const', 'mse_const_bwd', 'l1_mean',
           'l1_bwd', 'stft_basis', 'stft_frames', 'stft_spectrum', 'stft_spectrum_bwd', 'powdb',
           'powdb_bwd', 'stft_overlap_add', 'snorm_fwd', 'snorm_bwd', 'bn_partial', 'bn_final', 'act_bwd_bn_reduce',

@@ -10,7 +10,7 @@ import pytest
 import torch
 
 import emu_ops
-from conftest import max_rel
+from conftest import VARIANT_NAMES, max_rel
 
 # RMSprop's first step moves every weight by lr*g/(0.1|g|+1e-8) = +-10*lr = 5e-4 wherever
 # |g| >> 1e-7 and is ill-conditioned where the gradient is at roundoff level (|g| ~ 1e-8):
@@ -83,6 +83,13 @@ def test_gan_step_orchestration(tiny_step):
 
 def test_gan_step_orchestration_stride2(tiny_s2):
     check_step(tiny_s2)
+
+
+@pytest.mark.parametrize('name', [n for n in VARIANT_NAMES if not n.endswith('_snorm')])
+def test_gan_step_orchestration_variants(tiny_variants, name):
+    """Host side of the architecture switches (conv skips, pooling-1 layers, conv last block,
+    the conv / gmax / gavg discriminator heads) against one step of the real reference each."""
+    check_step(tiny_variants[name])
 
 
 def test_hidden_outputs(tiny_step):
