@@ -261,6 +261,18 @@ int segan_l1_mean(const float* x, const float* y, float* loss, float* ws, int64_
 int segan_l1_bwd(const float* x, const float* y, const float* gout, float gscale, float* grad,
                  int64_t n, void* stream);
 
+/* Data gradient of conv1d_fwd for SHORT rows (L/S in {4, 8, 16, 32, 64}; N % 4 == 0, M % 16 == 0;
+ * any supported stride), as the GEMM + col2im of a transposed conv: no zero-halo columns, the
+ * reflect fold and the roll are applied in the epilogue, complete dx rows are stored (no halo
+ * scratch).  `wg` is the "G" packing of the weight: wg[m][n*32 + r*U + u] = w[m][n][S*u + r]
+ * (U = 32/S; 0 for S*u + r >= K), segan_packed_g_bytes() bytes, written by
+ * segan_pack_weights_g.  Same result as segan_conv1d_dgrad (fp32).  Returns SEGAN_EUNSUPPORTED
+ * for other geometries. */
+size_t segan_packed_g_bytes(int M, int N, int S);
+int segan_pack_weights_g(const float* w, float* wg, int M, int N, int K, int S, void* stream);
+int segan_conv1d_dgrad_short(const float* da, const float* wg, float* dx, int B, int N, int M,
+                             int L, int K, int S, int padL, int roll, void* stream);
+
 /* Global pooling over time of x[rows][L] (rows = B*C), the 'gmax' / 'gavg' discriminator heads
  * (discriminator.py:128-137,183-190).  mode 0: y[row] = max, idx[row] = the FIRST position
  * attaining it; mode 1: y[row] = mean (idx unused, may be NULL).  bwd: dx[row][t] =

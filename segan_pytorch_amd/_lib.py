@@ -68,6 +68,10 @@ SIGNATURES = {
     'segan_mse_const': (c_int, [_P, c_float, _P, _P, _P, c_float, c_int, _P]),
     'segan_l1_bwd': (c_int, [_P, _P, _P, c_float, _P, c_int64, _P]),
     'segan_l1_mean': (c_int, [_P, _P, _P, _P, c_int64, _P]),
+    'segan_packed_g_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'segan_pack_weights_g': (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    'segan_conv1d_dgrad_short': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                        c_int, _P]),
     'segan_pool_time_fwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
     'segan_pool_time_bwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
     'segan_mse_mean': (c_int, [_P, _P, _P, _P, c_int64, _P]),

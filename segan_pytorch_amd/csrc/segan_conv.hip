@@ -758,6 +758,159 @@ __global__ void fold_halo_kernel(float* dx, const float* halo, int rows, int L, 
   }
 }
 
+// ====================================================================================
+// conv data gradient of SHORT rows (Ls = L/S of 64 or fewer positions: the deep encoder /
+// discriminator layers).  The T form above computes S*q + r over the padded row and spends
+// (Ls + U-1)/Ls of its columns — 23 of 16 at S = 4, Ls = 16; 23 of 8 in the deepest stride-2
+// layer — on positions that are mostly zeros.  Here the contraction is the GEMM + col2im of a
+// transposed conv instead: no halo columns at all.
+//   Y[(n, r, u), (b, t)] = sum_m W[m, n, S*u + r] * da[b, m, t]             (MFMA GEMM over m)
+//   dxp[b, n, P]         = sum_u Y[(n, P%S, u), (b, P/S - u)]              (col2im, U terms)
+//   dx[b, n, i]          = dxp[i + padL] + reflected halo terms, rolled back (as fold_halo_kernel)
+// A 128 x 128 tile holds 4 channels x (S phases x U taps = 32) rows and 128/Ls samples x Ls
+// positions; each wave's 64 x 64 quarter holds, for 2 channels, ALL rows of its 64/Ls samples,
+// so the col2im and the reflect fold are wave-local: the quarter goes through LDS once (one
+// channel at a time) and complete dx rows are stored — no halo buffer, no fold pass, no atomics.
+// Both operands are K-major ([m][128 floats]) and go HBM/L2 -> LDS by LDS-DMA: the weight from
+// the "G" packing Wg[m][n*32 + r*U + u] (segan_pack_weights_g), da as it lies in memory.
+// ====================================================================================
+#define CS_KC 16
+struct ShortArgs {
+  const float* da;
+  const float* wg;
+  float* dx;
+  int B, N, M, L, Ls, padL, padRw, roll, ncoltiles;
+};
+
+template <int S>
+__global__ __launch_bounds__(256, 2) void conv_dgrad_short_kernel(const ShortArgs a) {
+  constexpr int MB = 128, NB = 128, KC = CS_KC, NI = 2, NJ = 2, YP = 65, U = 32 / S;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Wl0 = smem;                  // [2][KC*MB]
+  float* Il0 = smem + 2 * KC * MB;   // [2][KC*NB]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int rowtile = blockIdx.x / a.ncoltiles, coltile = blockIdx.x - rowtile * a.ncoltiles;
+  const int Ls = a.Ls, L = a.L;
+  const int n0 = rowtile * 4;
+  const int b0 = coltile * (NB / Ls);
+  const int rowpitch = a.N * 32;
+
+  const long wbytes = (long)a.M * rowpitch * 4, xbytes = (long)a.B * a.M * Ls * 4;
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.wg), 0, (int)(wbytes < 0x7fffffffL ? wbytes : 0x7fffffffL), 0x00020000);
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.da), 0, (int)(xbytes < 0x7fffffffL ? xbytes : 0x7fffffffL), 0x00020000);
+  // one DMA instruction = 64 lanes x 16 B = two K-rows of 128 floats
+  const int lr = lane >> 5, lc = 4 * (lane & 31);
+  const int wvo = (lr * rowpitch + rowtile * MB + lc) * 4;
+  const int s_l = lc / Ls, t_l = lc - s_l * Ls;
+  const int xvo = (b0 + s_l < a.B) ? ((s_l * a.M + lr) * Ls + t_l) * 4 : (int)0x80000000u;
+
+  auto load_chunk = [&](int ch, int buf) {
+    float* Wl = Wl0 + buf * (KC * MB);
+    float* Il = Il0 + buf * (KC * NB);
+#pragma unroll
+    for (int p = 0; p < KC / 8; ++p) {
+      const int q = wave + 4 * p;       // K-rows 2q, 2q+1 of the chunk
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          wrs, (__attribute__((address_space(3))) void*)(Wl + q * 256), 16, wvo,
+          (ch * KC + 2 * q) * rowpitch * 4, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          xrs, (__attribute__((address_space(3))) void*)(Il + q * 256), 16, xvo,
+          ((b0 * a.M + ch * KC + 2 * q) * Ls) * 4, 0, 0);
+    }
+  };
+
+  int aoff[NI], boff[NJ], rsh[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    aoff[i] = h * MB + 32 * (wm * NI + i) + l31;
+    rsh[i] = 0;
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) boff[j] = h * NB + 64 * wn + 32 * j + l31;
+
+  f32x16 acc[NI][NJ];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+  const int nch = a.M / KC;
+  load_chunk(0, 0);
+  __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0): the DMA of chunk 0 has landed
+  __syncthreads();
+  for (int ch = 0; ch < nch; ++ch) {
+    const int buf = ch & 1;
+    if (ch + 1 < nch) load_chunk(ch + 1, buf ^ 1);
+    corr_mma_chunk<MB, 1, KC, NI, NJ, false>(Wl0 + buf * (KC * MB), Il0 + buf * (KC * NB), NB, aoff,
+                                             boff, rsh, acc);
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    __syncthreads();
+  }
+
+  // ---- col2im + reflect fold, one channel of the wave's quarter at a time ----
+  float* Yb = smem + wave * (32 * YP);     // [32 rows (r, u)][64 columns], row pitch 65
+  const int bw = b0 + (64 * wn) / Ls;      // first sample of this wave's columns
+  // dxp[P] of local sample sl from the staged rows
+  auto dxp = [&](int P, int cbase) -> float {
+    const int r = P % S, qq = P / S;
+    float v = 0.0f;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = qq - u;
+      if (t >= 0 && t < Ls) v += Yb[(r * U + u) * YP + cbase + t];
+    }
+    return v;
+  };
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        Yb[((e & 3) + 8 * (e >> 2) + 4 * h) * YP + 32 * j + l31] = acc[i][j][e];
+    __syncthreads();
+    const int n = n0 + 2 * wm + i;
+#pragma unroll
+    for (int p = 0; p < S; ++p) {
+      const int o = p * 64 + lane;         // 64*S outputs: 64/Ls samples x L positions
+      const int sl = o / L, io = o - sl * L;
+      const int b = bw + sl;
+      float v = dxp(io + a.padL, sl * Ls);
+      if (io >= 1 && io <= a.padL) v += dxp(a.padL - io, sl * Ls);
+      const int jr = L - 2 - io;           // right halo sample that mirrors onto io
+      if (jr >= 0 && jr < a.padRw) v += dxp(L + a.padL + jr, sl * Ls);
+      if (b < a.B && n < a.N) {
+        int ii = io - a.roll;
+        if (ii < 0) ii += L;
+        if (ii >= L) ii -= L;
+        a.dx[((size_t)b * a.N + n) * L + ii] = v;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void pack_g_kernel(const float* __restrict__ w, float* __restrict__ wg, int M, int N,
+                              int K, int S) {
+  const size_t total = (size_t)M * N * 32;
+  const int U = 32 / S;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i & 31);           // r*U + u
+    const size_t mn = i >> 5;
+    const int k = S * (c % U) + c / U;
+    wg[i] = k < K ? w[mn * K + k] : 0.0f;
+  }
+}
+
 // diagnostics: how the last forward / data-gradient contraction of this thread was launched
 static thread_local int g_last_corr[6];
 static void note_launch(int kind, unsigned grid, const CorrArgs& a, int ntiles) {
@@ -1152,4 +1305,54 @@ extern "C" int segan_conv1d_dgrad(const float* da, const void* wt, const float* 
     return segan_check_launch("fold_halo_kernel");
   }
   return SEGAN_OK;
+}
+
+// ---- short rows (GEMM + col2im form) -------------------------------------------------------
+static bool short_ok(int N, int M, int L, int K, int S, int padL) {
+  if (!stride_ok(S) || L % S != 0) return false;
+  const int Ls = L / S;
+  return (Ls == 4 || Ls == 8 || Ls == 16 || Ls == 32 || Ls == 64) && N % 4 == 0 &&
+         M % CS_KC == 0 && K >= 1 && K <= 32 && padL >= 0 && K - 1 - padL >= 0 && padL < L &&
+         K - S - padL < L;
+}
+
+extern "C" size_t segan_packed_g_bytes(int M, int N, int S) {
+  if (!stride_ok(S) || M <= 0 || N <= 0) return 0;
+  return (size_t)M * N * 32 * sizeof(float);
+}
+
+extern "C" int segan_pack_weights_g(const float* w, float* wg, int M, int N, int K, int S,
+                                    void* stream) {
+  SEGAN_REQUIRE(w && wg && M > 0 && N > 0, "pack_weights_g: bad arguments");
+  SEGAN_REQUIRE(stride_ok(S) && K >= 1 && K <= 32, "pack_weights_g: stride in {1,2,4}, K <= 32");
+  const size_t total = (size_t)M * N * 32;
+  const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+  hipLaunchKernelGGL(pack_g_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, wg, M, N, K,
+                     S);
+  return segan_check_launch("pack_weights_g");
+}
+
+extern "C" int segan_conv1d_dgrad_short(const float* da, const float* wg, float* dx, int B, int N,
+                                        int M, int L, int K, int S, int padL, int roll,
+                                        void* stream) {
+  SEGAN_REQUIRE(da && wg && dx && B > 0, "conv1d_dgrad_short: bad arguments");
+  SEGAN_REQUIRE(roll > -L && roll < L, "conv1d_dgrad_short: |roll| must be < L");
+  if (!short_ok(N, M, L, K, S, padL)) {
+    segan_set_error("conv1d_dgrad_short: geometry not covered (L/S in {4,8,16,32,64}, N %% 4 == 0, "
+                    "M %% 16 == 0)");
+    return SEGAN_EUNSUPPORTED;
+  }
+  ShortArgs a;
+  a.da = da; a.wg = wg; a.dx = dx;
+  a.B = B; a.N = N; a.M = M; a.L = L; a.Ls = L / S; a.padL = padL;
+  a.padRw = K - S - padL > 0 ? K - S - padL : 0;
+  a.roll = roll;
+  a.ncoltiles = ceil_div(B, 128 / a.Ls);
+  const size_t lds = 4 * 32 * 65 * sizeof(float);      // >= 2 * CS_KC * 256 floats of the main loop
+  const dim3 grid((unsigned)(N / 4 * a.ncoltiles));
+  hipStream_t st = (hipStream_t)stream;
+  if (S == 4) hipLaunchKernelGGL(conv_dgrad_short_kernel<4>, grid, dim3(256), lds, st, a);
+  else if (S == 2) hipLaunchKernelGGL(conv_dgrad_short_kernel<2>, grid, dim3(256), lds, st, a);
+  else hipLaunchKernelGGL(conv_dgrad_short_kernel<1>, grid, dim3(256), lds, st, a);
+  return segan_check_launch("conv_dgrad_short_kernel");
 }

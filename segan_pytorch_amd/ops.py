@@ -215,6 +215,27 @@ class WeightPack(object):
     def f(self, w, S):
         return self._get(w, S, 0, 'f')
 
+    def g(self, w, S):
+        """"G" packing wg[m][n*32 + r*8 + u] = w[m][n][4u + r] of the short-row data gradient
+        (segan_pack_weights_g)."""
+        _chk(w, 'weight', 3)
+        key = (w.data_ptr(), w._version, _weights_epoch, getattr(w, '_segan_epoch', 0),
+               tuple(w.shape), S)
+        if self._key.get('g') == key:
+            return self._buf['g']
+        lib = _lib.load()
+        M, N, K = w.shape
+        nbytes = lib.segan_packed_g_bytes(M, N, S)
+        if nbytes == 0:
+            raise ValueError('G packing: stride {} not supported'.format(S))
+        buf = self._buf.get('g')
+        if buf is None or buf.numel() * 4 != nbytes or buf.device != w.device:
+            buf = torch.empty(nbytes // 4, device=w.device, dtype=torch.float32)
+        check(lib.segan_pack_weights_g(_ptr(w), _ptr(buf), M, N, K, S, _stream()), 'pack_weights_g')
+        self._buf['g'] = buf
+        self._key['g'] = key
+        return buf
+
     def t(self, w, S, pad_t):
         return self._get(w, S, pad_t, 't')
 
@@ -299,10 +320,40 @@ def conv1d_dgrad(da, w, L, S, roll=0, padL=None, pack=None):
         if rc != _EUNSUPPORTED:
             check(rc, 'conv1d_dgrad')
             return dx
+    if short_rows_ok(N, M, L, S):
+        # deep layers (at most 64 positions per row after the stride): GEMM + col2im form, no
+        # zero-halo columns, fold and roll in the epilogue
+        return conv1d_dgrad_short(da, w, L, S, roll=roll, padL=padL, pack=pack)
     check(lib.segan_conv1d_dgrad(_ptr(da), _ptr(pack.t(w, S, 0)), None, _ptr(dx), _ptr(halo), B, N,
                                  M, L, K, S, padL, roll, PREC_FP32, *_scratch(), _stream()),
           'conv1d_dgrad')
     return dx
+
+
+def conv1d_dgrad_short(da, w, L, S, roll=0, padL=None, pack=None):
+    """conv1d_dgrad through segan_conv1d_dgrad_short (L/S in {4, 8, 16, 32, 64}, N % 4 == 0,
+    M % 16 == 0); raises for other geometries."""
+    _chk(da, 'da', 3)
+    _chk(w, 'weight', 3)
+    M, N, K = w.shape
+    B = da.shape[0]
+    if padL is None:
+        padL = conv_pad(K, S)[0]
+    dx = torch.empty((B, N, L), device=da.device, dtype=torch.float32)
+    pack = pack or WeightPack()
+    check(_lib.load().segan_conv1d_dgrad_short(_ptr(da), _ptr(pack.g(w, S)), _ptr(dx), B, N,
+                                               M, L, K, S, padL, roll, _stream()),
+          'conv1d_dgrad_short')
+    return dx
+
+
+_SHORT_LS = (4, 8, 16, 32, 64)
+
+
+def short_rows_ok(N, M, L, S):
+    """Does the fp32 conv data gradient of this geometry run the short-row kernel
+    (segan_conv1d_dgrad_short)?"""
+    return S in (2, 4) and L % S == 0 and (L // S) in _SHORT_LS and N % 4 == 0 and M % 16 == 0
 
 
 def wgrad(lo, hi, dw, K, S, padL, pad_mode, roll=0):

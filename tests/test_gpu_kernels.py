@@ -913,3 +913,33 @@ def test_global_pooling_over_time(L):
         dx = ops.pool_time_bwd(dy.to(DEV), idx, L, mode)
         assert torch.equal(y.cpu(), yr.detach()) or max_rel(y, yr.detach()) < 1e-6
         assert max_rel(dx, xr.grad) < 1e-6, mode
+
+
+@pytest.mark.parametrize('B,N,M,L,S,K,roll', [
+    (3, 8, 16, 64, 4, 31, 0),        # Ls 16, one partial column tile
+    (17, 16, 64, 64, 4, 31, 1),      # three column tiles, the last one partial; rolled
+    (9, 4, 32, 128, 4, 31, -3),      # Ls 32
+    (5, 12, 48, 64, 4, 5, 2),        # narrow kernel: padL 1, no reachable right halo
+    (2, 8, 16, 256, 4, 31, 7),       # Ls 64
+    (80, 512, 1024, 64, 4, 31, 0),   # the enc4 shape of the SEGAN+ nets
+    (19, 8, 16, 16, 2, 31, 0),       # stride 2, Ls 8: the deepest layer of the 11-layer SEGAN
+    (5, 16, 32, 32, 2, 31, -2),      # stride 2, Ls 16
+    (3, 4, 16, 128, 2, 31, 3),       # stride 2, Ls 64
+    (8, 256, 512, 32, 2, 31, 1),     # a deep layer of the 11-layer net
+    (4, 8, 16, 32, 1, 31, 2),        # stride 1 (pooling-1 layers)
+    (40, 4, 16, 16, 4, 31, 0),       # Ls 4: 32 samples per column tile
+])
+def test_conv1d_dgrad_short_rows(B, N, M, L, S, K, roll):
+    """segan_conv1d_dgrad_short (GEMM + col2im form, fold and roll in the epilogue) against the
+    fp64 autograd of the reflect-padded strided conv, and bit-reproducible."""
+    ops = _ops()
+    w = rnd(M, N, K, seed=2, scale=0.1)
+    da = rnd(B, M, L // S, seed=4)
+    xd = torch.zeros(B, N, L, dtype=torch.float64, requires_grad=True)
+    conv_ref(xd, w.double(), None, S, roll).backward(da.double())
+    dag, wg = da.to(DEV), w.to(DEV)
+    dx = ops.conv1d_dgrad_short(dag, wg, L, S, roll=roll)
+    assert max_rel(dx, xd.grad) < TOL
+    assert torch.equal(dx, ops.conv1d_dgrad_short(dag, wg, L, S, roll=roll))
+    if ops.short_rows_ok(N, M, L, S):
+        assert torch.equal(dx, ops.conv1d_dgrad(dag, wg, L, S, roll=roll))   # the routed path
