@@ -268,10 +268,12 @@ def pmc_mfma_busy(family):
         return None
 
 
-def pmc_traffic(kernel_prefix):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+def pmc_traffic(main=('corr2_kernel', 'corr_kernel<', 'conv_dgrad_short_kernel'),
+                extra=('corr_fixup_kernel',)):
+    """HBM bytes per launch of the dominant kernel family from the committed rocprofv3 PMC passes
     (profiles/r02_pmc_hbm_traffic.json: FETCH_SIZE and WRITE_SIZE in separate passes over this
-    same command; FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md)."""
+    same command; FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md): bytes of
+    the contraction kernels plus their stream-K fix-up passes, per contraction launch."""
     path = os.path.join(ROOT, 'profiles', 'r02_pmc_hbm_traffic.json')
     if not os.path.exists(path):
         return None
@@ -279,8 +281,9 @@ def pmc_traffic(kernel_prefix):
         ks = json.load(open(path))['kernels']
         n = f = w = 0.0
         for name, v in ks.items():
-            if kernel_prefix in name:
-                n += v['launches']
+            is_main = any(m in name for m in main)
+            if is_main or any(m in name for m in extra):
+                n += v['launches'] if is_main else 0
                 f += v['launches'] * v['fetch_kb_avg']
                 w += v['launches'] * v['write_kb_avg']
         if n == 0:
@@ -484,9 +487,9 @@ def main():
             c = s.get('corr')
             if c:
                 line['roofline'] = {
-                    'bound': 'mfma', 'kernel': 'corr2_kernel (conv/deconv forward + data gradient)',
+                    'bound': 'mfma', 'kernel': 'corr2_kernel + conv_dgrad_short_kernel (conv/deconv forward + data gradient)',
                     'achieved': c['tflops'], 'peak': PEAK_F32_MFMA_TF, 'unit': 'TFLOP/s',
-                    'frac': c['tflops'] / PEAK_F32_MFMA_TF, 'traffic': pmc_traffic('corr'),
+                    'frac': c['tflops'] / PEAK_F32_MFMA_TF, 'traffic': pmc_traffic(),
                     'traffic_unit': 'HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, '
                                     'profiles/r02_pmc_hbm_traffic.json)',
                     'avg_launch_us': c['avg_us'], 'launches': c['launches'],
