@@ -208,9 +208,12 @@ def _chk(t, c, tol):
     assert (got - c['sample']).abs().max().item() / den < tol
 
 
-@pytest.fixture
+@pytest.fixture(autouse=True)
 def deterministic():
-    """Bit-reproducible kernels for the duration of a test (ops.set_deterministic)."""
+    """Bit-reproducible kernels (ops.set_deterministic) for every test of this file: the
+    comparisons with the reference then give the same numbers on every run and every box — no
+    tolerance is ever met by luck.  The default mode (fp32 atomics in the weight-gradient tail) is
+    what tests/test_gpu_kernels.py and bench.py run."""
     from segan_pytorch_amd import ops
     old = ops.get_deterministic()
     ops.set_deterministic(True)
