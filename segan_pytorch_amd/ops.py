@@ -302,11 +302,15 @@ def conv1d_dgrad(da, w, L, S, roll=0, padL=None, pack=None):
             tuple(da.shape), tuple(w.shape), L))
     if padL is None:
         padL = conv_pad(K, S)[0]
-    dx = torch.empty((B, N, L), device=da.device, dtype=torch.float32)
-    halo = torch.empty((B * N * max(K - 1, 1),), device=da.device, dtype=torch.float32)
     small = N <= 2          # first layer: direct VALU kernel on the unpacked weight
     _chk(w, 'weight', 3)
     pack = pack or WeightPack()
+    if not small and not _precision and short_rows_ok(N, M, L, S):
+        # deep layers (at most 64 positions per row after the stride): GEMM + col2im form, no
+        # zero-halo columns, fold and roll in the epilogue
+        return conv1d_dgrad_short(da, w, L, S, roll=roll, padL=padL, pack=pack)
+    dx = torch.empty((B, N, L), device=da.device, dtype=torch.float32)
+    halo = torch.empty((B * N * max(K - 1, 1),), device=da.device, dtype=torch.float32)
     lib = _lib.load()
     if small:
         check(lib.segan_conv1d_dgrad(_ptr(da), None, _ptr(w.detach()), _ptr(dx), _ptr(halo), B, N,
@@ -320,9 +324,7 @@ def conv1d_dgrad(da, w, L, S, roll=0, padL=None, pack=None):
         if rc != _EUNSUPPORTED:
             check(rc, 'conv1d_dgrad')
             return dx
-    if short_rows_ok(N, M, L, S):
-        # deep layers (at most 64 positions per row after the stride): GEMM + col2im form, no
-        # zero-halo columns, fold and roll in the epilogue
+    if short_rows_ok(N, M, L, S):        # a bf16 mode whose kernel does not cover this geometry
         return conv1d_dgrad_short(da, w, L, S, roll=roll, padL=padL, pack=pack)
     check(lib.segan_conv1d_dgrad(_ptr(da), _ptr(pack.t(w, S, 0)), None, _ptr(dx), _ptr(halo), B, N,
                                  M, L, K, S, padL, roll, PREC_FP32, *_scratch(), _stream()),
