@@ -11,6 +11,9 @@ f2  normalize_wave_minmax + pre_emphasize (se_dataset.py:108-117) on int16 PCM, 
 f3  a checkpoint written by the reference's Saver (core.py:21-67), and — asserted here, at
     generation time — a checkpoint written by OUR Saver loaded back by the reference's.
 f4  SSNR (utils.py:350-395) on noisy/clean pairs.
+
+python oracle/make_golden_frows.py samples -> tests/golden/train_samples.pt: the wav files the
+reference's gen_train_samples (model.py:177-217) writes for three slices of the tiny net.
 """
 import os
 import shutil
@@ -30,8 +33,38 @@ from make_golden import clone_sd, seed_all, tiny_opts  # noqa: E402
 OUT = os.path.join(ROOT, 'tests', 'golden')
 
 
+def make_train_samples(ref):
+    from scipy.io import wavfile
+    o = tiny_opts()
+    tmp = tempfile.mkdtemp()
+    o['save_path'] = tmp
+    seed_all(111)
+    segan = ref.SEGAN(SimpleNamespace(**o))
+    g = torch.Generator().manual_seed(33)
+    clean = (torch.rand(3, 1, 1024, generator=g) * 2 - 1) * 0.5
+    noisy = (clean + 0.1 * torch.randn(3, 1, 1024, generator=g)).clamp(-1, 1)
+    z = torch.randn(3, o['z_dim'], 16, generator=g)
+    segan.gen_train_samples(clean, noisy, z, iteration=5)
+    fx = {'opts': o, 'G0': clone_sd(segan.G), 'clean': clean, 'noisy': noisy, 'z': z,
+          'iteration': 5, 'files': sorted(os.listdir(tmp))}
+    for kind, pat in (('sample', 'sample_5-{}.wav'), ('gtruth', 'gtruth_{}.wav'),
+                      ('noisy_wav', 'noisy_{}.wav'), ('dif', 'dif_{}.wav')):
+        rows = []
+        for m in range(3):
+            rate, data = wavfile.read(os.path.join(tmp, pat.format(m)))
+            assert rate == 16000
+            rows.append(torch.from_numpy(np.asarray(data, dtype=np.float32)))
+        fx[kind] = torch.stack(rows)
+    shutil.rmtree(tmp, ignore_errors=True)
+    torch.save(fx, os.path.join(OUT, 'train_samples.pt'))
+    print('train_samples.pt done', fx['files'])
+
+
 def main():
     ref = ref_harness.import_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == 'samples':
+        make_train_samples(ref)
+        return
     import importlib
     ref_ds = importlib.import_module('segan.datasets.se_dataset')
     ref_utils = importlib.import_module('segan.utils')

@@ -32,7 +32,10 @@ from .generator import Generator
 
 try:  # logging is optional plumbing (not installed in every image)
     from tensorboardX import SummaryWriter
+    _HAVE_TBX = True
 except Exception:  # pragma: no cover
+    _HAVE_TBX = False
+
     class SummaryWriter(object):
         def __init__(self, *a, **k):
             pass
@@ -174,6 +177,55 @@ class SEGAN(Model):
         # into the first conv's two-pointer load
         return self.D(x_, ref)
 
+    def gen_train_samples(self, clean_samples, noisy_samples, z_sample, iteration=None):
+        """The periodic listening samples of the training loop (model.py:177-217): G on the first
+        (up to) 20 slices of the first batch with the z of the first step, de-emphasised and
+        written as save_path/sample_<iteration>-<m>.wav; on the first call also gtruth_<m>.wav,
+        noisy_<m>.wav and dif_<m>.wav.  The de-emphasis of all slices is one scan kernel."""
+        from scipy.io import wavfile
+        with torch.no_grad():
+            if z_sample is not None:
+                canvas_w = self.infer_G(noisy_samples, clean_samples, z=z_sample)
+            else:
+                canvas_w = self.infer_G(noisy_samples, clean_samples)
+
+        def rows(t):
+            t = t[:, 0].contiguous().float()
+            if t.is_cuda:
+                from .. import ops
+                return (ops.de_emphasize(t, self.preemph) if self.preemph > 0 else t).cpu().numpy()
+            return np.stack([de_emphasize(r.numpy(), self.preemph) for r in t])
+
+        canvas = rows(canvas_w)
+        n = noisy_samples.size(0)
+        missing = [m for m in range(n)
+                   if not os.path.exists(os.path.join(self.save_path, 'gtruth_{}.wav'.format(m)))]
+        if missing:
+            cl, no, di = rows(clean_samples), rows(noisy_samples), rows(noisy_samples - clean_samples)
+        for m in range(n):
+            m_canvas = canvas[m]
+            print('w{} max: {} min: {}'.format(m, m_canvas.max(), m_canvas.min()))
+            wavfile.write(os.path.join(self.save_path, 'sample_{}-{}.wav'.format(iteration, m)),
+                          int(16e3), m_canvas)
+            if m in missing:
+                wavfile.write(os.path.join(self.save_path, 'gtruth_{}.wav'.format(m)), int(16e3), cl[m])
+                wavfile.write(os.path.join(self.save_path, 'noisy_{}.wav'.format(m)), int(16e3), no[m])
+                wavfile.write(os.path.join(self.save_path, 'dif_{}.wav'.format(m)), int(16e3), di[m])
+
+    def _log_weight_norms(self, iteration):
+        """model.py:372-386: per-layer and total weight norms of G and D (scalars for the
+        tensorboard writer; skipped when no writer is installed)."""
+        if not _HAVE_TBX:
+            return
+        for model, total_name in ((self.G, 'Gtotal'), (self.D, 'Dtotal')):
+            total = 0.0
+            for k, v in model.named_parameters():
+                if 'weight' in k:
+                    wn = float(torch.norm(v.data))
+                    self.writer.add_scalar('{}_Wnorm'.format(k), wn, iteration)
+                    total += wn
+            self.writer.add_scalar('{}_Wnorm'.format(total_name), total, iteration)
+
     # ---- training ---------------------------------------------------------------------
     def build_optimizers(self, opts):
         if opts.opt == 'rmsprop':
@@ -237,9 +289,6 @@ class SEGAN(Model):
             raise NotImplementedError('criterion {}: the step runs nn.MSELoss (train.py:94) or '
                                       'BCEWithLogitsLoss natively; other criteria are not '
                                       'implemented'.format(type(criterion).__name__))
-        if not getattr(opts, 'no_train_gen', True):
-            print('note: the periodic sample_*.wav dumps of the reference (gen_train_samples, '
-                  'model.py:350-392) are not produced; use clean.py on a checkpoint instead')
         self.writer = SummaryWriter(os.path.join(self.save_path, 'train'))
         Gopt, Dopt = self.build_optimizers(opts)
         self.G.optim = Gopt
@@ -254,6 +303,8 @@ class SEGAN(Model):
         l1_weight = l1_init
         iteration = 1
         timings = []
+        clean_samples = noisy_samples = z_sample = None
+        train_gen = is_main and not getattr(opts, 'no_train_gen', True)
         best_val_obj, patience = None, getattr(opts, 'patience', 100)
         for epoch in range(1, opts.epoch + 1):
             beg_t = timeit.default_timer()
@@ -270,11 +321,17 @@ class SEGAN(Model):
                 uttname, clean, noisy, slice_idx = batch
                 clean = clean.unsqueeze(1).to(device)
                 noisy = noisy.unsqueeze(1).to(device)
+                if train_gen and noisy_samples is None:      # model.py:288-290
+                    noisy_samples = noisy[:20, :, :].contiguous()
+                    clean_samples = clean[:20, :, :].contiguous()
                 d_real_loss, d_fake_loss, g_adv_loss, g_l1_loss = self.gan_step(
                     clean, noisy, Gopt, Dopt, criterion, l1_weight)
                 end_t = timeit.default_timer()
                 timings.append(end_t - beg_t)
                 beg_t = timeit.default_timer()
+                if train_gen and z_sample is None and not self.G.no_z:   # model.py:325-330
+                    z_sample = self.G.z[:20, :, :].contiguous().to(device)
+                    print('z_sample size: ', z_sample.size())
                 if is_main and (bidx % log_freq == 0 or bidx >= len(dloader)):
                     vals = [v.cpu().item() for v in
                             (d_real_loss, d_fake_loss, g_adv_loss, g_l1_loss)]
@@ -285,6 +342,10 @@ class SEGAN(Model):
                                                     l1_weight, timings[-1], np.mean(timings)))
                     for k, v in zip(('D_real', 'D_fake', 'G_adv', 'G_l1'), vals):
                         self.writer.add_scalar(k, v, iteration)
+                    self._log_weight_norms(iteration)
+                    if train_gen:
+                        self.gen_train_samples(clean_samples, noisy_samples, z_sample,
+                                               iteration=iteration)
                 iteration += 1
             if va_dloader is not None:
                 # validation (model.py:394-433).  The reference's objective adds COVL and PESQ,
@@ -452,14 +513,22 @@ class WSEGAN(SEGAN):
         eoe_d_saver = Saver(self.D, opts.save_path, max_ckpts=3, optimizer=Dopt, prefix='EOE_D-')
         l1_weight = l1_init     # never decays here (model.py:655-667)
         timings = []
+        clean_samples = noisy_samples = z_sample = None
+        train_gen = is_main and not getattr(opts, 'no_train_gen', True)
         self.G.train()
         self.D.train()
         for iteration in range(1, opts.epoch * len(dloader) + 1):
             beg_t = timeit.default_timer()
             uttname, clean, noisy, _ = self.sample_dloader(dloader, device)
+            if train_gen and noisy_samples is None:          # model.py:673-675
+                noisy_samples = noisy[:20, :, :].contiguous()
+                clean_samples = clean[:20, :, :].contiguous()
             d_loss, G_cost, pow_loss, den_loss = self.wgan_step(uttname, clean, noisy, Gopt, Dopt,
                                                                 l1_weight)
             timings.append(timeit.default_timer() - beg_t)
+            if train_gen and z_sample is None and not self.G.no_z:       # model.py:676-681
+                z_sample = self.G.z[:20, :, :].contiguous().to(device)
+                print('z_sample size: ', z_sample.size())
             if is_main and iteration % log_freq == 0:
                 print('Iter {}/{} ({} bpe) d_loss:{:.4f}, g_loss: {:.4f}, pow_loss: {:.4f}, '
                       'den_loss: {:.4f} btime: {:.4f} s, mbtime: {:.4f} s'.format(
@@ -468,6 +537,10 @@ class WSEGAN(SEGAN):
                           np.mean(timings)))
                 self.writer.add_scalar('D_loss', d_loss.item(), iteration)
                 self.writer.add_scalar('G_loss', G_cost.item(), iteration)
+                self._log_weight_norms(iteration)
+                if train_gen:                                # model.py:744-747
+                    self.gen_train_samples(clean_samples, noisy_samples, z_sample,
+                                           iteration=iteration)
             if is_main and iteration % len(dloader) == 0:
                 self.G.save(self.save_path, iteration, saver=eoe_g_saver)
                 self.D.save(self.save_path, iteration, saver=eoe_d_saver)

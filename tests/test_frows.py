@@ -154,3 +154,46 @@ def test_train_with_validation_runs(frows, tmp_path):
     assert any('best_Generator' in n_ for n_ in names), names
     ev, nev = m.evaluate(SimpleNamespace(**o), va, 1, do_noisy=True, device='cuda')
     assert len(ev['ssnr']) == 2 and len(nev['ssnr']) == 2 and all(-10 <= v <= 35 for v in ev['ssnr'])
+
+
+# ---- the listening samples of the training loop (model.py:177-217) -------------------------------
+def _check_train_samples(device, tmp_path):
+    from scipy.io import wavfile
+    from segan_pytorch_amd.models import SEGAN
+    fx = load_golden('train_samples.pt')
+    o = dict(fx['opts'])
+    o['save_path'] = str(tmp_path)
+    m = SEGAN(SimpleNamespace(**o))
+    m.G.load_state_dict(fx['G0'])
+    m.to(device)
+    m.G.train()
+    m.gen_train_samples(fx['clean'].to(device), fx['noisy'].to(device), fx['z'].to(device),
+                        iteration=fx['iteration'])
+    assert sorted(os.listdir(str(tmp_path))) == fx['files']
+    for kind, pat in (('sample', 'sample_5-{}.wav'), ('gtruth', 'gtruth_{}.wav'),
+                      ('noisy_wav', 'noisy_{}.wav'), ('dif', 'dif_{}.wav')):
+        for i in range(3):
+            rate, data = wavfile.read(str(tmp_path / pat.format(i)))
+            assert rate == 16000 and data.dtype == np.float32
+            # de-emphasis amplifies by up to 1/(1-0.95): compare relative to the signal's peak
+            assert max_rel(torch.from_numpy(data), fx[kind][i]) < 2e-5, (kind, i)
+    # a second call leaves the one-off files alone and adds the new samples
+    m.gen_train_samples(fx['clean'].to(device), fx['noisy'].to(device), fx['z'].to(device),
+                        iteration=9)
+    assert len(os.listdir(str(tmp_path))) == len(fx['files']) + 3
+
+
+def test_training_samples_host_logic_matches_reference(tmp_path):
+    """gen_train_samples with the kernels emulated on CPU (tests/emu_ops.py): file set and
+    contents against the reference's."""
+    import emu_ops
+    emu_ops.install()
+    try:
+        _check_train_samples('cpu', tmp_path)
+    finally:
+        emu_ops.uninstall()
+
+
+@pytest.mark.gpu
+def test_training_samples_match_reference_on_gpu(tmp_path):
+    _check_train_samples('cuda', tmp_path)

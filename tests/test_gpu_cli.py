@@ -68,6 +68,8 @@ def test_train_wsegan_snorm_from_a_pcm_shard(tmp_path):
     assert out.returncode == 0, out.stderr[-2000:]
     names = os.listdir(ck)
     assert any(n_.startswith('weights_EOE_G-Generator-') for n_ in names)
+    # no --no_train_gen: the listening samples of model.py:744-747 are written at every log step
+    assert any(n_.startswith('sample_') for n_ in names) and 'gtruth_0.wav' in names, names
 
 
 def test_train_from_wav_dirs_with_a_validation_set(tmp_path):
