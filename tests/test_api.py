@@ -165,3 +165,37 @@ def test_saver_rotation_matches_reference_format(tmp_path):
     assert files == ['weights_EOE_G-Generator-{}.ckpt'.format(s) for s in (3, 4, 5)]
     ck = torch.load(os.path.join(str(tmp_path), files[-1]), weights_only=False)
     assert set(ck.keys()) == {'step', 'state_dict'} and ck['step'] == 5
+
+
+def test_weight_pack_cache_follows_the_optimizer_epoch(monkeypatch):
+    """A packed weight copy is refreshed when the fused optimizer has touched the weight through
+    raw pointers (ops.bump_weights_epoch marks the PARAMETER object): callers must hand the
+    parameter itself to the pack, not a detached alias, which carries no mark."""
+    from segan_pytorch_amd import _lib, ops
+    calls = []
+
+    class FakeLib(object):
+        def segan_packed_g_bytes(self, M, N, S):
+            return M * N * 32 * 4
+
+        def segan_pack_weights_g(self, w, wg, M, N, K, S, stream):
+            calls.append((M, N, K, S))
+            return 0
+
+    monkeypatch.setattr(_lib, 'load', lambda: FakeLib())
+    monkeypatch.setattr(ops, '_chk', lambda t, name, ndim=None: t)
+    monkeypatch.setattr(ops, '_stream', lambda: None)
+    w = torch.nn.Parameter(torch.randn(16, 8, 31))
+    pack = ops.WeightPack()
+    a = pack.g(w, 4)
+    assert pack.g(w, 4) is a and len(calls) == 1            # cached
+    ops.bump_weights_epoch([w])                              # what the fused optimizers do
+    pack.g(w, 4)
+    assert len(calls) == 2                                   # re-packed
+    with torch.no_grad():
+        w.add_(1.0)                                          # an in-place torch update: version counter
+    pack.g(w, 4)
+    assert len(calls) == 3
+    ops.bump_weights_epoch()                                 # global invalidation (DP broadcast)
+    pack.g(w, 4)
+    assert len(calls) == 4
