@@ -25,6 +25,11 @@ tiny_variants.pt (python oracle/make_golden.py variants) one GAN step of the tin
                  --skip_type conv (concat and sum merges), stride-1 (pooling 1) layers in the
                  encoder and the decoder (generator.py:171-176), a conv block as last decoder
                  layer, --dpool_type conv / gmax / gavg (discriminator.py:122-137).
+tiny_gvariants.pt (python oracle/make_golden.py gvariants) the Generator options no train.py flag
+                 reaches (model.py:82-96 never passes them): norm_type='bnorm' (BatchNorm in
+                 every block, generator.py:126,166-176) and skip_dropout (generator.py:53-54,
+                 70-71), alone and combined: output, eval-mode output and all gradients of a
+                 linear loss, with the torch seed that drives the dropout masks.
 """
 import json
 import os
@@ -278,6 +283,43 @@ def make_variants(ref):
     print('tiny_variants.pt done')
 
 
+GVARIANTS = {
+    'bnorm_concat': dict(norm_type='bnorm', skip_merge='concat'),
+    'bnorm_sum': dict(norm_type='bnorm', skip_merge='sum'),
+    'dropout_alpha': dict(skip_dropout=0.3, skip_merge='concat'),
+    'dropout_conv_sum': dict(skip_dropout=0.3, skip_type='conv', skip_merge='sum'),
+    'bnorm_dropout': dict(norm_type='bnorm', skip_dropout=0.2, skip_merge='concat'),
+}
+
+
+def make_gvariants(ref):
+    out = {}
+    for i, (name, kw) in enumerate(GVARIANTS.items()):
+        seed_all(300 + i)
+        kwargs = dict(z_dim=16, bias=True, skip_init='randn')
+        kwargs.update(kw)
+        G = ref.Generator(1, [4, 8, 16], 31, [4, 4, 4], **kwargs)
+        G.train()
+        g0 = clone_sd(G)
+        gen = torch.Generator().manual_seed(400 + i)
+        x = torch.rand(3, 1, 1024, generator=gen) * 2 - 1
+        z = torch.randn(3, 16, 16, generator=gen)
+        c = torch.randn(3, 1, 1024, generator=gen)
+        fwd_seed = 500 + i
+        torch.manual_seed(fwd_seed)                 # drives the dropout masks of this forward
+        y = G(x, z=z)
+        (y * c).sum().backward()
+        fx = {'kwargs': kwargs, 'G0': g0, 'x': x, 'z': z, 'c': c, 'fwd_seed': fwd_seed,
+              'y': y.detach().clone(), 'grads': grads_of(G), 'G_after_fwd': clone_sd(G)}
+        G.eval()
+        with torch.no_grad():
+            fx['y_eval'] = G(x, z=z).clone()
+        out[name] = fx
+        print(name, tuple(y.shape), float(y.abs().mean()), sorted(fx['grads'])[:3])
+    torch.save(out, os.path.join(OUT, 'tiny_gvariants.pt'))
+    print('tiny_gvariants.pt done')
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = ref_harness.import_reference()
@@ -291,6 +333,9 @@ def main():
         return
     if len(sys.argv) > 1 and sys.argv[1] == 'variants':
         make_variants(ref)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == 'gvariants':
+        make_gvariants(ref)
         return
 
     # ---------------- tiny_step ----------------

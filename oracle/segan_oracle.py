@@ -59,14 +59,25 @@ def gconv_block(x, w, b, slope, stride, bn=None, training=True):
     return h, a
 
 
-def gdeconv_block(x, w, b, slope, stride, tanh=False):
+def gdeconv_block(x, w, b, slope, stride, tanh=False, bn=None, training=True):
     """modules.py:135-141 (pad from modules.py:115)."""
     K = w.shape[2]
     pad = max(0, (stride - K) // -2)
     h = F.conv_transpose1d(x, w, b, stride=stride, padding=pad)
     if K % 2 != 0:
         h = h[:, :, :-1]
+    if bn is not None:
+        h = F.batch_norm(h, bn['running_mean'], bn['running_var'], bn['weight'], bn['bias'],
+                         training, 0.1, 1e-5)
     return torch.tanh(h) if tanh else F.prelu(h, slope)
+
+
+def _bn_of(sd, p):
+    """The BatchNorm1d of block prefix `p` as a dict, or None (build_norm_layer, modules.py:9-18)."""
+    if p + 'norm.weight' not in sd:
+        return None
+    return {'weight': sd[p + 'norm.weight'], 'bias': sd[p + 'norm.bias'],
+            'running_mean': sd[p + 'norm.running_mean'], 'running_var': sd[p + 'norm.running_var']}
 
 
 def spectral_weight(sd, prefix, dim=0, training=True, eps=1e-12):
@@ -109,11 +120,14 @@ def _count(sd, prefix):
 
 
 def generator_forward(sd, x, z, strides, dec_strides=None, ret_hid=False, training=True,
-                      skip_merge='concat'):
+                      skip_merge='concat', skip_dropout=0.0):
     """generator.py:180-230.  The architecture is read off the state_dict: a level has a skip
     when ``alpha_<l>.skip_k`` (alpha / constant) or ``alpha_<l>.skip_k.weight`` (conv skip,
     generator.py:42-49) exists; a decoder block is a transposed conv (``deconv``) or, for a
-    pooling of 1, a GConv1DBlock (``conv``, generator.py:171-176)."""
+    pooling of 1, a GConv1DBlock (``conv``, generator.py:171-176); a block has a BatchNorm1d
+    when ``norm.weight`` exists (norm_type='bnorm'; the running buffers in `sd` are updated in
+    place in training mode).  `skip_dropout` > 0: nn.Dropout on the skip path
+    (generator.py:53-54,70-71), drawing its masks from torch's global RNG like the reference."""
     n_enc = _count(sd, 'enc_blocks')
     n_dec = _count(sd, 'dec_blocks')
     dec_strides = dec_strides or list(strides)
@@ -123,7 +137,7 @@ def generator_forward(sd, x, z, strides, dec_strides=None, ret_hid=False, traini
     for l in range(n_enc):
         p = 'enc_blocks.{}.'.format(l)
         hi, lin = gconv_block(hi, _weight(sd, p + 'conv.', 0, training), sd.get(p + 'conv.bias'),
-                              sd[p + 'act.weight'], strides[l])
+                              sd[p + 'act.weight'], strides[l], bn=_bn_of(sd, p), training=training)
         if l < n_enc - 1 and ('alpha_{}.skip_k'.format(l) in sd or
                               'alpha_{}.skip_k.weight'.format(l) in sd):
             skips[l] = lin                       # the PRE-activation (generator.py:185,191)
@@ -143,16 +157,20 @@ def generator_forward(sd, x, z, strides, dec_strides=None, ret_hid=False, traini
             else:
                 alpha = sd['alpha_{}.skip_k'.format(enc_idx)]
                 sk = alpha.repeat(hi.size(0), 1, hj.size(2)) * hj
+            if skip_dropout > 0:
+                sk = F.dropout(sk, skip_dropout, training)
             # GSkip merge, generator.py:64-76
             hi = torch.cat((hi, sk), dim=1) if skip_merge == 'concat' else sk + hi
         p = 'dec_blocks.{}.'.format(l)
         if p + 'conv.weight' in sd or p + 'conv.weight_orig' in sd:
             hi, _ = gconv_block(hi, _weight(sd, p + 'conv.', 0, training), sd.get(p + 'conv.bias'),
-                                sd[p + 'act.weight'], dec_strides[l])
+                                sd[p + 'act.weight'], dec_strides[l], bn=_bn_of(sd, p),
+                                training=training)
         else:
             last = (p + 'act.weight') not in sd
             hi = gdeconv_block(hi, _weight(sd, p + 'deconv.', 1, training), sd[p + 'deconv.bias'],
-                               sd.get(p + 'act.weight'), dec_strides[l], tanh=last)
+                               sd.get(p + 'act.weight'), dec_strides[l], tanh=last,
+                               bn=_bn_of(sd, p), training=training)
         enc_idx -= 1
         hall['dec_{}'.format(l)] = hi
     return (hi, hall) if ret_hid else hi
@@ -168,11 +186,7 @@ def discriminator_forward(sd, x, rolls, strides, training=True, ret_act=False, p
     for l in range(n):
         p = 'enc_blocks.{}.'.format(l)
         h = roll(h, rolls[l])
-        bn = None
-        if p + 'norm.weight' in sd:
-            bn = {'weight': sd[p + 'norm.weight'], 'bias': sd[p + 'norm.bias'],
-                  'running_mean': sd[p + 'norm.running_mean'],
-                  'running_var': sd[p + 'norm.running_var']}
+        bn = _bn_of(sd, p)
         h, _ = gconv_block(h, _weight(sd, p + 'conv.', 0, training), sd.get(p + 'conv.bias'),
                            sd[p + 'act.weight'], strides[l], bn=bn, training=training)
         acts['h_{}'.format(l)] = h

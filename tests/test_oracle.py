@@ -93,6 +93,36 @@ def test_generator_with_spectral_norm(tiny_snorm):
         assert max_rel(sd[k], v) < TOL, k
 
 
+GVARIANT_NAMES = ('bnorm_concat', 'bnorm_sum', 'dropout_alpha', 'dropout_conv_sum', 'bnorm_dropout')
+
+
+@pytest.mark.parametrize('name', GVARIANT_NAMES)
+def test_generator_options_no_flag_reaches(name):
+    """Generator(norm_type='bnorm') and skip_dropout (generator.py:53-54,126,166-176): output,
+    gradients, BatchNorm buffers after the forward and the eval-mode output of the REAL reference
+    (oracle/make_golden.py gvariants); dropout masks replayed from the recorded torch seed."""
+    from conftest import load_golden
+    g = load_golden('tiny_gvariants.pt')[name]
+    kw = g['kwargs']
+    sd = O._leafs(g['G0'])
+    torch.manual_seed(g['fwd_seed'])
+    y = O.generator_forward(sd, g['x'], g['z'], [4, 4, 4], skip_merge=kw['skip_merge'],
+                            skip_dropout=kw.get('skip_dropout', 0.0))
+    assert max_rel(y, g['y']) < TOL
+    keys = [k for k in sd if sd[k].requires_grad]
+    grads = torch.autograd.grad((y * g['c']).sum(), [sd[k] for k in keys])
+    for k, gr in zip(keys, grads):
+        assert max_rel(gr, g['grads'][k]) < 1e-4, k
+    for k, v in g['G_after_fwd'].items():            # running statistics after one forward
+        if torch.is_floating_point(v):
+            assert max_rel(sd[k], v) < TOL, k
+    with torch.no_grad():
+        ye = O.generator_forward(sd, g['x'], g['z'], [4, 4, 4], training=False,
+                                 skip_merge=kw['skip_merge'],
+                                 skip_dropout=kw.get('skip_dropout', 0.0))
+    assert max_rel(ye, g['y_eval']) < TOL
+
+
 def test_tiny_literal_train_replay(tiny_train2):
     """Replay the reference's literal SEGAN.train (two batches): z comes from the global
     torch RNG (generator.py:197), the phase shifts from python's random
