@@ -184,6 +184,15 @@ int segan_bn_final(const float* ws, int nsplit_total, const float* gamma, const 
                    float eps, float momentum, float* running_mean, float* running_var, float* mean,
                    float* rstd, float* scale, float* shift, int C, void* stream);
 
+/* y = tanh(x*scale[c] + shift[c]) on [B, C, L] (scale / shift may be NULL): the generator's
+ * last block when it carries a BatchNorm (modules.py:135-141 with norm_type='bnorm'). */
+int segan_affine_tanh(const float* x, const float* scale, const float* shift, float* y, int B,
+                      int C, int L, void* stream);
+/* y = x * scale[c] * mask on [B, C, L] (scale may be NULL; y may alias x): nn.Dropout on the skip
+ * path (generator.py:53-54,70-71) with mask = 0 or 1/(1-p) per element, and its backward. */
+int segan_scale_mask(const float* x, const float* scale, const float* mask, float* y, int B, int C,
+                     int L, void* stream);
+
 /* y = prelu(x*scale[c] + shift[c], slope[c]) materialised (used for the FC input
  * h.view(B,-1) of discriminator.py:181 and for int_act / ret_hid outputs). */
 int segan_affine_prelu(const float* x, const float* scale, const float* shift, const float* slope,

@@ -57,6 +57,8 @@ SIGNATURES = {
     'segan_act_bwd_bn_reduce': (c_int, [_P] * 12 + [c_int, c_int, c_int, _P]),
     'segan_act_bwd_bn_apply': (c_int, [_P] * 11 + [c_int, c_int, c_int, c_double, _P]),
     'segan_affine_prelu': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    'segan_affine_tanh': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    'segan_scale_mask': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
     'segan_sum_skip': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     'segan_bce_logits_const': (c_int, [_P, c_float, _P, _P, _P, c_float, c_int, _P]),
     'segan_act_bwd': (c_int, [_P] * 16 + [c_int, c_int, c_int, _P]),

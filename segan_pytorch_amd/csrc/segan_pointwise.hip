@@ -220,6 +220,52 @@ extern "C" int segan_affine_prelu(const float* x, const float* scale, const floa
   return segan_check_launch("affine_prelu");
 }
 
+// y = tanh(x*scale + shift): the last generator block when it carries a BatchNorm
+// (GDeconv1DBlock with norm_type='bnorm' and act='Tanh', modules.py:135-141)
+__global__ void affine_tanh_kernel(const float* __restrict__ x, const float* scale,
+                                   const float* shift, float* __restrict__ y, size_t total, int C,
+                                   int L) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)((i / L) % C);
+    y[i] = tanhf(fmaf(x[i], scale ? scale[c] : 1.0f, shift ? shift[c] : 0.0f));
+  }
+}
+
+extern "C" int segan_affine_tanh(const float* x, const float* scale, const float* shift, float* y,
+                                 int B, int C, int L, void* stream) {
+  SEGAN_REQUIRE(x && y, "affine_tanh: NULL pointer");
+  SEGAN_REQUIRE(B > 0 && C > 0 && L > 0, "affine_tanh: bad sizes");
+  const size_t total = (size_t)B * C * L;
+  const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipLaunchKernelGGL(affine_tanh_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, scale,
+                     shift, y, total, C, L);
+  return segan_check_launch("affine_tanh");
+}
+
+// y = x * scale[c] * mask: nn.Dropout on the skip path (generator.py:53-54,70-71) — mask holds
+// 0 or 1/(1-p) per element — with the alpha skip scale folded in (scale may be NULL)
+__global__ void scale_mask_kernel(const float* __restrict__ x, const float* scale,
+                                  const float* __restrict__ mask, float* __restrict__ y,
+                                  size_t total, int C, int L) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)((i / L) % C);
+    y[i] = x[i] * (scale ? scale[c] : 1.0f) * mask[i];
+  }
+}
+
+extern "C" int segan_scale_mask(const float* x, const float* scale, const float* mask, float* y,
+                                int B, int C, int L, void* stream) {
+  SEGAN_REQUIRE(x && mask && y, "scale_mask: NULL pointer");
+  SEGAN_REQUIRE(B > 0 && C > 0 && L > 0, "scale_mask: bad sizes");
+  const size_t total = (size_t)B * C * L;
+  const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipLaunchKernelGGL(scale_mask_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, scale,
+                     mask, y, total, C, L);
+  return segan_check_launch("scale_mask");
+}
+
 // out = prelu(x0, slope0) + alpha * x1   (GSkip with merge_mode 'sum', generator.py:64-74)
 __global__ void sum_skip_kernel(const float* __restrict__ x0, const float* slope0,
                                 const float* __restrict__ x1, const float* alpha,

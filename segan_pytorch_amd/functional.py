@@ -135,19 +135,59 @@ class _Weights(object):
         ops.snorm_bwd(tmp, mod.weight_orig.detach(), u, v, sigma, dim, grad_buf(mod.weight_orig))
 
 
-def _skip_conv_bwd(gskip, dsk, aj):
-    """Backward of GSkip 'conv' (generator.py:42-49,65-66), sk = conv1d(aj, Wk, bk, stride 1,
-    zero padding kw//2): accumulates dWk / dbk, returns the gradient w.r.t. aj.  The data
-    gradient of a stride-1 zero-padded conv is the same kernel run with the weight transposed
-    and flipped (padding kw - 1 - kw//2)."""
+def _skip_conv_bwd(gskip, dsk, src_j):
+    """Backward of GSkip 'conv' (generator.py:42-49,65-66), sk = conv1d(h_j, Wk, bk, stride 1,
+    zero padding kw//2) with h_j given as a Src (the encoder's linear output, normalised on load
+    when the block has a BatchNorm): accumulates dWk / dbk, returns the gradient w.r.t. h_j.
+    The data gradient of a stride-1 zero-padded conv is the same kernel run with the weight
+    transposed and flipped (padding kw - 1 - kw//2)."""
     mod = gskip.skip_k
     kw = mod.kernel_size[0]
     if mod.bias is not None and mod.bias.requires_grad:
         ops.act_bwd(dsk, dsk, dbias=grad_buf(mod.bias))          # dbk += sum over (b, t)
     if mod.weight.requires_grad:
-        ops.wgrad(Src(dsk), Src(aj), grad_buf(mod.weight), kw, 1, kw // 2, PAD_ZERO)
+        ops.wgrad(Src(dsk), src_j, grad_buf(mod.weight), kw, 1, kw // 2, PAD_ZERO)
     wt = mod.weight.detach().transpose(0, 1).flip(2).contiguous()
     return ops.conv1d_fwd(Src(dsk), wt, None, 1, pad_mode=PAD_ZERO, padL=kw - 1 - kw // 2)
+
+
+def _block_norm(blk, c, training):
+    """BatchNorm of a generator block applied to its conv output c (build_norm_layer 'bnorm',
+    modules.py:9-11): (scale, shift) for the consumers' on-load transform and what the backward
+    needs — (mean, rstd, gamma, beta) in training mode, 'eval' with the running statistics —
+    or (None, None, None) for a block without one."""
+    bn = getattr(blk, 'norm', None)
+    if bn is None:
+        return None, None, None
+    if training:
+        mean, rstd, scale, shift = _bn_train_stats(c, bn)
+        if bn.num_batches_tracked is not None:
+            bn.num_batches_tracked += 1
+        return scale, shift, (mean, rstd, bn.weight, bn.bias)
+    rstd = torch.rsqrt(bn.running_var + bn.eps)
+    scale = (bn.weight.detach() * rstd).contiguous()
+    shift = (bn.bias.detach() - bn.running_mean * scale).contiguous()
+    return scale, shift, 'eval'
+
+
+def _vec2(v0, n0, v1, n1, fill, ref):
+    """Per-channel vector over two concatenated channel groups; None stands for `fill`
+    everywhere in a group, and the result is None when both groups are."""
+    if v0 is None and v1 is None:
+        return None
+    parts = []
+    for v, n in ((v0, n0), (v1, n1)):
+        parts.append(v.detach().reshape(-1) if v is not None else
+                     torch.full((n,), fill, device=ref.device, dtype=torch.float32))
+    return torch.cat(parts)
+
+
+def _dropout_mask(shape, p, device):
+    """The noise nn.Dropout multiplies with (0 or 1/(1-p)), drawn from torch's global CPU
+    generator exactly as the reference's CPU run draws it (F.dropout of a same-shaped tensor),
+    then moved to the device."""
+    noise = torch.nn.functional.dropout(torch.ones(shape), p, True)
+    return noise.to(device)
 
 
 # =====================================================================================
@@ -161,82 +201,130 @@ class GeneratorFn(torch.autograd.Function):
         x = x.contiguous()
         enc, dec = list(gen.enc_blocks), list(gen.dec_blocks)
         n_enc = len(enc)
-        a_enc, src_enc = [], []
+        training = gen.training
+        a_enc, src_enc, xf_enc, bn_enc = [], [], [], []
         src = Src(x)
         W = _Weights()
         for blk in enc:
             a = ops.conv1d_fwd(src, W.get(blk.conv), blk.conv.bias, blk.stride, pack=blk._pack)
+            sc, sh, bnsv = _block_norm(blk, a, training)
             src_enc.append(src)
             a_enc.append(a)
-            src = Src(a, slope=blk.act.weight)
+            xf_enc.append((sc, sh))
+            bn_enc.append(bnsv)
+            src = Src(a, scale=sc, shift=sh, slope=blk.act.weight)
         last = a_enc[-1]
         s_last = enc[-1].act.weight
+        sc_l, sh_l = xf_enc[-1]
         if not gen.no_z:
             z = z.contiguous()
-            src = Src(z, last, slope=_cat(_ones(z.shape[1], z), s_last))
+            nz, nl = z.shape[1], last.shape[1]
+            src = Src(z, last, scale=_vec2(None, nz, sc_l, nl, 1.0, z),
+                      shift=_vec2(None, nz, sh_l, nl, 0.0, z), slope=_cat(_ones(nz, z), s_last))
         else:
-            src = Src(last, slope=s_last)
-        a_dec, src_dec = [], []
+            src = Src(last, scale=sc_l, shift=sh_l, slope=s_last)
+        a_dec, src_dec, xf_dec, bn_dec = [], [], [], []
+        skip_saved = {}     # enc index -> (dropout mask or None, materialised bn(a_j) or None)
         enc_idx = n_enc - 1
         for li, blk in enumerate(dec):
             is_conv = hasattr(blk, 'conv')       # pooling 1: a GConv1DBlock (generator.py:171-176)
             if li > 0:
                 prev = a_dec[-1]
                 s_prev = dec[li - 1].act.weight
+                sc_p, sh_p = xf_dec[-1]
+                np_ = prev.shape[1]
                 if gen.skip and enc_idx in gen.skips and gen.dec_poolings[li] > 1:
                     gskip = gen.skips[enc_idx]['alpha']
                     aj = a_enc[enc_idx]
-                    ones_j = _ones(aj.shape[1], aj)
+                    sc_j, sh_j = xf_enc[enc_idx]
+                    nj = aj.shape[1]
+                    ones_j = _ones(nj, aj)
+                    drop_p = gskip.skip_dropout.p if (training and hasattr(gskip, 'skip_dropout')) \
+                        else 0.0
+                    a_norm = None
                     if gskip.skip_type == 'conv':
                         # GSkip 'conv' (generator.py:42-49,65-66): a stride-1 zero-padded conv of
-                        # the encoder's pre-activation, materialised; the merge stays fused
+                        # the encoder's linear output, materialised; the merge stays fused
                         kw = gskip.skip_k.kernel_size[0]
-                        sk = ops.conv1d_fwd(Src(aj), W.get(gskip.skip_k), gskip.skip_k.bias, 1,
-                                            pad_mode=PAD_ZERO, padL=kw // 2, pack=gskip._pack)
+                        sk = ops.conv1d_fwd(Src(aj, scale=sc_j, shift=sh_j), W.get(gskip.skip_k),
+                                            gskip.skip_k.bias, 1, pad_mode=PAD_ZERO, padL=kw // 2,
+                                            pack=gskip._pack)
                         scale_j = ones_j
                     else:
-                        sk = aj
+                        if sc_j is not None:     # the linear output is the NORMALISED one
+                            a_norm = ops.affine_prelu(aj, sc_j, sh_j, None)
+                        sk = aj if a_norm is None else a_norm
                         scale_j = gskip.skip_k
+                    mask = None
+                    if drop_p > 0:               # nn.Dropout on sk_h (generator.py:70-71)
+                        mask = _dropout_mask(tuple(sk.shape), drop_p, sk.device)
+                        fold = None if gskip.skip_type == 'conv' else \
+                            scale_j.detach().reshape(-1).contiguous()
+                        sk = ops.scale_mask(sk, fold, mask)
+                        scale_j = ones_j         # alpha is folded into the masked tensor
+                    skip_saved[enc_idx] = (mask, a_norm)
                     if gskip.merge_mode == 'concat':
                         src = Src(prev, sk,
-                                  scale=_cat(_ones(prev.shape[1], prev), scale_j),
+                                  scale=_cat(sc_p if sc_p is not None else _ones(np_, prev), scale_j),
+                                  shift=_vec2(sh_p, np_, None, nj, 0.0, prev),
                                   slope=_cat(s_prev, ones_j))
-                    else:   # 'sum' (generator.py:71-73): prelu(prev) + alpha*a_j, materialised
-                        src = Src(ops.sum_skip(prev, s_prev, sk, scale_j.detach().reshape(-1)))
+                    else:   # 'sum' (generator.py:71-73): prelu(prev) + skip, materialised
+                        hp, sl0 = prev, s_prev
+                        if sc_p is not None:
+                            hp, sl0 = ops.affine_prelu(prev, sc_p, sh_p, s_prev), None
+                        src = Src(ops.sum_skip(hp, sl0, sk, scale_j.detach().reshape(-1)))
                         src.sum_of = True
                 else:
-                    src = Src(prev, slope=s_prev)
+                    src = Src(prev, scale=sc_p, shift=sh_p, slope=s_prev)
+            has_bn = getattr(blk, 'norm', None) is not None
             if is_conv:
                 a = ops.conv1d_fwd(src, W.get(blk.conv), blk.conv.bias, blk.stride,
                                    pack=blk._pack)
             else:
-                act = ACT_TANH if blk.is_tanh else ACT_NONE
+                # the Tanh is fused into the deconv's epilogue unless a BatchNorm sits between
+                act = ACT_TANH if (blk.is_tanh and not has_bn) else ACT_NONE
                 a = ops.deconv1d_fwd(src, W.get(blk.deconv), blk.deconv.bias, blk.stride, act,
                                      pack=blk._pack)
+            sc, sh, bnsv = _block_norm(blk, a, training)
             src_dec.append(src)
             a_dec.append(a)
+            xf_dec.append((sc, sh))
+            bn_dec.append(bnsv)
             enc_idx -= 1
-        last_conv = hasattr(dec[-1], 'conv')
-        # a conv block as last layer ends in its PReLU, not in a Tanh
-        y = ops.affine_prelu(a_dec[-1], slope=dec[-1].act.weight) if last_conv else a_dec[-1]
+        lastb = dec[-1]
+        last_conv = hasattr(lastb, 'conv')
+        sc, sh = xf_dec[-1]
+        if last_conv:       # a conv block as last layer ends in its PReLU, not in a Tanh
+            y = ops.affine_prelu(a_dec[-1], sc, sh, lastb.act.weight)
+        elif bn_dec[-1] is not None:
+            y = ops.affine_tanh(a_dec[-1], sc, sh) if lastb.is_tanh else \
+                ops.affine_prelu(a_dec[-1], sc, sh, lastb.act.weight)
+        else:
+            y = a_dec[-1]
+        keep_last = y is not a_dec[-1]
         ctx.gen = gen
         ctx.set_materialize_grads(False)
         ctx.x_needs = x.requires_grad
         # the output goes through save_for_backward (no ctx -> y -> grad_fn -> ctx cycle that a
         # never-backpropagated grad-mode forward would leak); the rest are plain intermediates
         ctx.save_for_backward(y)
-        ctx.last_conv = last_conv
-        ctx.state = (x, z, a_enc, src_enc, a_dec if last_conv else a_dec[:-1], src_dec, W)
+        ctx.keep_last = keep_last
+        ctx.state = (x, z, a_enc, src_enc, xf_enc, bn_enc, a_dec if keep_last else a_dec[:-1],
+                     src_dec, bn_dec, skip_saved, W)
         hid = None
         if want_hid:
             hid = {}
             for i, blk in enumerate(enc):
-                hid['enc_{}'.format(i)] = ops.affine_prelu(a_enc[i], slope=blk.act.weight)
+                hid['enc_{}'.format(i)] = ops.affine_prelu(a_enc[i], xf_enc[i][0], xf_enc[i][1],
+                                                           blk.act.weight)
             if not gen.no_z:
                 hid['enc_zc'] = torch.cat((z, hid['enc_{}'.format(n_enc - 1)]), dim=1)
             for i, blk in enumerate(dec):
-                hid['dec_{}'.format(i)] = (a_dec[i] if getattr(blk, 'is_tanh', False) else
-                                           ops.affine_prelu(a_dec[i], slope=blk.act.weight))
+                if i == len(dec) - 1:
+                    hid['dec_{}'.format(i)] = y
+                else:
+                    hid['dec_{}'.format(i)] = ops.affine_prelu(a_dec[i], xf_dec[i][0],
+                                                               xf_dec[i][1], blk.act.weight)
         ctx.mark_non_differentiable(*([] if hid is None else list(hid.values())))
         if hid is None:
             return y
@@ -245,16 +333,20 @@ class GeneratorFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, *unused):
         gen = ctx.gen
-        x, z, a_enc, src_enc, a_dec, src_dec, W = ctx.state
-        a_dec = list(a_dec) if ctx.last_conv else list(a_dec) + [ctx.saved_tensors[0]]
+        x, z, a_enc, src_enc, xf_enc, bn_enc, a_dec, src_dec, bn_dec, skip_saved, W = ctx.state
+        y = ctx.saved_tensors[0]
+        a_dec = list(a_dec) if ctx.keep_last else list(a_dec) + [y]
         enc, dec = list(gen.enc_blocks), list(gen.dec_blocks)
         n_enc, n_dec = len(enc), len(dec)
         if dy is None:
             ctx.state = None
             return (None,) * len(ctx.needs_input_grad)
+        if 'eval' in bn_enc or 'eval' in bn_dec:
+            raise RuntimeError('Generator backward in eval() mode with BatchNorm is not supported; '
+                               'call .train()')
         dy = dy.contiguous()
         dh = dy
-        dskip = {}          # enc index -> gradient w.r.t. the skip tensor (alpha*a_enc or conv(a_enc))
+        dskip = {}          # enc index -> gradient w.r.t. the skip tensor entering the deconv
         dh_last_enc = None  # gradient w.r.t. h of the last encoder layer
         # ---- decoder, last to first ----
         da = None
@@ -264,11 +356,20 @@ class GeneratorFn(torch.autograd.Function):
             mod = blk.conv if is_conv else blk.deconv
             w = W.get(mod)
             K, S = blk.kwidth, blk.stride
+            bnsv = bn_dec[li]
+            bnm = getattr(blk, 'norm', None)
             if not is_conv and blk.is_tanh:
-                da = ops.tanh_bwd(a_dec[li], dy, dbias=_gb(mod.bias))
-            else:
+                if bnsv is None:
+                    da = ops.tanh_bwd(a_dec[li], dy, dbias=_gb(mod.bias))
+                else:       # y = tanh(bn(c)): through the Tanh, then through the BatchNorm
+                    da = _act_bwd_bn(a_dec[li], ops.tanh_bwd(y, dy), None, bnsv, None,
+                                     _gb(bnm.weight), _gb(bnm.bias), _gb(mod.bias))
+            elif bnsv is None:
                 da = ops.act_bwd(a_dec[li], dh, slope=blk.act.weight,
                                  dslope=_gb(blk.act.weight), dbias=_gb(mod.bias))
+            else:
+                da = _act_bwd_bn(a_dec[li], dh, blk.act.weight, bnsv, _gb(blk.act.weight),
+                                 _gb(bnm.weight), _gb(bnm.bias), _gb(mod.bias))
             src = src_dec[li]
             if W.needs_grad(mod):
                 gw = W.grad_target(mod)
@@ -308,22 +409,41 @@ class GeneratorFn(torch.autograd.Function):
             blk = enc[l]
             w = W.get(blk.conv)
             K, S = blk.kwidth, blk.stride
+            bnsv = bn_enc[l]
+            bnm = getattr(blk, 'norm', None)
+            sc, sh = xf_enc[l]
             gskip = gen.skips[l]['alpha'] if (gen.skip and l in gen.skips) else None
             dsk = dskip.get(l)
+            mask, a_norm = skip_saved.get(l, (None, None))
+            if dsk is not None and mask is not None:
+                dsk = ops.scale_mask(dsk, None, mask)              # back through the dropout
             alpha_p = None
             if gskip is not None and gskip.skip_type == 'conv':
-                if dsk is not None:
-                    dsk = _skip_conv_bwd(gskip, dsk, a_enc[l])     # -> gradient w.r.t. a_enc[l]
+                if dsk is not None:     # -> gradient w.r.t. the (normalised) linear output
+                    dsk = _skip_conv_bwd(gskip, dsk, Src(a_enc[l], scale=sc, shift=sh))
                 alpha_v = _ones(a_enc[l].shape[1], a_enc[l]) if dsk is not None else None
                 ready_extra = gskip.skip_k
             else:
                 alpha_p = gskip.skip_k if gskip is not None else None
                 alpha_v = alpha_p if dsk is not None else None
                 ready_extra = alpha_p
-            da = ops.act_bwd(a_enc[l], dh, dskip=dsk, slope=blk.act.weight, alpha=alpha_v,
-                             dslope=_gb(blk.act.weight),
-                             dalpha=_gb(alpha_p, dsk is not None),
-                             dbias=_gb(blk.conv.bias))
+            if bnsv is None:
+                da = ops.act_bwd(a_enc[l], dh, dskip=dsk, slope=blk.act.weight, alpha=alpha_v,
+                                 dslope=_gb(blk.act.weight),
+                                 dalpha=_gb(alpha_p, dsk is not None),
+                                 dbias=_gb(blk.conv.bias))
+            elif dsk is None:
+                da = _act_bwd_bn(a_enc[l], dh, blk.act.weight, bnsv, _gb(blk.act.weight),
+                                 _gb(bnm.weight), _gb(bnm.bias), _gb(blk.conv.bias))
+            else:
+                # the skip taps the NORMALISED linear output: PReLU + skip gradients meet on
+                # bn(c) first, then go through the BatchNorm together
+                if a_norm is None:
+                    a_norm = ops.affine_prelu(a_enc[l], sc, sh, None)
+                g = ops.act_bwd(a_norm, dh, dskip=dsk, slope=blk.act.weight, alpha=alpha_v,
+                                dslope=_gb(blk.act.weight), dalpha=_gb(alpha_p, True))
+                da = _act_bwd_bn(a_enc[l], g, None, bnsv, None, _gb(bnm.weight), _gb(bnm.bias),
+                                 _gb(blk.conv.bias))
             padL = ops.conv_pad(K, S)[0]
             if W.needs_grad(blk.conv):
                 gw = W.grad_target(blk.conv)

@@ -77,10 +77,6 @@ class GDeconv1DBlock(nn.Module):
         _check_geometry(kwidth, stride)
         if stride < 2:
             raise ValueError('GDeconv1DBlock needs stride > 1')
-        if norm_type not in (None, 'snorm'):
-            raise NotImplementedError("only norm_type None / 'snorm' are implemented inside "
-                                      "GDeconv1DBlock (BatchNorm in G is never built by the "
-                                      "reference's recipes)")
         pad = max(0, (stride - kwidth) // -2)
         # NOTE the reference ignores `bias` here: the deconv always has a bias
         # (modules.py:116-119)
@@ -101,5 +97,9 @@ class GDeconv1DBlock(nn.Module):
         if x.dim() != 3 or x.shape[1] != self.deconv.in_channels:
             raise ValueError('expected input [B, {}, L], got {}'.format(
                 self.deconv.in_channels, tuple(x.shape)))
+        if isinstance(self.norm, nn.BatchNorm1d):
+            raise NotImplementedError('a GDeconv1DBlock with BatchNorm runs inside the Generator '
+                                      '(functional.GeneratorFn); the stand-alone call is not '
+                                      'implemented')
         params = [p for p in self.parameters()]
         return Fn.DeconvBlockFn.apply(self, x, *params)

@@ -539,6 +539,30 @@ def affine_prelu(x, scale=None, shift=None, slope=None):
     return y
 
 
+def affine_tanh(x, scale=None, shift=None):
+    """tanh(x*scale + shift) with per-channel scale / shift on [B, C, L]."""
+    _chk(x, 'x', 3)
+    B, C, L = x.shape
+    y = torch.empty_like(x)
+    check(_lib.load().segan_affine_tanh(_ptr(x), _ptr(scale), _ptr(shift), _ptr(y), B, C, L,
+                                        _stream()), 'affine_tanh')
+    return y
+
+
+def scale_mask(x, scale, mask):
+    """x * scale[c] * mask on [B, C, L] (scale may be None): dropout on the skip path with the
+    alpha scale folded in, and (scale None) its backward."""
+    _chk(x, 'x', 3)
+    _chk(mask, 'mask', 3)
+    if mask.shape != x.shape:
+        raise ValueError('scale_mask: mask {} vs x {}'.format(tuple(mask.shape), tuple(x.shape)))
+    B, C, L = x.shape
+    y = torch.empty_like(x)
+    check(_lib.load().segan_scale_mask(_ptr(x), _ptr(scale), _ptr(mask), _ptr(y), B, C, L,
+                                       _stream()), 'scale_mask')
+    return y
+
+
 def sum_skip(x0, slope0, x1, alpha):
     """prelu(x0, slope0) + alpha * x1 (GSkip merge_mode 'sum')."""
     _chk(x0, 'x0', 3)

@@ -60,6 +60,39 @@ def oracle_kwargs(opts):
                 skip_merge=opts['skip_merge'], pool_type=opts['dpool_type'])
 
 
+GVARIANT_NAMES = ('bnorm_concat', 'bnorm_sum', 'dropout_alpha', 'dropout_conv_sum', 'bnorm_dropout')
+
+
+def check_gvariant(g, device, act_tol, grad_tol):
+    """A Generator option no train.py flag reaches (BatchNorm in G, skip dropout) against the
+    REAL reference's forward / backward (tests/golden/tiny_gvariants.pt) on `device`."""
+    from segan_pytorch_amd.models import Generator
+    G = Generator(1, [4, 8, 16], 31, [4, 4, 4], **g['kwargs'])
+    assert sorted(G.state_dict().keys()) == sorted(g['G0'].keys())
+    G.load_state_dict(g['G0'])
+    G = G.to(device)
+    G.train()
+    torch.manual_seed(g['fwd_seed'])          # the dropout masks of the reference's forward
+    y = G(g['x'].to(device), z=g['z'].to(device))
+    assert max_rel(y, g['y']) < act_tol
+    (y * g['c'].to(device)).sum().backward()
+    named = dict(G.named_parameters())
+    for k, gr in g['grads'].items():
+        if g['kwargs'].get('norm_type') == 'bnorm' and k.endswith(('conv.bias', 'deconv.bias')):
+            continue    # a bias in front of a BatchNorm: mathematically zero gradient, roundoff
+        assert max_rel(named[k].grad, gr) < grad_tol, k
+    for k, v in g['G_after_fwd'].items():     # BatchNorm running statistics after the forward
+        if torch.is_floating_point(v):
+            assert max_rel(G.state_dict()[k], v) < act_tol, k
+        else:
+            assert torch.equal(G.state_dict()[k].cpu(), v), k
+    G.eval()
+    with torch.no_grad():
+        ye = G(g['x'].to(device), z=g['z'].to(device))
+    assert max_rel(ye, g['y_eval']) < act_tol
+
+
+
 def draw_rolls(n_layers, phase_shift):
     """The python-`random` draws of one Discriminator.forward (discriminator.py:159-163)."""
     import random

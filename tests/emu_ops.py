@@ -179,6 +179,17 @@ def affine_prelu(x, scale=None, shift=None, slope=None):
     return _mat(ops.Src(x, scale=scale, shift=shift, slope=slope)).float()
 
 
+def affine_tanh(x, scale=None, shift=None):
+    return torch.tanh(_mat(ops.Src(x, scale=scale, shift=shift))).float()
+
+
+def scale_mask(x, scale, mask):
+    v = x.double() * mask.double()
+    if scale is not None:
+        v = v * scale.detach().double().view(1, -1, 1)
+    return v.float()
+
+
 def sum_skip(x0, slope0, x1, alpha):
     v = x0.double()
     if slope0 is not None:
@@ -241,7 +252,8 @@ def act_bwd(a, dh, dskip=None, slope=None, alpha=None, bn=None, dslope=None, dal
     be = beta.detach().double().view(1, -1, 1)
     xh = (ad - mu) * rs
     v = ga * xh + be
-    g = dhd * torch.where(v > 0, torch.ones_like(v), sl.expand_as(v))
+    # slope None = no activation behind the BatchNorm (the kernel's slope defaults to 1)
+    g = dhd * torch.where(v > 0, torch.ones_like(v), sl.expand_as(v)) if sl is not None else dhd
     _acc(dslope, (dhd * torch.where(v > 0, torch.zeros_like(v), v)).sum((0, 2)))
     db, dg = g.sum((0, 2)), (g * xh).sum((0, 2))
     _acc(dbeta, db)
@@ -427,7 +439,7 @@ def _chk(t, name, ndim=None):
 
 
 _NAMES = ['conv1d_fwd', 'conv1d_dgrad', 'wgrad', 'deconv1d_fwd', 'deconv1d_dgrad', 'bn_stats',
-          'affine_prelu', 'sum_skip', 'pool_time_fwd', 'pool_time_bwd', 'bce_logits_const', 'bce_logits_const_bwd', 'act_bwd', 'tanh_bwd', 'linear_fwd', 'linear_dgrad', 'linear_wgrad',
+          'affine_prelu', 'affine_tanh', 'scale_mask', 'sum_skip', 'pool_time_fwd', 'pool_time_bwd', 'bce_logits_const', 'bce_logits_const_bwd', 'act_bwd', 'tanh_bwd', 'linear_fwd', 'linear_dgrad', 'linear_wgrad',
           'bias_prelu_rows', 'bias_prelu_rows_bwd', 'mse_const', 'mse_const_bwd', 'l1_mean',
           'l1_bwd', 'stft_basis', 'stft_frames', 'stft_spectrum', 'stft_spectrum_bwd', 'powdb',
           'powdb_bwd', 'stft_overlap_add', 'snorm_fwd', 'snorm_bwd', 'bn_partial', 'bn_final', 'act_bwd_bn_reduce',

@@ -13,7 +13,8 @@ import pytest
 import torch
 
 import segan_oracle as O
-from conftest import VARIANT_NAMES, max_rel, oracle_kwargs
+from conftest import (GVARIANT_NAMES, VARIANT_NAMES, check_gvariant, load_golden, max_rel,
+                      oracle_kwargs)
 
 # RMSprop's first step moves every weight by lr*g/(0.1|g|+1e-8) = +-10*lr = 5e-4 wherever
 # |g| >> 1e-7 and is ill-conditioned where the gradient is at roundoff level (|g| ~ 1e-8):
@@ -154,6 +155,14 @@ def test_architecture_variants_match_reference(tiny_variants, name):
     (the conv head also with spectral norm)."""
     fx = tiny_variants[name]
     (check_snorm_step if fx['opts']['dnorm_type'] == 'snorm' else check_step_against_golden)(fx)
+
+
+@pytest.mark.parametrize('name', GVARIANT_NAMES)
+def test_generator_batchnorm_and_skip_dropout_match_reference(name):
+    """Generator(norm_type='bnorm') and skip_dropout on the GPU against the REAL reference's
+    output, gradients, running statistics and eval-mode output (oracle/make_golden.py gvariants);
+    the dropout masks are drawn on the host from the same torch seed."""
+    check_gvariant(load_golden('tiny_gvariants.pt')[name], DEV, ACT_TOL, GRAD_TOL)
 
 
 def test_tiny_forward_hidden_and_int_act(tiny_step):

@@ -10,7 +10,7 @@ import pytest
 import torch
 
 import emu_ops
-from conftest import VARIANT_NAMES, max_rel
+from conftest import GVARIANT_NAMES, VARIANT_NAMES, check_gvariant, max_rel
 
 # RMSprop's first step moves every weight by lr*g/(0.1|g|+1e-8) = +-10*lr = 5e-4 wherever
 # |g| >> 1e-7 and is ill-conditioned where the gradient is at roundoff level (|g| ~ 1e-8):
@@ -304,6 +304,14 @@ def test_generator_with_spectral_norm(tiny_snorm):
         assert max_rel(named[k].grad, gr) < 1e-4, k
     for k, v in g['G_after_fwd'].items():
         assert max_rel(G.state_dict()[k], v) < 2e-5, k
+
+
+@pytest.mark.parametrize('name', GVARIANT_NAMES)
+def test_generator_batchnorm_and_skip_dropout(name):
+    """Generator(norm_type='bnorm') and skip_dropout, host side: against the REAL reference's
+    output, gradients, running statistics and eval-mode output (tests/golden/tiny_gvariants.pt)."""
+    from conftest import load_golden
+    check_gvariant(load_golden('tiny_gvariants.pt')[name], 'cpu', 2e-5, 1e-4)
 
 
 def test_distributed_sampler_epochs_advance(tiny_wsegan2):
