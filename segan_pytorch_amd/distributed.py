@@ -125,12 +125,16 @@ class GradReducer(object):
         self.armed = False
         self.pending, self.sent, self.works = [], [], []
 
-    def arm(self):
-        """Call before the LAST backward pass that adds to these gradients."""
+    def arm(self, passes=1):
+        """Call before the LAST backward() that adds to these gradients.  `passes`: how many
+        times that backward runs the network's node — WSEGAN's summed discriminator loss holds
+        2 to 4 D forwards (model.py:577-631), so every D parameter is written (and reported)
+        that many times and a bucket may only leave after the LAST report of its members."""
         self.opt._resync()
-        self.pending = list(self.members)
+        self.passes = int(passes)
+        self.pending = [n * self.passes for n in self.members]
         self.sent = [False] * len(self.buckets)
-        self.seen = set()
+        self.seen = {}
         self.works = []
         self.armed = True
 
@@ -142,9 +146,9 @@ class GradReducer(object):
 
     def ready(self, p):
         b = self.bucket_of.get(id(p))
-        if b is None or not self.armed or self.sent[b] or id(p) in self.seen:
+        if b is None or not self.armed or self.sent[b] or self.seen.get(id(p), 0) >= self.passes:
             return
-        self.seen.add(id(p))
+        self.seen[id(p)] = self.seen.get(id(p), 0) + 1
         self.pending[b] -= 1
         if self.pending[b] == 0:
             self._send(b)
@@ -179,14 +183,16 @@ def _reducer(optimizer):
     return r
 
 
-def arm(optimizer):
-    """Announce that the next backward pass is the last one into `optimizer`'s gradients before
-    its step: from here on ``grad_ready`` starts the all-reduce of every bucket that completes."""
+def arm(optimizer, passes=1):
+    """Announce that the next backward() is the last one into `optimizer`'s gradients before
+    its step: from here on ``grad_ready`` starts the all-reduce of every bucket that completes.
+    `passes` = number of forwards of the network that backward() differentiates (each one
+    reports every parameter once; a bucket leaves after the last report)."""
     global _active
     if not _collectives_on():
         return
     _active = _reducer(optimizer)
-    _active.arm()
+    _active.arm(passes)
 
 
 def grad_ready(*params):
@@ -220,6 +226,20 @@ def broadcast_params(module, src=0):
         for t in list(module.parameters()) + list(module.buffers()):
             dist.broadcast(t.data, src)
     ops.bump_weights_epoch()
+
+
+def broadcast_scalar(value, src=0, device=None):
+    """Rank `src`'s python float on every rank (the validation objective: every rank must take
+    the same early-stopping / best-checkpoint branch, or the ranks that go on hang in the next
+    gradient all-reduce).  Identity without data parallelism."""
+    if not is_dist():
+        return float(value)
+    if device is None or dist.get_backend() != 'nccl':
+        device = torch.device('cpu') if dist.get_backend() != 'nccl' else \
+            torch.device('cuda', torch.cuda.current_device())
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.broadcast(t, src)
+    return float(t.item())
 
 
 def shard_batch(t, dim=0):

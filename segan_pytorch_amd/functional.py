@@ -135,20 +135,32 @@ class _Weights(object):
         ops.snorm_bwd(tmp, mod.weight_orig.detach(), u, v, sigma, dim, grad_buf(mod.weight_orig))
 
 
-def _skip_conv_bwd(gskip, dsk, src_j):
+def _skip_conv_bwd(gskip, dsk, src_j, W):
     """Backward of GSkip 'conv' (generator.py:42-49,65-66), sk = conv1d(h_j, Wk, bk, stride 1,
     zero padding kw//2) with h_j given as a Src (the encoder's linear output, normalised on load
     when the block has a BatchNorm): accumulates dWk / dbk, returns the gradient w.r.t. h_j.
     The data gradient of a stride-1 zero-padded conv is the same kernel run with the weight
-    transposed and flipped (padding kw - 1 - kw//2)."""
+    transposed and flipped (padding kw - 1 - kw//2).  `W` holds the effective weights of the
+    forward call (the spectrally normalised one when the conv carries a spectral norm); the
+    flipped copy and its packed form are cached on the module until the weight changes."""
     mod = gskip.skip_k
     kw = mod.kernel_size[0]
+    w = W.get(mod)
     if mod.bias is not None and mod.bias.requires_grad:
         ops.act_bwd(dsk, dsk, dbias=grad_buf(mod.bias))          # dbk += sum over (b, t)
-    if mod.weight.requires_grad:
-        ops.wgrad(Src(dsk), src_j, grad_buf(mod.weight), kw, 1, kw // 2, PAD_ZERO)
-    wt = mod.weight.detach().transpose(0, 1).flip(2).contiguous()
-    return ops.conv1d_fwd(Src(dsk), wt, None, 1, pad_mode=PAD_ZERO, padL=kw - 1 - kw // 2)
+    if W.needs_grad(mod):
+        gw = W.grad_target(mod)
+        ops.wgrad(Src(dsk), src_j, gw, kw, 1, kw // 2, PAD_ZERO)
+        W.finish(mod, gw)
+    key = (w.data_ptr(), w._version, ops._weights_epoch, getattr(w, '_segan_epoch', 0))
+    cached = gskip.__dict__.get('_wt_cache')
+    if cached is None or cached[0] != key:
+        wt = w.detach().transpose(0, 1).flip(2).contiguous()
+        wt._segan_epoch = next(_sn_epoch)    # a new tensor at a recycled address is a new weight
+        cached = (key, wt)
+        gskip.__dict__['_wt_cache'] = cached
+    return ops.conv1d_fwd(Src(dsk), cached[1], None, 1, pad_mode=PAD_ZERO, padL=kw - 1 - kw // 2,
+                          pack=gskip._pack_t)
 
 
 def _block_norm(blk, c, training):
@@ -420,7 +432,7 @@ class GeneratorFn(torch.autograd.Function):
             alpha_p = None
             if gskip is not None and gskip.skip_type == 'conv':
                 if dsk is not None:     # -> gradient w.r.t. the (normalised) linear output
-                    dsk = _skip_conv_bwd(gskip, dsk, Src(a_enc[l], scale=sc, shift=sh))
+                    dsk = _skip_conv_bwd(gskip, dsk, Src(a_enc[l], scale=sc, shift=sh), W)
                 alpha_v = _ones(a_enc[l].shape[1], a_enc[l]) if dsk is not None else None
                 ready_extra = gskip.skip_k
             else:

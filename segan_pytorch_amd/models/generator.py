@@ -193,8 +193,14 @@ class Generator(Model):
                     z = torch.randn(*zshape)
             if z.dim() != x.dim():
                 raise ValueError('len(z.size) {} != len(hi.size) {}'.format(z.dim(), x.dim()))
+            if getattr(z, '_segan_staged', False) and (torch.is_grad_enabled() or
+                                                       not hasattr(self, 'z')):
+                # a staging buffer is re-used two calls later, but the autograd node keeps z for
+                # the first decoder layer's weight gradient (several graphs may be alive at once:
+                # gradient accumulation, held fake batches): hand it its own copy (20 MB, ~10 us)
+                z = z.clone()
             if not hasattr(self, 'z'):
-                self.z = z.clone() if getattr(z, '_segan_staged', False) else z
+                self.z = z
         else:
             z = None
         out = Fn.GeneratorFn.apply(self, bool(ret_hid), x, z, *self._fn_params())

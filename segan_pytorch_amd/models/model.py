@@ -352,7 +352,9 @@ class SEGAN(Model):
                 # which need the external `pesqmain` binary; here the objective is the
                 # segmental SNR, computed on the GPU
                 evals = self.evaluate(opts, va_dloader, log_freq, device=device)
-                val_obj = float(np.mean(evals['ssnr']))
+                # every rank evaluates with its own z; rank 0's figure decides for all of them
+                # (ranks disagreeing on `break` would deadlock the next all-reduce)
+                val_obj = sdist.broadcast_scalar(float(np.mean(evals['ssnr'])), 0, device)
                 self.writer.add_scalar('Genh-ssnr', val_obj, epoch)
                 if best_val_obj is None or val_obj > best_val_obj:
                     if is_main:
@@ -452,6 +454,7 @@ class WSEGAN(SEGAN):
         d_fake_loss = cost(d_fake.view(-1), 0.0)
         d_weight = 0.5
         d_loss = d_fake_loss + d_real_loss
+        n_d_fwd = 2             # D forwards the one backward below differentiates
         if self.misalign_pair:
             perm = list(range(bsz))
             shuffle(perm)      # same RNG draws as shuffling the chunk list (model.py:598-600)
@@ -459,6 +462,7 @@ class WSEGAN(SEGAN):
             d_fake_shuf, _ = self.infer_D(clean, clean_shuf)
             d_loss = d_loss + cost(d_fake_shuf.view(-1), 0.0)
             d_weight = 1 / 3
+            n_d_fwd += 1
         if self.interf_pair:
             from scipy import signal
             freqs, amps = [250, 1000, 4000], [0.01, 0.05, 0.1, 1]
@@ -473,8 +477,10 @@ class WSEGAN(SEGAN):
             d_fake_inter, _ = self.infer_D(clean + squares, noisy)
             d_loss = d_loss + cost(d_fake_inter.view(-1), 0.0)
             d_weight = 1 / 4
+            n_d_fwd += 1
         d_loss = d_weight * d_loss
-        sdist.arm(Dopt)
+        # every D forward reports every D parameter once: a bucket leaves after the last one
+        sdist.arm(Dopt, passes=n_d_fwd)
         d_loss.backward()
         sdist.allreduce_grads(Dopt)
         Dopt.step()

@@ -209,3 +209,95 @@ def test_two_rank_sync_batchnorm_equals_the_full_batch_step():
             err = (torch.from_numpy(res[r][k]).double() - v.double()).abs().max().item()
             tol = 5e-5 if k.startswith('Dw.') else 5e-5 * scale
             assert err < tol, (k, r, err, scale)
+
+
+# ---- WSEGAN under data parallelism: several D forwards, ONE backward -----------------------
+def _wsegan_step(rank_seed, clean, noisy, names):
+    """One WSEGAN step (misalign + interference pairs: four D forwards under one backward) on CPU
+    through the emulated kernel entry points; returns D / G gradients and the stepped D weights."""
+    import random
+    import sys
+    from types import SimpleNamespace
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import emu_ops
+    emu_ops.install()
+    from segan_pytorch_amd.models import WSEGAN
+    here = os.path.dirname(os.path.abspath(__file__))
+    fx = torch.load(os.path.join(here, 'golden', 'tiny_wsegan2.pt'), map_location='cpu',
+                    weights_only=False)
+    o = dict(fx['opts'])
+    o['interf_pair'] = True
+    random.seed(1)
+    torch.manual_seed(1)
+    m = WSEGAN(SimpleNamespace(**o))
+    m.G.load_state_dict(fx['G0'])
+    m.D.load_state_dict(fx['D0'])
+    Gopt, Dopt = m.build_optimizers(SimpleNamespace(**o))
+    m.G.train()
+    m.D.train()
+    random.seed(rank_seed)      # phase shifts, the misalign permutation, the interference draws
+    torch.manual_seed(rank_seed)
+    g = torch.Generator().manual_seed(rank_seed)
+    z = torch.randn(clean.size(0), 32, 16, generator=g)
+    m.wgan_step(names, clean, noisy, Gopt, Dopt, 100.0, z=z)
+    out = {'Dg.' + k: p.grad.detach().clone() for k, p in m.D.named_parameters()}
+    out.update({'Gg.' + k: p.grad.detach().clone() for k, p in m.G.named_parameters()})
+    emu_ops.uninstall()
+    return out
+
+
+def _wsegan_inputs():
+    g = torch.Generator().manual_seed(5)
+    clean = torch.rand(4, 1, 1024, generator=g) * 2 - 1
+    noisy = (clean + 0.1 * torch.randn(4, 1, 1024, generator=g)).clamp(-1, 1)
+    names = ['a_additive', 'b', 'c_additive', 'd']
+    return clean, noisy, names
+
+
+def _wsegan_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from segan_pytorch_amd import distributed as sdist
+    sdist.init_from_env(backend='gloo')
+    sdist.set_bucket_bytes(4 * 1024)         # many buckets: they must wait for the LAST D pass
+    clean, noisy, names = _wsegan_inputs()
+    sl = slice(2 * rank, 2 * rank + 2)
+    out = _wsegan_step(40 + rank, clean[sl].contiguous(), noisy[sl].contiguous(), names[sl])
+    q.put((rank, {k: v.numpy() for k, v in out.items()}))
+    dist.destroy_process_group()
+
+
+def test_two_rank_wsegan_step_averages_all_discriminator_passes():
+    """WSEGAN's summed discriminator loss (model.py:577-631; here real + fake + misaligned +
+    interference = four D forwards) is differentiated by ONE backward(), which runs D's node four
+    times.  Every bucket of the overlapped reducer must leave only after the LAST pass wrote its
+    gradients: both ranks must hold the mean of the two ranks' single-process gradients (each
+    rank's own shard, RNG draws and local BatchNorm statistics), for D and for G."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_wsegan_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    clean, noisy, names = _wsegan_inputs()
+    solo = [_wsegan_step(40 + r, clean[2 * r:2 * r + 2].contiguous(),
+                         noisy[2 * r:2 * r + 2].contiguous(), names[2 * r:2 * r + 2])
+            for r in range(2)]
+    for k in solo[0]:
+        if k.startswith('Gg.'):
+            continue        # G's gradients go through the stepped D: checked below, loosely
+        want = 0.5 * (solo[0][k] + solo[1][k])
+        scale = max(want.abs().max().item(), 1e-30)
+        for r in (0, 1):
+            err = (torch.from_numpy(res[r][k]) - want).abs().max().item()
+            assert err < 2e-5 * scale, (k, r, err, scale)
+    # the two ranks hold the same (averaged) generator gradients
+    for k in solo[0]:
+        if k.startswith('Gg.'):
+            a, b = torch.from_numpy(res[0][k]), torch.from_numpy(res[1][k])
+            assert torch.equal(a, b), k
