@@ -42,6 +42,7 @@ if ROOT not in sys.path:
 GFLOP_PER_CHUNK = 37.96      # 2*(3*3144.94 + 9*1060.67) MMAC
 MB_PER_CHUNK = 80.0          # SURVEY.md 8(d) algorithmic HBM bytes (fp32)
 PEAK_F32_MFMA_TF = 157.3     # MI355X_MICROARCH.md
+PEAK_BF16_MFMA_TF = 2500.0   # dense bf16 MFMA peak, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 
 
@@ -62,9 +63,12 @@ VANILLA11 = dict(genc_fmaps=[16, 32, 32, 64, 64, 128, 128, 256, 256, 512, 1024],
                  genc_poolings=[2] * 11, denc_poolings=[2] * 11, dpool_slen=8)
 
 
-def gflop_per_chunk(o, T=16384, wsegan=False):
+def gflop_per_chunk(o, T=16384, wsegan=False, executed=False):
     """Algorithmic FLOPs of one GAN step per chunk, SURVEY.md 8(d) accounting: 2 * (3 * G forward
-    MACs + 9 * D forward MACs) (12 * D with the WSEGAN misalign pair), from the layer shapes."""
+    MACs + 9 * D forward MACs) (12 * D with the WSEGAN misalign pair), from the layer shapes.
+    `executed`: what this engine runs — the D weight gradients of the generator phase (which the
+    reference computes and discards at its next Dopt.zero_grad()) are not computed: one D
+    forward-equivalent less."""
     K = o['gkwidth']
     g, cin, L = 0, 1, T
     for c, s in zip(o['genc_fmaps'], o['genc_poolings']):
@@ -85,7 +89,7 @@ def gflop_per_chunk(o, T=16384, wsegan=False):
         d += c * cin * K * L
         cin = c
     d += cin * L * 256 + 256 * 128 + 128
-    return 2.0 * (3 * g + (12 if wsegan else 9) * d) / 1e9
+    return 2.0 * (3 * g + ((12 if wsegan else 9) - (1 if executed else 0)) * d) / 1e9
 
 
 class KernelTimer(object):
@@ -158,7 +162,75 @@ class KernelTimer(object):
         return out
 
 
-def cpu_baseline(B=300, steps=2, dev=None):
+def _rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-300)).item()
+
+
+def _lrel(a, b):
+    return abs(float(a) - float(b)) / max(abs(float(b)), 1e-30)
+
+
+def hip_step_parity(ref, opts, gsd0, dsd0, clean, noisy, z, rolls, dev, precision, deterministic):
+    """One HIP GAN step from (gsd0, dsd0) on (clean, noisy, z, rolls) in the given contraction
+    precision / reduction mode against the oracle step `ref` from the same state: generator
+    output, the four losses, gradients per tensor (relative L2, worst tensor).  The generator
+    phase runs through the ORACLE's post-step discriminator (RMSprop's first step is
+    ill-conditioned where |g| is at roundoff level: DESIGN.md section 6)."""
+    from segan_pytorch_amd import losses, ops
+    from segan_pytorch_amd.models import SEGAN
+    old_d, old_p = ops.get_deterministic(), ops.get_precision()
+    ops.set_deterministic(deterministic)
+    ops.set_precision(precision)
+    try:
+        mm = SEGAN(SimpleNamespace(**opts))
+        mm.G.load_state_dict(gsd0)
+        mm.D.load_state_dict(dsd0)
+        mm = mm.to(dev)
+        Gopt, Dopt = mm.build_optimizers(SimpleNamespace(**opts))
+        mm.G.train(); mm.D.train()
+        it = iter(rolls)
+        mm.D.draw_rolls = lambda: list(next(it))
+        crit = losses.MSELoss()
+        cg, ng, zg = clean.to(dev), noisy.to(dev), z.to(dev)
+        Genh, d_real, d_fake = mm.d_phase(cg, ng, Dopt, crit, z=zg)
+        y = Genh.detach().cpu().double()
+        yr = ref['Genh'].double()
+        dn = dict(mm.D.named_parameters())
+        d_grad = max(_rel(dn[k].grad, g) for k, g in ref['d_grads'].items()
+                     if not k.endswith('conv.bias'))
+        mm.D.load_state_dict({k: ref['D'].get(k, v) for k, v in dsd0.items()})
+        ops.bump_weights_epoch()
+        g_adv, g_l1 = mm.g_phase(Genh, cg, ng, Gopt, crit, 100.0)
+        torch.cuda.synchronize()
+        gn = dict(mm.G.named_parameters())
+        g_grad = max(_rel(gn[k].grad, g) for k, g in ref['g_grads'].items())
+        out = {
+            'batch': int(clean.size(0)), 'precision': precision,
+            'reduction_mode': 'deterministic (fixed-order)' if deterministic else
+                              'default (fp32 atomics in the weight-gradient / dense-head splits: the timed mode)',
+            'g_mse': ((y - yr) ** 2).mean().item(), 'g_max_abs': (y - yr).abs().max().item(),
+            'd_real_loss_rel': _lrel(d_real, ref['d_real_loss']),
+            'd_fake_loss_rel': _lrel(d_fake, ref['d_fake_loss']),
+            'g_adv_loss_rel': _lrel(g_adv, ref['g_adv_loss']),
+            'g_l1_loss_rel': _lrel(g_l1, ref['g_l1_loss']),
+            'd_grad_rel_l2_worst_tensor': d_grad, 'g_grad_rel_l2_worst_tensor': g_grad}
+        del mm, Gopt, Dopt
+        return out
+    finally:
+        ops.set_deterministic(old_d)
+        ops.set_precision(old_p)
+
+
+PARITY_NOTE = ('HIP step vs the CPU oracle step timed above, same weights / inputs / z / phase shifts; '
+               'generator phase through the oracle\'s post-step D; gradient figures are relative L2 per '
+               'tensor (ReLU-gate flips at fp32 roundoff bound them, tests/test_gpu_kernels.py::'
+               'test_discriminator_batchnorm_at_batch_300); `parity` = fp32 in the deterministic mode, '
+               '`parity_default_mode` = fp32 in the timed (atomics) mode, other_precisions.*.parity = the '
+               'bf16x3 / bf16 contractions in the timed mode')
+
+
+def cpu_baseline(B=300, steps=2, dev=None, modes=('bf16x3', 'bf16')):
     """Time the CPU oracle's GAN step (oracle/segan_oracle.py: the reference's path restated on
     torch CPU ops; /root/reference does not exist on the GPU box, hence kind = 'port') on this
     host's cores at the metric's batch size: per oneDNN setting one warm-up step at batch 8
@@ -166,12 +238,11 @@ def cpu_baseline(B=300, steps=2, dev=None):
     (oneDNN off is the numerically trustworthy one).
 
     The first timed oneDNN-off step doubles as the parity reference: the HIP model takes the
-    same step from the same weights / inputs / z / phase shifts (deterministic kernels; the
-    generator phase runs through the oracle's post-step discriminator, see
-    tests/test_gpu_model.py) and the differences are returned as `parity`."""
+    same step from the same weights / inputs / z / phase shifts — in fp32 in the deterministic
+    and in the default (timed) reduction mode, and with the bf16x3 / bf16 contractions — and the
+    differences are returned as a dict of parity blocks (hip_step_parity)."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import segan_oracle as O
-    from segan_pytorch_amd import losses, ops
     from segan_pytorch_amd.datasets import synthetic_pairs
     from segan_pytorch_amd.models import SEGAN
     opts = default_opts()
@@ -207,12 +278,57 @@ def cpu_baseline(B=300, steps=2, dev=None):
                       '{} timed steps per oneDNN setting; s/step oneDNN off {}, on {}; reported = {} '
                       '(mean)'.format(B, steps, ['%.2f' % t for t in results['onednn_off']],
                                       ['%.2f' % t for t in results['onednn_on']], best))
-    parity = None
+    parity = {}
     if dev is not None and ref is not None:
+        for name, prec, det in (('fp32_deterministic', 'fp32', True), ('fp32_default', 'fp32', False)) + \
+                tuple((p, p, False) for p in modes):
+            try:
+                parity[name] = hip_step_parity(ref, opts, gsd0, dsd0, clean, noisy, z, rolls, dev,
+                                               prec, det)
+            except Exception as e:      # a parity leg must never cost the bench line
+                parity[name] = {'error': repr(e)}
+    return out, parity
+
+
+def wsegan_parity(opts, B, dev):
+    """BASELINE config 4 at its benchmarked batch: ONE step of the oracle's WSEGAN step
+    (oracle.wsegan_step: --misalign_pair, LSGAN cost, STFT power loss; oneDNN off) timed on the
+    host cores, and the HIP WSEGAN step from the same weights / inputs / z / phase shifts /
+    misalign permutation compared with it (fp32, both reduction modes; the generator phase through
+    the oracle's post-step D).  Returns (cpu_baseline, {mode: parity block})."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import segan_oracle as O
+    from segan_pytorch_amd import ops
+    from segan_pytorch_amd.datasets import synthetic_pairs
+    from segan_pytorch_amd.models import WSEGAN
+    random.seed(111); np.random.seed(111); torch.manual_seed(111)
+    m = WSEGAN(SimpleNamespace(**opts))
+    gsd0 = {k: v.detach().clone() for k, v in m.G.state_dict().items()}
+    dsd0 = {k: v.detach().clone() for k, v in m.D.state_dict().items()}
+    clean, noisy = synthetic_pairs(B, 16384, 0)
+    clean, noisy = clean.unsqueeze(1), noisy.unsqueeze(1)
+    z = torch.randn(B, 1024, 16, generator=torch.Generator().manual_seed(0))
+    rolls = [[1, -2, 3, -4, 5], [-3, 2, -1, 5, 4], [4, 1, -2, 2, -5], [2, -5, 1, -1, -4]]
+    names = ['utt_additive_{}'.format(i) if i % 2 == 0 else 'utt_{}'.format(i) for i in range(B)]
+    random.seed(77)
+    perm = list(range(B))
+    random.shuffle(perm)
+    st = opts['genc_poolings']
+    torch.backends.mkldnn.enabled = False
+    O.wsegan_step(gsd0, dsd0, clean[:4], noisy[:4], z[:4], rolls, [1, 0, 3, 2], names[:4], st)  # warm-up
+    t0 = time.perf_counter()
+    ref = O.wsegan_step(gsd0, dsd0, clean, noisy, z, rolls, perm, names, st, l1_weight=100.0,
+                        pow_weight=opts['pow_weight'], lr=5e-5, n_fft=opts['n_fft'])
+    dt = time.perf_counter() - t0
+    base = dict(value=B / dt, unit='chunks/s', cores=torch.get_num_threads(), nproc=os.cpu_count(),
+                kind='port', sample='oracle WSEGAN step (--misalign_pair) at batch {}: warm-up at batch '
+                                    '4, ONE timed step, oneDNN off: {:.2f} s'.format(B, dt))
+    out = {}
+    for name, det in (('fp32_deterministic', True), ('fp32_default', False)):
         old = ops.get_deterministic()
-        ops.set_deterministic(True)
+        ops.set_deterministic(det)
         try:
-            mm = SEGAN(SimpleNamespace(**opts))
+            mm = WSEGAN(SimpleNamespace(**opts))
             mm.G.load_state_dict(gsd0)
             mm.D.load_state_dict(dsd0)
             mm = mm.to(dev)
@@ -220,49 +336,58 @@ def cpu_baseline(B=300, steps=2, dev=None):
             mm.G.train(); mm.D.train()
             it = iter(rolls)
             mm.D.draw_rolls = lambda: list(next(it))
-            crit = losses.MSELoss()
             cg, ng, zg = clean.to(dev), noisy.to(dev), z.to(dev)
-            Genh, d_real, d_fake = mm.d_phase(cg, ng, Dopt, crit, z=zg)
-
-            def rel(a, b):
-                a, b = a.detach().double().cpu(), b.detach().double().cpu()
-                return ((a - b).norm() / b.norm().clamp_min(1e-300)).item()
-            y = Genh.detach().cpu().double()
-            yr = ref['Genh'].double()
+            random.seed(77)                 # the misalign permutation
+            Genh, d_loss = mm.wgan_d_phase(cg, ng, Dopt, z=zg)
+            y, yr = Genh.detach().cpu().double(), ref['Genh'].double()
             dn = dict(mm.D.named_parameters())
-            d_grad = max(rel(dn[k].grad, g) for k, g in ref['d_grads'].items()
+            d_grad = max(_rel(dn[k].grad, g) for k, g in ref['d_grads'].items()
                          if not k.endswith('conv.bias'))
             mm.D.load_state_dict({k: ref['D'].get(k, v) for k, v in dsd0.items()})
             ops.bump_weights_epoch()
-            g_adv, g_l1 = mm.g_phase(Genh, cg, ng, Gopt, crit, 100.0)
+            G_cost, g_adv, pow_loss, den_loss = mm.wgan_g_phase(names, Genh, cg, ng, Gopt, 100.0)
             torch.cuda.synchronize()
             gn = dict(mm.G.named_parameters())
-            g_grad = max(rel(gn[k].grad, g) for k, g in ref['g_grads'].items())
-            parity = {
-                'batch': B, 'g_mse': ((y - yr) ** 2).mean().item(),
-                'g_max_abs': (y - yr).abs().max().item(),
-                'd_real_loss_rel': abs(float(d_real) - float(ref['d_real_loss'])) / abs(float(ref['d_real_loss'])),
-                'd_fake_loss_rel': abs(float(d_fake) - float(ref['d_fake_loss'])) / abs(float(ref['d_fake_loss'])),
-                'g_adv_loss_rel': abs(float(g_adv) - float(ref['g_adv_loss'])) / abs(float(ref['g_adv_loss'])),
-                'g_l1_loss_rel': abs(float(g_l1) - float(ref['g_l1_loss'])) / abs(float(ref['g_l1_loss'])),
-                'd_grad_rel_l2_worst_tensor': d_grad, 'g_grad_rel_l2_worst_tensor': g_grad,
-                'note': 'HIP step (deterministic mode) vs the CPU oracle step timed above, same weights / '
-                        'inputs / z / phase shifts; generator phase through the oracle\'s post-step D; '
-                        'gradient figures are relative L2 per tensor (ReLU-gate flips at fp32 roundoff '
-                        'bound them, tests/test_gpu_kernels.py::test_discriminator_batchnorm_at_batch_300)',
-            }
+            g_grad = max(_rel(gn[k].grad, g) for k, g in ref['g_grads'].items())
+            out[name] = {'batch': B, 'g_mse': ((y - yr) ** 2).mean().item(),
+                         'g_max_abs': (y - yr).abs().max().item(),
+                         'd_loss_rel': _lrel(d_loss, ref['d_loss']), 'g_adv_loss_rel': _lrel(g_adv, ref['g_adv']),
+                         'pow_loss_rel': _lrel(pow_loss, ref['pow_loss']),
+                         'den_loss_rel': _lrel(den_loss, ref['den_loss']),
+                         'd_grad_rel_l2_worst_tensor': d_grad, 'g_grad_rel_l2_worst_tensor': g_grad}
             del mm, Gopt, Dopt
+        except Exception as e:
+            out[name] = {'error': repr(e)}
         finally:
             ops.set_deterministic(old)
-    return out, parity
+    return base, out
+
+
+def csrc_sha():
+    """Short hash over the HIP sources: profile-derived figures carry the hash of the sources they
+    were measured on, so a bench line built on newer kernels shows them as stale."""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(ROOT, 'segan_pytorch_amd', 'csrc', '*.hip')) +
+                    glob.glob(os.path.join(ROOT, 'segan_pytorch_amd', 'csrc', '*.h'))):
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()[:12]
+
+
+def _profile(name):
+    """The newest committed profiles/rNN_<name> file (round-numbered)."""
+    import glob
+    c = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_' + name)))
+    return c[-1] if c else None
 
 
 def pmc_mfma_busy(family):
-    """MFMA-pipe busy fraction of a kernel family from the committed SQ counter passes
-    (profiles/r02_sq_counters.json, scripts/pmc_sq.sh): MFMA instructions x 64 cycles over the
+    """MFMA-pipe busy fraction of a kernel family from the newest committed SQ counter passes
+    (profiles/rNN_sq_counters.json, scripts/pmc_sq.sh): MFMA instructions x 64 cycles over the
     SIMD-cycles of the launch."""
     try:
-        d = json.load(open(os.path.join(ROOT, 'profiles', 'r02_sq_counters.json')))
+        d = json.load(open(_profile('sq_counters.json')))
         return d['_summary'][family + '_mfma_pipe_busy_mean']
     except Exception:
         return None
@@ -270,15 +395,18 @@ def pmc_mfma_busy(family):
 
 def pmc_traffic(main=('corr2_kernel', 'corr_kernel<', 'conv_dgrad_short_kernel'),
                 extra=('corr_fixup_kernel',)):
-    """HBM bytes per launch of the dominant kernel family from the committed rocprofv3 PMC passes
-    (profiles/r02_pmc_hbm_traffic.json: FETCH_SIZE and WRITE_SIZE in separate passes over this
-    same command; FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md): bytes of
-    the contraction kernels plus their stream-K fix-up passes, per contraction launch."""
-    path = os.path.join(ROOT, 'profiles', 'r02_pmc_hbm_traffic.json')
-    if not os.path.exists(path):
-        return None
+    """HBM bytes per launch of the dominant kernel family from the newest committed rocprofv3 PMC
+    passes (profiles/rNN_pmc_hbm_traffic.json: FETCH_SIZE and WRITE_SIZE in separate passes over
+    this same command; FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md): bytes
+    of the contraction kernels plus their stream-K fix-up passes, per contraction launch.
+    Returns (bytes per launch, provenance dict) — the provenance says which file, which source
+    hash it was measured on and whether the sources have changed since (`stale`)."""
+    path = _profile('pmc_hbm_traffic.json')
+    if path is None:
+        return None, None
     try:
-        ks = json.load(open(path))['kernels']
+        d = json.load(open(path))
+        ks = d['kernels']
         n = f = w = 0.0
         for name, v in ks.items():
             is_main = any(m in name for m in main)
@@ -287,10 +415,13 @@ def pmc_traffic(main=('corr2_kernel', 'corr_kernel<', 'conv_dgrad_short_kernel')
                 f += v['launches'] * v['fetch_kb_avg']
                 w += v['launches'] * v['write_kb_avg']
         if n == 0:
-            return None
-        return (2.0 * f + w) * 1024.0 / n
+            return None, None
+        prov = {'file': os.path.relpath(path, ROOT), 'measured_on_csrc_sha': d.get('csrc_sha'),
+                'current_csrc_sha': csrc_sha()}
+        prov['stale'] = prov['measured_on_csrc_sha'] != prov['current_csrc_sha']
+        return (2.0 * f + w) * 1024.0 / n, prov
     except Exception:
-        return None
+        return None, None
 
 
 def main():
@@ -356,7 +487,9 @@ def main():
         backend = dist.get_backend()
         if backend != 'nccl' and 'SEGAN_DIST_BACKEND' not in os.environ:
             raise SystemExit('expected the RCCL (nccl) backend, got {}'.format(backend))
-        mine = torch.tensor([rank, dev.index], device=dev, dtype=torch.int64)
+        # (gloo — the shared-GPU test hook — gathers host tensors only)
+        mine = torch.tensor([rank, dev.index], device=dev if backend == 'nccl' else 'cpu',
+                            dtype=torch.int64)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         ranks_seen = sorted(int(t[0]) for t in allr)
@@ -367,6 +500,7 @@ def main():
     if args.shape == 'vanilla11':
         opts.update(VANILLA11)
     gflop = gflop_per_chunk(opts, wsegan=args.wsegan)
+    gflop_exec = gflop_per_chunk(opts, wsegan=args.wsegan, executed=True)
     random.seed(111); np.random.seed(111); torch.manual_seed(111)
     if args.wsegan:
         opts.update(dict(misalign_pair=True, interf_pair=False, pow_weight=0.001, vanilla_gan=False,
@@ -422,6 +556,27 @@ def main():
         dt = float(t.item())
     finite = all(bool(torch.isfinite(x)) for x in losses_out)
 
+    # what reproducibility costs: the same K steps with every reduction in a fixed order
+    ms_det = None
+    if not args.no_modes and not _ops.get_deterministic():
+        _ops.set_deterministic(True)
+        try:
+            for _ in range(2):
+                one_step()
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                one_step()
+            barrier()
+            dd = time.perf_counter() - t1
+            if world > 1:
+                t = torch.tensor([dd], device=dev, dtype=torch.float64)
+                torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+                dd = float(t.item())
+            ms_det = 1e3 * dd / args.steps
+        finally:
+            _ops.set_deterministic(False)
+
     # Same step with the contractions on the bf16 matrix cores, reported BESIDE the fp32
     # headline (never as `value`): 'bf16x3' = exact 3-way split of the fp32 operands,
     # 'bf16' = BASELINE config 5.  Every rank runs the same steps (the collectives match).
@@ -432,12 +587,18 @@ def main():
                 _ops.set_precision(prec)
                 for _ in range(2):
                     one_step()
+                mt = None
+                if not args.no_kernel_timer:
+                    mt = KernelTimer()
+                    mt.install()
                 barrier()
                 t1 = time.perf_counter()
                 for _ in range(args.steps):
                     lo = one_step()
                 barrier()
                 dm = time.perf_counter() - t1
+                if mt is not None:
+                    mt.uninstall()
                 if world > 1:
                     t = torch.tensor([dm], device=dev, dtype=torch.float64)
                     torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -445,6 +606,20 @@ def main():
                 modes[prec] = {'value': B * world * args.steps / dm, 'unit': 'chunks/s',
                                'ms_per_step': 1e3 * dm / args.steps,
                                'losses_finite': all(bool(torch.isfinite(x)) for x in lo)}
+                if mt is not None:
+                    # bf16: one bf16 MFMA per product; bf16x3: six, so the peak
+                    # in fp32-equivalent FLOPs is a sixth of the dense bf16 peak
+                    peak = PEAK_BF16_MFMA_TF / (6.0 if prec == 'bf16x3' else 1.0)
+                    for fam, key in (('corr', 'roofline'), ('wgrad', 'roofline_wgrad')):
+                        r = mt.summary().get(fam)
+                        if r:
+                            modes[prec][key] = {
+                                'bound': 'mfma', 'achieved': r['tflops'], 'peak': peak, 'unit': 'TFLOP/s',
+                                'frac': r['tflops'] / peak, 'avg_launch_us': r['avg_us'],
+                                'launches': r['launches'],
+                                'share_of_step_time': r['total_ms'] / (1e3 * dm),
+                                'kernel': ('conv/deconv forward + data gradient' if fam == 'corr'
+                                           else 'weight gradients') + ' on v_mfma_f32_32x32x16_bf16'}
             except Exception as e:      # a side measurement must never cost the headline line
                 modes[prec] = {'error': repr(e)}
                 break
@@ -476,22 +651,32 @@ def main():
                        'z': 'device generator' if args.device_z else 'host randn + H2D per step (as train.py)'},
             'losses_finite': finite,
             'precision': args.precision,
+            'reduction_mode': 'deterministic' if _ops.get_deterministic() else 'default (fp32 atomics in the weight-gradient / dense-head splits)',
+            'ms_per_step_deterministic': ms_det,
             'gflop_per_chunk': gflop,
+            'gflop_per_chunk_executed': gflop_exec,
             'step_tflops': gflop * value / 1e3,
             'step_frac_of_f32_mfma_peak': gflop * value / 1e3 / PEAK_F32_MFMA_TF / world,
+            'step_frac_executed': gflop_exec * value / 1e3 / PEAK_F32_MFMA_TF / world,
+            'step_frac_note': 'step_frac_of_f32_mfma_peak divides the REFERENCE accounting (SURVEY.md 8d: '
+                              'it counts the D weight gradients of the generator phase, which the reference '
+                              'computes and discards) by the time; step_frac_executed counts only what this '
+                              'engine executes (one D forward-equivalent less)',
             'step_hbm_gbs_algorithmic': MB_PER_CHUNK * value / 1e3 / world,
             'step_frac_of_hbm_roofline': MB_PER_CHUNK * value / 1e3 / world / PEAK_HBM_GBS,
         }
         if timer is not None:
             s = timer.summary()
             c = s.get('corr')
+            traffic, traffic_prov = pmc_traffic()
             if c:
                 line['roofline'] = {
                     'bound': 'mfma', 'kernel': 'corr2_kernel + conv_dgrad_short_kernel (conv/deconv forward + data gradient)',
                     'achieved': c['tflops'], 'peak': PEAK_F32_MFMA_TF, 'unit': 'TFLOP/s',
-                    'frac': c['tflops'] / PEAK_F32_MFMA_TF, 'traffic': pmc_traffic(),
-                    'traffic_unit': 'HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, '
-                                    'profiles/r02_pmc_hbm_traffic.json)',
+                    'frac': c['tflops'] / PEAK_F32_MFMA_TF, 'traffic': traffic,
+                    'traffic_unit': 'HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE; a committed '
+                                    'profile, not measured in this run: see traffic_source)',
+                    'traffic_source': traffic_prov,
                     'avg_launch_us': c['avg_us'], 'launches': c['launches'],
                     'gflop_per_launch': c['flops_per_launch'] / 1e9,
                     'share_of_step_time': c['total_ms'] / (1e3 * dt),
@@ -514,11 +699,30 @@ def main():
             try:
                 del model, Gopt, Dopt
                 torch.cuda.empty_cache()
-                line['cpu_baseline'], parity = cpu_baseline(args.cpu_batch, args.cpu_steps, dev)
+                line['cpu_baseline'], parity = cpu_baseline(
+                    args.cpu_batch, args.cpu_steps, dev,
+                    modes=tuple(k for k in modes if k in ('bf16x3', 'bf16') and 'error' not in modes[k]))
                 line['speedup_vs_cpu_baseline'] = value / line['cpu_baseline']['value']
-                if parity is not None:
-                    line['parity'] = parity
+                if parity:
+                    line['parity'] = dict(parity.get('fp32_deterministic', {}), note=PARITY_NOTE)
+                    line['parity_default_mode'] = parity.get('fp32_default')
+                    for k in ('bf16x3', 'bf16'):
+                        if k in parity and k in line.get('other_precisions', {}):
+                            line['other_precisions'][k]['parity'] = parity[k]
             except Exception as e:  # the bench line must still be printed
+                line['cpu_baseline'] = {'error': repr(e)}
+        elif world == 1 and not args.no_cpu_baseline and args.shape == 'segan_plus' and args.wsegan:
+            try:
+                del model, Gopt, Dopt
+                torch.cuda.empty_cache()
+                line['cpu_baseline'], par = wsegan_parity(opts, args.cpu_batch, dev)
+                line['speedup_vs_cpu_baseline'] = value / line['cpu_baseline']['value']
+                line['parity'] = dict(par.get('fp32_deterministic', {}),
+                                      note='HIP WSEGAN step vs the oracle WSEGAN step timed above (same '
+                                           'weights / inputs / z / phase shifts / misalign permutation; '
+                                           'generator phase through the oracle\'s post-step D)')
+                line['parity_default_mode'] = par.get('fp32_default')
+            except Exception as e:
                 line['cpu_baseline'] = {'error': repr(e)}
         print(json.dumps(line))
     if world > 1:

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SEGAN_ABI_VERSION 8
+#define SEGAN_ABI_VERSION 9
 
 #define SEGAN_PAD_REFLECT 0
 #define SEGAN_PAD_ZERO 1
@@ -365,6 +365,28 @@ int segan_adam_step(float* p, const float* g, float* m, float* v, float lr, floa
                     float beta2, float eps, int step, int64_t n, void* stream);
 int segan_fill(float* p, float value, int64_t n, void* stream);
 int segan_scale(float* p, float s, int64_t n, void* stream);
+
+/* ---- data-parallel exchange (the reference has none: README.md:79) --------
+ * One communicator per process (= per GPU) over RCCL, bound at run time (dlopen of librccl.so.1:
+ * a host process that already carries an RCCL, e.g. PyTorch-ROCm, keeps exactly one copy).  The
+ * communicator is the only library-owned resource.  Rendezvous: rank 0 calls
+ * segan_comm_unique_id, ships the segan_comm_id_bytes() bytes to the other ranks over any side
+ * channel, then every rank calls segan_comm_init (a collective) with its device current.
+ * segan_allreduce: in-place SUM over ranks of n floats followed by * scale (1/world = the mean
+ * of the per-rank gradients: D 25.8 M floats between the D backward passes and its optimizer
+ * step, G 64.8 M floats between the G backward and its step — or bucket by bucket from inside
+ * the backward), enqueued on `stream`, asynchronous w.r.t. the host.  segan_broadcast: rank
+ * `root`'s n floats to all (initial weights).  segan_allgather: recv[world][n] <- send[n]
+ * (synchronised-BatchNorm partial statistics). */
+int segan_comm_id_bytes(void);
+int segan_comm_unique_id(void* id_out);
+int segan_comm_init(void** comm_out, int world, int rank, const void* id);
+int segan_comm_destroy(void* comm);
+int segan_comm_rank(void* comm);
+int segan_comm_world(void* comm);
+int segan_allreduce(void* comm, float* buf, size_t n, float scale, void* stream);
+int segan_broadcast(void* comm, float* buf, size_t n, int root, void* stream);
+int segan_allgather(void* comm, const float* send, float* recv, size_t n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -30,6 +30,17 @@ tiny_gvariants.pt (python oracle/make_golden.py gvariants) the Generator options
                  every block, generator.py:126,166-176) and skip_dropout (generator.py:53-54,
                  70-71), alone and combined: output, eval-mode output and all gradients of a
                  linear loss, with the torch seed that drives the dropout masks.
+tiny_nobias.pt / segan_plus_nobias_b2.pt (python oracle/make_golden.py nobias) --no_bias, the
+                 reference's own batch-300 recipe (run_segan+_train.sh:7, train.py:248): G's
+                 convs (and conv skips) are built without a bias, the transposed convs keep
+                 theirs (modules.py:116-119 ignores the flag), D keeps all of its biases.  One
+                 GAN step of the tiny net (full tensors) and of the default net at B=2
+                 (checksums, like segan_plus_b2.pt).
+tiny_wsegan_interf.pt (python oracle/make_golden.py interf) the literal ``WSEGAN.train`` with
+                 --interf_pair (model.py:606-628), two iterations each: 'both' =
+                 --misalign_pair --interf_pair (four D forwards per step, d_weight 1/4),
+                 'interf_only' = --interf_pair alone (three forwards, still weighted 1/4 as the
+                 reference does).
 """
 import json
 import os
@@ -320,10 +331,95 @@ def make_gvariants(ref):
     print('tiny_gvariants.pt done')
 
 
+def make_nobias(ref):
+    o = tiny_opts()
+    o['no_bias'] = True
+    o['bias'] = False                       # train.py:248
+    seed_all(111)
+    segan = ref.SEGAN(SimpleNamespace(**o))
+    clean, noisy = synth(3, 1024, 20)
+    clean, noisy = clean.unsqueeze(1), noisy.unsqueeze(1)
+    z = torch.randn(3, 32, 16, generator=torch.Generator().manual_seed(21))
+    fx = {'opts': o, 'G0': clone_sd(segan.G), 'D0': clone_sd(segan.D), 'clean': clean,
+          'noisy': noisy, 'z': z, 'roll_seed': 17,
+          'rolls': ref_harness.ReplayRandom(17).rolls(3, o['phase_shift'], 3)}
+    fx.update(manual_step(ref, segan, clean, noisy, z, 17))
+    torch.save(fx, os.path.join(OUT, 'tiny_nobias.pt'))
+    print('tiny_nobias.pt done; G keys with bias:', sorted(k for k in fx['G0'] if 'bias' in k))
+    ob = base_opts()
+    ob['save_path'] = '/tmp/segan_golden_ckpt'
+    ob['no_bias'] = True
+    ob['bias'] = False
+    seed_all(111)
+    segan = ref.SEGAN(SimpleNamespace(**ob))
+    clean, noisy = synth(2, 16384, 0)
+    clean, noisy = clean.unsqueeze(1), noisy.unsqueeze(1)
+    z = torch.randn(2, 1024, 16, generator=torch.Generator().manual_seed(0))
+    fx4 = {'opts': ob, 'seed': 111, 'roll_seed': 3, 'z_seed': 0, 'data_seed': 0,
+           'rolls': ref_harness.ReplayRandom(3).rolls(5, ob['phase_shift'], 3),
+           'init_G': {k: checksum(v) for k, v in segan.G.state_dict().items()},
+           'init_D': {k: checksum(v) for k, v in segan.D.state_dict().items()}}
+    res = manual_step(ref, segan, clean, noisy, z, 3)
+    for k in ('Genh', 'd_real', 'd_fake', 'd_fake_', 'd_real_loss', 'd_fake_loss', 'g_adv_loss',
+              'g_l1_loss'):
+        fx4[k] = res[k]
+    fx4['d_grads'] = {k: checksum(v) for k, v in res['d_grads'].items()}
+    fx4['g_grads'] = {k: checksum(v) for k, v in res['g_grads'].items()}
+    fx4['small_d_grads'] = {k: v for k, v in res['d_grads'].items() if v.numel() <= 4096}
+    fx4['small_g_grads'] = {k: v for k, v in res['g_grads'].items() if v.numel() <= 4096}
+    fx4['G_after'] = {k: checksum(v) for k, v in res['G_after'].items()}
+    fx4['D_after'] = {k: checksum(v) for k, v in res['D_after'].items()}
+    torch.save(fx4, os.path.join(OUT, 'segan_plus_nobias_b2.pt'))
+    print('segan_plus_nobias_b2.pt done', res['Genh'].shape, res['g_l1_loss'],
+          sum(p.numel() for p in segan.G.parameters()))
+
+
+def make_interf(ref):
+    """The literal WSEGAN.train with --interf_pair (same harness-only patches as tiny_wsegan2:
+    legacy torch.stft call, hard .cuda())."""
+    _stft = torch.stft
+    torch.stft = lambda *a, **k: torch.view_as_real(_stft(*a, return_complex=True, **k))
+    _cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    out = {}
+    try:
+        for i, (name, mis) in enumerate((('both', True), ('interf_only', False))):
+            ow = tiny_opts()
+            ow.update(dict(wsegan=True, misalign_pair=mis, interf_pair=True, cuda=False,
+                           save_freq=1000))
+            seed_all(111)
+            wseg = ref.WSEGAN(SimpleNamespace(**ow))
+            c1, n1 = synth(3, 1024, 24 + i)
+            names = ['utt_additive_0', 'utt_1', 'utt_additive_2']
+            loader = [[names, c1, n1, torch.zeros(3)]]
+            fxw = {'opts': ow, 'G0': clone_sd(wseg.G), 'D0': clone_sd(wseg.D), 'clean': c1,
+                   'noisy': n1, 'names': names, 'seed': 41 + i, 'iters': 2}
+            ow2 = dict(ow)
+            ow2['epoch'] = 2
+            seed_all(41 + i)
+            wseg.train(SimpleNamespace(**ow2), loader, None, ow['l1_weight'], ow['l1_dec_step'],
+                       ow['l1_dec_epoch'], 1000, va_dloader=None, device='cpu')
+            fxw['G_final'] = clone_sd(wseg.G)
+            fxw['D_final'] = clone_sd(wseg.D)
+            out[name] = fxw
+            print('interf', name, 'done')
+    finally:
+        torch.stft = _stft
+        torch.Tensor.cuda = _cuda
+    torch.save(out, os.path.join(OUT, 'tiny_wsegan_interf.pt'))
+    print('tiny_wsegan_interf.pt done')
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = ref_harness.import_reference()
     torch.set_num_threads(max(1, os.cpu_count() or 1))
+    if len(sys.argv) > 1 and sys.argv[1] == 'nobias':
+        make_nobias(ref)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == 'interf':
+        make_interf(ref)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'snorm':     # only the spectral-norm fixtures
         make_snorm(ref)
         make_wsegan_snorm(ref)

@@ -300,28 +300,60 @@ def stft_pow_db(x, n_fft=2048):
     return 10 * torch.log10(st.abs() ** 2 + 10e-20)
 
 
+def interf_squares(n, T):
+    """The interference pair's square waves, model.py:606-623: per sample one
+    random.choice(freqs) and one random.choice(amps) (python `random`, in that order),
+    a * scipy.signal.square(2 pi f t) on t = linspace(0, 2, 32000), cut to T samples."""
+    import random
+    import numpy as np
+    from scipy import signal
+    freqs, amps = [250, 1000, 4000], [0.01, 0.05, 0.1, 1]
+    t = np.linspace(0, 2, 32000)
+    out = []
+    for _ in range(n):
+        f_ = random.choice(freqs)
+        a_ = random.choice(amps)
+        sq = a_ * signal.square(2 * np.pi * f_ * t)
+        out.append(torch.FloatTensor(sq[:T].reshape((1, -1))))
+    return torch.cat(out, dim=0).unsqueeze(1)
+
+
 def wsegan_step(g_sd, d_sd, clean, noisy, z, rolls, perm, names, strides, l1_weight=100.0,
-                pow_weight=0.001, lr=5e-5, n_fft=2048, g_sq=None, d_sq=None):
-    """One WSEGAN step with --misalign_pair, model.py:577-669 (LSGAN cost).  rolls: the
-    four roll lists in call order (D real, D fake, D misaligned, D fake-for-G); perm: the
-    batch permutation random.shuffle produced (model.py:598-600)."""
+                pow_weight=0.001, lr=5e-5, n_fft=2048, g_sq=None, d_sq=None, squares=None):
+    """One WSEGAN step, model.py:577-669 (LSGAN cost).  rolls: the roll lists in call order
+    (D real, D fake, [D misaligned,] [D interference,] D fake-for-G); perm: the batch
+    permutation random.shuffle produced for --misalign_pair (model.py:598-600) or None;
+    squares: the --interf_pair square waves [B, 1, T] (model.py:606-628) or None.  The weight
+    of the summed D loss follows the reference literally: 1/2, 1/3 with the misaligned pair,
+    1/4 with the interference pair (with or without the misaligned one)."""
     G = _leafs(g_sd)
     D = _leafs(d_sd)
     B = clean.size(0)
+    rolls = list(rolls)
     ones, zeros = torch.ones(B, 1, dtype=clean.dtype), torch.zeros(B, 1, dtype=clean.dtype)
-    d_real = discriminator_forward(D, torch.cat((clean, noisy), 1), rolls[0], strides)
+    d_real = discriminator_forward(D, torch.cat((clean, noisy), 1), rolls.pop(0), strides)
     Genh = generator_forward(G, noisy, z, strides)
-    d_fake = discriminator_forward(D, torch.cat((Genh.detach(), noisy), 1), rolls[1], strides)
+    d_fake = discriminator_forward(D, torch.cat((Genh.detach(), noisy), 1), rolls.pop(0), strides)
     d_loss = F.mse_loss(d_fake, zeros) + F.mse_loss(d_real, ones)
-    d_shuf = discriminator_forward(D, torch.cat((clean, clean[perm]), 1), rolls[2], strides)
-    d_loss = (d_loss + F.mse_loss(d_shuf, zeros)) * (1 / 3)
+    d_weight = 0.5
+    if perm is not None:
+        d_shuf = discriminator_forward(D, torch.cat((clean, clean[perm]), 1), rolls.pop(0), strides)
+        d_loss = d_loss + F.mse_loss(d_shuf, zeros)
+        d_weight = 1 / 3
+    if squares is not None:
+        d_int = discriminator_forward(D, torch.cat((clean + squares, noisy), 1), rolls.pop(0),
+                                      strides)
+        d_loss = d_loss + F.mse_loss(d_int, zeros)
+        d_weight = 1 / 4
+    d_loss = d_weight * d_loss
     dkeys = [k for k in D if _is_param(k)]
     dgr = torch.autograd.grad(d_loss, [D[k] for k in dkeys])
+    d_grads = {k: g for k, g in zip(dkeys, dgr)}
     d_sq = d_sq or {k: torch.zeros_like(D[k]) for k in dkeys}
     with torch.no_grad():
         for k, g in zip(dkeys, dgr):
             rmsprop_update(D[k], g, d_sq[k], lr)
-    d_fake_ = discriminator_forward(D, torch.cat((Genh, noisy), 1), rolls[3], strides)
+    d_fake_ = discriminator_forward(D, torch.cat((Genh, noisy), 1), rolls.pop(0), strides)
     g_adv = F.mse_loss(d_fake_, ones)
     pow_loss = pow_weight * F.l1_loss(stft_pow_db(Genh, n_fft), stft_pow_db(clean, n_fft))
     mask = torch.zeros(B, 1, Genh.size(2), dtype=clean.dtype)
@@ -331,10 +363,12 @@ def wsegan_step(g_sd, d_sd, clean, noisy, z, rolls, perm, names, strides, l1_wei
     den_loss = l1_weight * F.l1_loss(Genh * mask, clean * mask)
     gkeys = [k for k in G if G[k].requires_grad]
     ggr = torch.autograd.grad(g_adv + pow_loss + den_loss, [G[k] for k in gkeys])
+    g_grads = {k: g for k, g in zip(gkeys, ggr)}
     g_sq = g_sq or {k: torch.zeros_like(G[k]) for k in gkeys}
     with torch.no_grad():
         for k, g in zip(gkeys, ggr):
             rmsprop_update(G[k], g, g_sq[k], lr)
     return {'G': {k: v.detach() for k, v in G.items()}, 'D': {k: v.detach() for k, v in D.items()},
             'g_sq': g_sq, 'd_sq': d_sq, 'd_loss': d_loss.detach(), 'g_adv': g_adv.detach(),
-            'pow_loss': pow_loss.detach(), 'den_loss': den_loss.detach(), 'Genh': Genh.detach()}
+            'pow_loss': pow_loss.detach(), 'den_loss': den_loss.detach(), 'Genh': Genh.detach(),
+            'd_grads': d_grads, 'g_grads': g_grads}

@@ -5,7 +5,10 @@ usage: python scripts/pmc_traffic.py FETCH_counter_collection.csv WRITE_counter_
 import collections
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def per_kernel(path, counter):
@@ -30,6 +33,7 @@ out = {
             '--precision fp32, B=300; units KB per launch as reported; gfx950 FETCH_SIZE '
             'under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md HBM section)'.format(steps - 1),
     'steps_profiled': steps,
+    'csrc_sha': __import__('bench').csrc_sha(),      # the HIP sources these numbers were measured on
     'per_step_fetch_gb_raw': sum(sum(v) for v in fetch.values()) / 1e6 / steps * 1.024,
     'per_step_write_gb': sum(sum(v) for v in write.values()) / 1e6 / steps * 1.024,
     'kernels': kernels,

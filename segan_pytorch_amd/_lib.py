@@ -14,7 +14,7 @@ PAD_REFLECT = 0
 PAD_ZERO = 1
 ACT_NONE = 0
 ACT_TANH = 1
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class SeganSrc(Structure):
@@ -96,6 +96,15 @@ SIGNATURES = {
                                 _P]),
     'segan_fill': (c_int, [_P, c_float, c_int64, _P]),
     'segan_scale': (c_int, [_P, c_float, c_int64, _P]),
+    'segan_comm_id_bytes': (c_int, []),
+    'segan_comm_unique_id': (c_int, [_P]),
+    'segan_comm_init': (c_int, [POINTER(c_void_p), c_int, c_int, _P]),
+    'segan_comm_destroy': (c_int, [_P]),
+    'segan_comm_rank': (c_int, [_P]),
+    'segan_comm_world': (c_int, [_P]),
+    'segan_allreduce': (c_int, [_P, _P, c_size_t, c_float, _P]),
+    'segan_broadcast': (c_int, [_P, _P, c_size_t, c_int, _P]),
+    'segan_allgather': (c_int, [_P, _P, _P, c_size_t, _P]),
 }
 
 _lib = None

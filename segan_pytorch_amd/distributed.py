@@ -73,7 +73,40 @@ def init_from_env(backend=None):
                                     device_id=torch.device('cuda', lr))
         else:
             dist.init_process_group(backend, rank=rk, world_size=ws)
+    _init_native(rk, ws)
     return rk, ws, lr
+
+
+# ---- the exchange through libsegan_hip's own RCCL communicator (SEGAN_COMM=native) ------------
+_native = None          # ops.Comm
+_native_stream = None   # side stream the bucket all-reduces run on
+
+
+def native_comm():
+    """The library-owned RCCL communicator (C ABI: segan_comm_init / segan_allreduce /
+    segan_comm_destroy) when SEGAN_COMM=native, else None.  torch.distributed then only carries
+    the 128-byte rendezvous id (and the host-side barriers of the launch scripts); gradients,
+    initial weights and synchronised-BatchNorm statistics travel through the C ABI."""
+    return _native
+
+
+def _init_native(rk, ws):
+    global _native, _native_stream
+    if _native is not None or os.environ.get('SEGAN_COMM') != 'native' or not torch.cuda.is_available():
+        return
+    ident = [ops.comm_unique_id() if rk == 0 else None]
+    if ws > 1:
+        dist.broadcast_object_list(ident, src=0)
+    _native = ops.Comm(ws, rk, ident[0])
+    _native_stream = torch.cuda.Stream()
+
+
+def destroy_native():
+    global _native, _native_stream
+    if _native is not None:
+        torch.cuda.synchronize()
+        _native.destroy()
+        _native, _native_stream = None, None
 
 
 def allreduce_mean_(flat):
@@ -81,6 +114,8 @@ def allreduce_mean_(flat):
     ws = world_size()
     if ws <= 1:
         return flat
+    if _native is not None and flat.is_cuda:
+        return _native.allreduce(flat, 1.0 / ws)
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     if flat.is_cuda:
         ops.scale_(flat, 1.0 / ws)
@@ -140,8 +175,17 @@ class GradReducer(object):
 
     def _send(self, b):
         lo, hi = self.buckets[b]
-        self.works.append(dist.all_reduce(self.opt.flat_grad[lo:hi], op=dist.ReduceOp.SUM,
-                                          async_op=True))
+        flat = self.opt.flat_grad
+        if _native is not None and flat.is_cuda:
+            # C-ABI path: the bucket's sum AND its 1/world scale on the side stream, behind the
+            # kernels that produced it (event), under the rest of the backward pass
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            _native_stream.wait_event(ev)
+            _native.allreduce(flat[lo:hi], 1.0 / world_size(), stream=_native_stream)
+            self.native = True
+        else:
+            self.works.append(dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
         self.sent[b] = True
 
     def ready(self, p):
@@ -165,6 +209,12 @@ class GradReducer(object):
         self.armed = False
         self.works = []
         flat = self.opt.flat_grad
+        if getattr(self, 'native', False):
+            done = torch.cuda.Event()
+            done.record(_native_stream)
+            torch.cuda.current_stream().wait_event(done)     # the optimizer step follows
+            self.native = False
+            return                                           # already scaled per bucket
         if flat.is_cuda:
             ops.scale_(flat, 1.0 / world_size())
         else:
@@ -224,7 +274,10 @@ def broadcast_params(module, src=0):
         return
     with torch.no_grad():
         for t in list(module.parameters()) + list(module.buffers()):
-            dist.broadcast(t.data, src)
+            if _native is not None and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous():
+                _native.broadcast(t.data, src)
+            else:
+                dist.broadcast(t.data, src)
     ops.bump_weights_epoch()
 
 
@@ -265,14 +318,20 @@ def sync_bn_enabled():
 
 def bn_stats_sync(x, gamma, beta, eps, momentum, running_mean, running_var):
     ws = ops.bn_partial(x)                                   # [nsplit, C, 3]
-    parts = [torch.empty_like(ws) for _ in range(world_size())]
-    dist.all_gather(parts, ws)
-    return ops.bn_final(torch.cat(parts, 0).contiguous(), gamma, beta, eps, momentum, running_mean,
-                        running_var)
+    if _native is not None:
+        allp = _native.allgather(ws).view(-1, ws.shape[1], 3)
+    else:
+        parts = [torch.empty_like(ws) for _ in range(world_size())]
+        dist.all_gather(parts, ws)
+        allp = torch.cat(parts, 0).contiguous()
+    return ops.bn_final(allp, gamma, beta, eps, momentum, running_mean, running_var)
 
 
 def act_bwd_bn_sync(a, dh, slope, bn, dslope=None, dgamma=None, dbeta=None, dbias=None):
     totals, ws = ops.act_bwd_bn_reduce(a, dh, slope, bn, dslope, dgamma, dbeta)
-    dist.all_reduce(totals, op=dist.ReduceOp.SUM)
+    if _native is not None:
+        _native.allreduce(totals, 1.0)
+    else:
+        dist.all_reduce(totals, op=dist.ReduceOp.SUM)
     count = float(a.shape[0]) * float(a.shape[2]) * world_size()
     return ops.act_bwd_bn_apply(a, dh, slope, bn, totals, count, dbias, ws)

@@ -440,9 +440,11 @@ class WSEGAN(SEGAN):
         return (uttname, clean.unsqueeze(1).to(device), noisy.unsqueeze(1).to(device),
                 slice_idx.to(device))
 
-    def wgan_step(self, uttname, clean, noisy, Gopt, Dopt, l1_weight, z=None):
-        """One WSEGAN step (model.py:577-669).  Returns (d_loss, G_cost, pow_loss,
-        den_loss) as device scalars."""
+    def wgan_d_phase(self, clean, noisy, Dopt, z=None):
+        """Discriminator half of the WSEGAN step (model.py:577-631): D on the real pair, G
+        forward, D on the (detached) fake pair, optionally on the misaligned and the interference
+        pair; ONE backward of the weighted sum, gradient all-reduce, ``Dopt.step()``.  Returns
+        (Genh, d_loss); Genh keeps its graph for ``wgan_g_phase``."""
         from random import shuffle
         cost = losses.BCEWithLogitsLoss() if self.vanilla_gan else losses.MSELoss()
         bsz = clean.size(0)
@@ -476,7 +478,7 @@ class WSEGAN(SEGAN):
             squares = torch.cat(squares, dim=0).unsqueeze(1).to(clean.device)
             d_fake_inter, _ = self.infer_D(clean + squares, noisy)
             d_loss = d_loss + cost(d_fake_inter.view(-1), 0.0)
-            d_weight = 1 / 4
+            d_weight = 1 / 4    # also without the misaligned pair, as the reference (model.py:627)
             n_d_fwd += 1
         d_loss = d_weight * d_loss
         # every D forward reports every D parameter once: a bucket leaves after the last one
@@ -484,7 +486,14 @@ class WSEGAN(SEGAN):
         d_loss.backward()
         sdist.allreduce_grads(Dopt)
         Dopt.step()
+        return Genh, d_loss
 
+    def wgan_g_phase(self, uttname, Genh, clean, noisy, Gopt, l1_weight):
+        """Generator half (model.py:633-669): D (just updated, frozen here) on the fake pair,
+        adversarial + STFT log-power L1 + masked L1, backward, all-reduce, ``Gopt.step()``.
+        Returns (G_cost, g_adv_loss, pow_loss, den_loss)."""
+        cost = losses.BCEWithLogitsLoss() if self.vanilla_gan else losses.MSELoss()
+        bsz = clean.size(0)
         Gopt.zero_grad()
         with _frozen(self.D):
             d_fake_, _ = self.infer_D(Genh, noisy)
@@ -505,6 +514,14 @@ class WSEGAN(SEGAN):
             G_cost.backward()
         sdist.allreduce_grads(Gopt)
         Gopt.step()
+        return G_cost, g_adv_loss, pow_loss, den_loss
+
+    def wgan_step(self, uttname, clean, noisy, Gopt, Dopt, l1_weight, z=None):
+        """One WSEGAN step (model.py:577-669).  Returns (d_loss, G_cost, pow_loss,
+        den_loss) as device scalars."""
+        Genh, d_loss = self.wgan_d_phase(clean, noisy, Dopt, z=z)
+        G_cost, _g_adv, pow_loss, den_loss = self.wgan_g_phase(uttname, Genh, clean, noisy, Gopt,
+                                                               l1_weight)
         return d_loss, G_cost, pow_loss, den_loss
 
     def train(self, opts, dloader, criterion, l1_init, l1_dec_step, l1_dec_epoch, log_freq,

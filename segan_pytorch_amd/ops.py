@@ -939,3 +939,55 @@ def scale_(t, s):
     _chk(t, 't')
     check(_lib.load().segan_scale(_ptr(t), float(s), t.numel(), _stream()), 'scale')
     return t
+
+
+# ---- data-parallel exchange through the C ABI (RCCL bound at run time) ------------------------
+def comm_unique_id():
+    """Rendezvous id (bytes) for `Comm`: create on rank 0, ship to the other ranks."""
+    lib = _lib.load()
+    buf = ctypes.create_string_buffer(lib.segan_comm_id_bytes())
+    check(lib.segan_comm_unique_id(buf), 'comm_unique_id')
+    return buf.raw
+
+
+class Comm(object):
+    """One RCCL communicator owned by libsegan_hip (segan_comm_init ... segan_comm_destroy): the
+    data-parallel exchange of the GAN step without torch.distributed in the data path.  Creation
+    is a collective over all ranks; the current CUDA device becomes the communicator's."""
+
+    def __init__(self, world, rank, unique_id):
+        lib = _lib.load()
+        if len(unique_id) != lib.segan_comm_id_bytes():
+            raise ValueError('Comm: unique id must be {} bytes'.format(lib.segan_comm_id_bytes()))
+        h = ctypes.c_void_p()
+        check(lib.segan_comm_init(ctypes.byref(h), int(world), int(rank), unique_id), 'comm_init')
+        self._h, self.world, self.rank = h, int(world), int(rank)
+
+    def _s(self, stream):
+        return ctypes.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
+
+    def allreduce(self, t, scale=1.0, stream=None):
+        """In-place sum over ranks of a contiguous fp32 CUDA tensor, then * scale."""
+        _chk(t, 't')
+        check(_lib.load().segan_allreduce(self._h, _ptr(t), t.numel(), float(scale), self._s(stream)),
+              'allreduce')
+        return t
+
+    def broadcast(self, t, root=0, stream=None):
+        _chk(t, 't')
+        check(_lib.load().segan_broadcast(self._h, _ptr(t), t.numel(), int(root), self._s(stream)),
+              'broadcast')
+        return t
+
+    def allgather(self, send, stream=None):
+        """[world, *send.shape] <- every rank's `send`."""
+        _chk(send, 'send')
+        recv = torch.empty((self.world,) + tuple(send.shape), device=send.device, dtype=torch.float32)
+        check(_lib.load().segan_allgather(self._h, _ptr(send), _ptr(recv), send.numel(),
+                                          self._s(stream)), 'allgather')
+        return recv
+
+    def destroy(self):
+        if self._h is not None:
+            check(_lib.load().segan_comm_destroy(self._h), 'comm_destroy')
+            self._h = None

@@ -20,8 +20,10 @@ if mode != 'plain':
                       MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
                       SEGAN_DP_BUCKET_MB='8')
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-if mode == 'syncbn':
+if mode in ('syncbn', 'native_syncbn'):
     os.environ['SEGAN_SYNC_BN'] = '1'
+if mode.startswith('native'):
+    os.environ['SEGAN_COMM'] = 'native'      # gradients through libsegan_hip's own communicator
 
 import numpy as np
 import torch
@@ -55,22 +57,35 @@ random.seed(1000); torch.manual_seed(2000)
 crit = losses.MSELoss()
 if mode != 'plain':
     # count the collectives RCCL is asked for
-    n = {'all_reduce': 0}
+    n = {'all_reduce': 0, 'native_all_reduce': 0, 'native_floats': 0}
     real = dist.all_reduce
 
     def counted(*a, **k):
         n['all_reduce'] += 1
         return real(*a, **k)
     dist.all_reduce = counted
+    if mode.startswith('native'):
+        from segan_pytorch_amd import ops
+        assert sdist.native_comm() is not None and sdist.native_comm().world == 1
+        real_native = ops.Comm.allreduce
+
+        def counted_native(self, t, *a, **k):
+            n['native_all_reduce'] += 1
+            n['native_floats'] += t.numel()
+            return real_native(self, t, *a, **k)
+        ops.Comm.allreduce = counted_native
 for _ in range(2):
     ls = model.gan_step(clean, noisy, Gopt, Dopt, crit, 100.0, z=None)
 torch.cuda.synchronize()
 if mode != 'plain':
     info['all_reduce_calls'] = n['all_reduce']
+    info['native_all_reduce_calls'] = n['native_all_reduce']
+    info['native_floats'] = n['native_floats']
     dist.all_reduce = real
 info['losses'] = [float(x) for x in ls]
 sd = {'G.' + k: v.detach().cpu() for k, v in model.G.state_dict().items()}
 sd.update({'D.' + k: v.detach().cpu() for k, v in model.D.state_dict().items()})
 torch.save({'info': info, 'sd': sd}, out)
 if mode != 'plain':
+    sdist.destroy_native()
     dist.destroy_process_group()

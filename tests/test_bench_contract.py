@@ -1,13 +1,19 @@
-"""The committed bench line (profiles/r02_bench_line.json, the stdout of `python bench.py` on
-an MI355X) carries every field of the driver's contract."""
+"""The committed bench line (the newest profiles/rNN_bench_line.json, the stdout of `python
+bench.py` on an MI355X) carries every field of the driver's contract."""
+import glob
 import json
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _line():
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_bench_line.json')))
+    return json.load(open(files[-1])), os.path.basename(files[-1])
+
+
 def test_committed_bench_line_has_the_contract_fields():
-    d = json.load(open(os.path.join(ROOT, 'profiles', 'r02_bench_line.json')))
+    d, name = _line()
     for k, typ in (('metric', str), ('value', float), ('unit', str), ('n_gpus', int), ('steps', int),
                    ('warmup', int), ('ms_per_step', float), ('higher_is_better', bool),
                    ('scaling', str), ('dtype', str), ('data', str), ('config', dict)):
@@ -27,3 +33,26 @@ def test_committed_bench_line_has_the_contract_fields():
     pr = d['parity']
     assert pr['batch'] == 300 and pr['g_mse'] < 1e-4 and pr['g_max_abs'] < 1e-5
     assert max(pr['d_real_loss_rel'], pr['d_fake_loss_rel'], pr['g_adv_loss_rel'], pr['g_l1_loss_rel']) < 1e-4
+    if name >= 'r03':
+        # from round 3 on: the timed (atomics) mode and the bf16 modes are compared with the
+        # oracle at the benchmarked batch too, and the deterministic mode is timed
+        pd = d['parity_default_mode']
+        assert pd['batch'] == 300 and pd['g_mse'] < 1e-4 and pd['g_max_abs'] < 1e-5
+        for k, mse_tol in (('bf16x3', 1e-9), ('bf16', 1e-4)):
+            pp = d['other_precisions'][k]['parity']
+            assert pp['batch'] == 300 and pp['g_mse'] < mse_tol, k
+            assert d['other_precisions'][k]['roofline']['peak'] > 400
+        assert d['ms_per_step_deterministic'] > 0
+        assert d['gflop_per_chunk_executed'] < d['gflop_per_chunk']
+        assert abs(d['step_frac_executed'] - d['gflop_per_chunk_executed'] * d['value'] / 1e3 / 157.3) < 1e-9
+        assert 'stale' in r['traffic_source']
+
+
+def test_flop_accounting():
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    o = bench.default_opts()
+    assert abs(bench.gflop_per_chunk(o) - 37.96) < 0.01
+    assert abs(bench.gflop_per_chunk(o, executed=True) - 35.84) < 0.01
+    assert abs(bench.gflop_per_chunk(o, wsegan=True) - 44.33) < 0.01

@@ -92,6 +92,12 @@ def test_gan_step_orchestration_variants(tiny_variants, name):
     check_step(tiny_variants[name])
 
 
+def test_gan_step_orchestration_no_bias():
+    """--no_bias (run_segan+_train.sh:7): G's convs without a bias."""
+    from conftest import load_golden
+    check_step(load_golden('tiny_nobias.pt'))
+
+
 def test_hidden_outputs(tiny_step):
     fx = tiny_step
     m = build(fx)
@@ -182,6 +188,29 @@ def test_wsegan_literal_train(golden, tmp_path):
     from conftest import load_golden
     from segan_pytorch_amd.models import WSEGAN
     fx = load_golden(golden)
+    o = dict(fx['opts'])
+    o['save_path'] = str(tmp_path)
+    o['epoch'] = fx['iters']
+    m = WSEGAN(SimpleNamespace(**o))
+    m.G.load_state_dict(fx['G0'])
+    m.D.load_state_dict(fx['D0'])
+    loader = [[fx['names'], fx['clean'], fx['noisy'], torch.zeros(3)]]
+    random.seed(fx['seed'])
+    np.random.seed(fx['seed'])
+    torch.manual_seed(fx['seed'])
+    m.train(SimpleNamespace(**o), loader, None, o['l1_weight'], o['l1_dec_step'],
+            o['l1_dec_epoch'], 1000, va_dloader=None, device='cpu')
+    assert_weights_after_step(m.G.state_dict(), fx['G_final'])
+    assert_weights_after_step(m.D.state_dict(), fx['D_final'], skip=NOISE_KEYS)
+
+
+@pytest.mark.parametrize('flavour', ['both', 'interf_only'])
+def test_wsegan_interf_pair_literal_train(flavour, tmp_path):
+    """WSEGAN.train with --interf_pair (with and without --misalign_pair) against the
+    reference's literal loop (oracle/make_golden.py interf)."""
+    from conftest import load_golden
+    from segan_pytorch_amd.models import WSEGAN
+    fx = load_golden('tiny_wsegan_interf.pt')[flavour]
     o = dict(fx['opts'])
     o['save_path'] = str(tmp_path)
     o['epoch'] = fx['iters']

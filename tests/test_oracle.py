@@ -166,14 +166,11 @@ def _chk(t, c, tol):
     assert (got - c['sample']).abs().max().item() / den < max(tol, 1e-5)
 
 
-def test_default_net_init_and_step(segan_plus_b2):
-    """The default SEGAN+ net: OUR constructors under seed 111 must reproduce the
-    reference's initial weights, and the oracle its outputs/gradients at B=2."""
+def _default_net_init_and_step(fx):
     import random as pyrandom
     import numpy as np
     from segan_pytorch_amd.models import SEGAN
     from segan_pytorch_amd.datasets import synthetic_pairs
-    fx = segan_plus_b2
     pyrandom.seed(fx['seed'])
     np.random.seed(fx['seed'])
     torch.manual_seed(fx['seed'])
@@ -199,6 +196,30 @@ def test_default_net_init_and_step(segan_plus_b2):
         _chk(res['d_grads'][k], c, 1e-4)
     for k, c in fx['g_grads'].items():
         _chk(res['g_grads'][k], c, 1e-4)
+    return gsd
+
+
+def test_default_net_init_and_step(segan_plus_b2):
+    """The default SEGAN+ net: OUR constructors under seed 111 must reproduce the
+    reference's initial weights, and the oracle its outputs/gradients at B=2."""
+    _default_net_init_and_step(segan_plus_b2)
+
+
+def test_default_net_no_bias_init_and_step():
+    """--no_bias, the reference's own batch-300 recipe (run_segan+_train.sh:7, train.py:248): G's
+    convs have no bias (the transposed convs keep theirs, modules.py:116-119), D is unchanged;
+    same checks as the default net at B=2 (oracle/make_golden.py nobias)."""
+    from conftest import load_golden
+    gsd = _default_net_init_and_step(load_golden('segan_plus_nobias_b2.pt'))
+    assert not any(k.endswith('.conv.bias') for k in gsd)
+    assert sum(k.endswith('deconv.bias') for k in gsd) == 5
+
+
+def test_tiny_no_bias_step():
+    from conftest import load_golden
+    fx = load_golden('tiny_nobias.pt')
+    assert not any(k.endswith('.conv.bias') for k in fx['G0'])
+    _check_step(fx)
 
 
 def test_vanilla11_net_init_and_step(vanilla11_b8):
@@ -266,6 +287,44 @@ def test_wsegan_literal_train_replay(tiny_wsegan2):
         G, D, g_sq, d_sq = res['G'], res['D'], res['g_sq'], res['d_sq']
     for k, v in fx['G_final'].items():
         assert (G[k] - v).abs().max().item() < 5e-5, k   # 10 % of an RMSprop step
+    for k, v in fx['D_final'].items():
+        if not torch.is_floating_point(v) or k.endswith(('conv.bias', 'norm.running_mean')):
+            continue
+        assert (D[k] - v).abs().max().item() < 5e-5, k
+
+
+@pytest.mark.parametrize('flavour', ['both', 'interf_only'])
+def test_wsegan_interf_pair_literal_train_replay(flavour):
+    """--interf_pair (model.py:606-628), with and without --misalign_pair: the oracle's step
+    replayed against the reference's literal WSEGAN.train, two iterations; the python `random`
+    stream interleaves phase shifts, the misalign shuffle and the per-sample (frequency,
+    amplitude) choices exactly as the reference draws them."""
+    from conftest import draw_rolls, load_golden
+    fx = load_golden('tiny_wsegan_interf.pt')[flavour]
+    o = fx['opts']
+    st = o['genc_poolings']
+    random.seed(fx['seed'])
+    torch.manual_seed(fx['seed'])
+    clean, noisy = fx['clean'].unsqueeze(1), fx['noisy'].unsqueeze(1)
+    G, D, g_sq, d_sq = fx['G0'], fx['D0'], None, None
+    for _ in range(fx['iters']):
+        rolls = [draw_rolls(len(st), o['phase_shift'])]
+        z = torch.randn(clean.size(0), o['z_dim'], 16)
+        rolls.append(draw_rolls(len(st), o['phase_shift']))
+        perm = None
+        if o['misalign_pair']:
+            perm = list(range(clean.size(0)))
+            random.shuffle(perm)
+            rolls.append(draw_rolls(len(st), o['phase_shift']))
+        squares = O.interf_squares(clean.size(0), clean.size(-1))
+        rolls.append(draw_rolls(len(st), o['phase_shift']))
+        rolls.append(draw_rolls(len(st), o['phase_shift']))
+        res = O.wsegan_step(G, D, clean, noisy, z, rolls, perm, fx['names'], st,
+                            l1_weight=o['l1_weight'], pow_weight=o['pow_weight'], lr=o['g_lr'],
+                            n_fft=o['n_fft'], g_sq=g_sq, d_sq=d_sq, squares=squares)
+        G, D, g_sq, d_sq = res['G'], res['D'], res['g_sq'], res['d_sq']
+    for k, v in fx['G_final'].items():
+        assert (G[k] - v).abs().max().item() < 5e-5, k
     for k, v in fx['D_final'].items():
         if not torch.is_floating_point(v) or k.endswith(('conv.bias', 'norm.running_mean')):
             continue
