@@ -36,6 +36,7 @@ SIGNATURES = {
     'segan_packed_bf_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     'segan_pack_weights_bf': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     'segan_corr_scratch_bytes': (c_size_t, []),
+    'segan_bf16_scratch_bytes': (c_size_t, [c_int] * 9),
     'segan_debug_last_corr': (None, [POINTER(c_int)]),
     'segan_debug_last_wgrad': (None, [POINTER(c_int)]),
     'segan_conv1d_fwd': (c_int, [_SRC, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,

@@ -1141,6 +1141,36 @@ static void set_scratch(CorrArgs& a, void* scratch, size_t scratch_bytes) {
 // ====================================================================================
 // C ABI: forward and data-gradient entry points
 // ====================================================================================
+// scratch of the bf16 / bf16x3 forms of the four entry points below: the packed activation
+// operand.  op: 0 conv forward, 1 conv data gradient, 2 deconv forward, 3 deconv data gradient;
+// (N, M) as in the entry point's weight [M, N, K] convention, L = length of the HIGH-rate side.
+extern "C" size_t segan_bf16_scratch_bytes(int op, int B, int N, int M, int L, int K, int S, int pad,
+                                           int planes) {
+  if (!stride_ok(S) || B <= 0 || N <= 0 || M <= 0 || L <= 0 || L % S != 0 || planes < 1 || planes > 3)
+    return 0;
+  const int U = 32 / S, Ls = L / S;
+  // + the stream-K slabs (as segan_corr_scratch_bytes) behind the packed operand
+  const size_t slabs = 256 + (size_t)1024 * 2 * 128 * 128 * sizeof(float);
+  switch (op) {
+    case 0: return slabs + segan_corr_bf2_scratch_bytes(B, N * S, Ls, U - 1, planes);
+    case 3: return slabs + segan_corr_bf2_scratch_bytes(B, N * S, Ls, U - 1, planes);
+    case 2: {
+      int cmin = 1 << 30, cmax = 0;
+      for (int r = 0; r < S; ++r) {
+        const int c = (r + pad) / S;
+        cmin = c < cmin ? c : cmin;
+        cmax = c > cmax ? c : cmax;
+      }
+      return slabs + segan_corr_bf2_scratch_bytes(B, M, Ls, U - 1 + (cmax - cmin), planes);
+    }
+    case 1: {
+      const int padR = K - S - pad > 0 ? K - S - pad : 0;
+      return slabs + segan_corr_bf2_scratch_bytes(B, M, (L + pad + padR - 1) / S + 1, U - 1, planes);
+    }
+  }
+  return 0;
+}
+
 extern "C" size_t segan_corr_scratch_bytes(void) {
   // 256 CUs x 4 resident workgroups x 2 slabs of a 128 x 128 fp32 tile
   return (size_t)1024 * 2 * 128 * 128 * sizeof(float);
@@ -1174,7 +1204,12 @@ extern "C" int segan_conv1d_fwd(const segan_src* x, const void* wf, const float*
   a.NP = 1; a.Nout = 0;
   a.OC0 = M; a.OC1 = 0; a.Lout = a.Tcols; a.act = SEGAN_ACT_NONE;
   a.out0_elems = (size_t)B * M * a.Tcols;
-  if (precision) return segan_corr_bf_f(a, U, wf, precision, (hipStream_t)stream);
+  if (precision) {
+    CorrArgs a2 = a;
+    const int e = segan_corr_bf2_f(a2, U, wf, precision, scratch, scratch_bytes, (hipStream_t)stream);
+    if (e != SEGAN_EUNSUPPORTED) return e;
+    return segan_corr_bf_f(a, U, wf, precision, (hipStream_t)stream);
+  }
   if (N <= 2) return segan_launch_fsmall(a, M, N, S, (hipStream_t)stream);
   set_scratch(a, scratch, scratch_bytes);
   return launch_corr<true, false>(a, U, (hipStream_t)stream);
@@ -1207,7 +1242,12 @@ extern "C" int segan_deconv1d_dgrad(const float* dy, const void* wf, float* dx0,
   a.Lout = Ls; a.act = SEGAN_ACT_NONE;
   a.out0_elems = (size_t)B * a.OC0 * Ls;
   a.out1_elems = (size_t)B * a.OC1 * Ls;
-  if (precision) return segan_corr_bf_f(a, U, wf, precision, (hipStream_t)stream);
+  if (precision) {
+    CorrArgs a2 = a;
+    const int e = segan_corr_bf2_f(a2, U, wf, precision, scratch, scratch_bytes, (hipStream_t)stream);
+    if (e != SEGAN_EUNSUPPORTED) return e;
+    return segan_corr_bf_f(a, U, wf, precision, (hipStream_t)stream);
+  }
   set_scratch(a, scratch, scratch_bytes);
   return launch_corr<true, false>(a, U, (hipStream_t)stream);
 }
@@ -1247,8 +1287,12 @@ extern "C" int segan_deconv1d_fwd(const segan_src* x, const void* wt, const floa
   a.o_padL = 0; a.o_roll = 0; a.o_padR = 0;
   a.out0_elems = (size_t)B * N * S * Ls;
   if (w && N <= 2) return segan_launch_tsmall(a, w, K, M, N, S, pad, (hipStream_t)stream);
-  if (precision && act == SEGAN_ACT_NONE)
+  if (precision && act == SEGAN_ACT_NONE) {
+    CorrArgs a2 = a;
+    const int e = segan_corr_bf2_t(a2, U, wt, precision, scratch, scratch_bytes, (hipStream_t)stream);
+    if (e != SEGAN_EUNSUPPORTED) return e;
     return segan_corr_bf_t(a, U, wt, precision, (hipStream_t)stream);
+  }
   SEGAN_REQUIRE(precision == 0, "deconv1d_fwd: tanh epilogue only on the fp32 path");
   set_scratch(a, scratch, scratch_bytes);
   return launch_corr<false, true>(a, U, (hipStream_t)stream);
@@ -1291,9 +1335,16 @@ extern "C" int segan_conv1d_dgrad(const float* da, const void* wt, const float* 
   a.out0_elems = (size_t)B * N * L;
   a.halo_elems = (size_t)B * N * (padL + padR);
   set_scratch(a, scratch, scratch_bytes);
-  int e = (w && N <= 2) ? segan_launch_tsmall(a, w, K, M, N, S, 0, st)
-          : precision   ? segan_corr_bf_t(a, U, wt, precision, st)
-                        : launch_corr<false, true>(a, U, st);
+  int e;
+  if (w && N <= 2) {
+    e = segan_launch_tsmall(a, w, K, M, N, S, 0, st);
+  } else if (precision) {
+    CorrArgs a2 = a;
+    e = segan_corr_bf2_t(a2, U, wt, precision, scratch, scratch_bytes, st);
+    if (e == SEGAN_EUNSUPPORTED) e = segan_corr_bf_t(a, U, wt, precision, st);
+  } else {
+    e = launch_corr<false, true>(a, U, st);
+  }
   if (e) return e;
   if (padL + padR > 0) {
     const int rows = B * N;

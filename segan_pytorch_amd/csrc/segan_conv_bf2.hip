@@ -1,0 +1,804 @@
+// segan_conv_bf2.hip — round-3 form of the F and T contractions on the bf16 matrix cores
+// (v_mfma_f32_32x32x16_bf16): BOTH operands reach LDS by LDS-DMA, nothing is converted, masked or
+// transformed inside the hot loop.
+//
+// Why: a bf16 MFMA retires 16x the products of the fp32 one in half its cycles, so staging work
+// that costs the fp32 kernels 0.5 VALU per MFMA would cost these 16 per MFMA.  Round 1's
+// corr_bf_kernel converted fp32 -> bf16 while staging (8-12 VALU, 0.6 VMEM, 0.3 ds_write_b128 per
+// MFMA: 0.15-0.24 of the bf16 peak).  Here the activation operand is converted ONCE per call by
+// act_pack_kernel — transform (BatchNorm scale / shift, PReLU slope, alpha), both torch.cat
+// segments, reflect / zero padding, the discriminator's roll, the polyphase split and the halo
+// are all applied there — into the exact piece order the tile wants:
+//
+//   P[plane][b][g][j][8]   bf16, g = group of 8 virtual channels, j = window position
+//                          F form: virtual channel (n, r), value xpad[n, S*(j + win_start) + r]
+//                          T form: virtual channel m,      value x[m, j + win_start] (0 outside)
+//
+// so a tile's operand for one 16-channel group is, per half g, a run of consecutive 16-byte
+// pieces per sample: one buffer_load_dwordx4 ... lds per 64 positions, per-lane offsets constant
+// for the whole tile, the channel group in the scalar offset.  The packed weights were already
+// stored in tile order (segan_pack_weights_bf) and stream the same way.  Per stage of TU taps a
+// wave issues 4 (weights) + ~0.4 (activations) DMA instructions, TU * (NI + NJ) ds_read_b128 and
+// TU * NI * NJ MFMAs — and nothing else.
+//
+// The packing pass is HBM-bound (4 B read, 2 B written per element and plane, coalesced both
+// ways).  Tile geometry, stream-K hybrid and epilogues are those of corr_bf_kernel.
+#include "segan_conv_shared.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split3b(float x, __bf16& p1, __bf16& p2, __bf16& p3) {
+  p1 = (__bf16)x;
+  const float r1 = x - (float)p1;
+  p2 = (__bf16)r1;
+  const float r2 = r1 - (float)p2;
+  p3 = (__bf16)r2;
+}
+
+// ====================================================================================
+// activation packing
+// ====================================================================================
+struct PackArgs {
+  segan_src in;
+  __bf16* out;
+  size_t plane_elems;     // elements between planes
+  int B, Cv, G, Qp;       // virtual channels, groups of 8 (even), positions per row
+  int Lin, padL, mode, roll, win_start;
+  int identity;
+};
+
+// one thread = one 16-byte piece (b, g, j); lanes run along j (coalesced reads of each of the
+// piece's rows, coalesced 16-byte writes)
+template <int S, bool IN_HI, int NPL>
+__global__ __launch_bounds__(256) void act_pack_kernel(const PackArgs a) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int g = blockIdx.y, b = blockIdx.z;
+  if (j >= a.Qp) return;
+  const int wq = j + a.win_start;
+  bf16x8 pl[3];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int cv = 8 * g + e;
+    const int n = IN_HI ? cv / S : cv;
+    const int r = IN_HI ? cv % S : 0;
+    int idx;
+    if (IN_HI) idx = segan_hi_index(S * wq + r, a.Lin, a.padL, a.mode, a.roll);
+    else idx = (wq >= 0 && wq < a.Lin) ? wq : -1;
+    const bool ok = cv < a.Cv && idx >= 0;
+    float v = 0.0f;
+    if (ok) {
+      v = segan_src_row(a.in, b, n, a.Lin)[idx];
+      if (!a.identity) {
+        const ChanXf xf = segan_chan_xf(a.in, n);
+        v = segan_apply_xf(xf, v);
+      }
+    }
+    __bf16 p1, p2, p3;
+    split3b(v, p1, p2, p3);
+    pl[0][e] = p1; pl[1][e] = p2; pl[2][e] = p3;
+  }
+  const size_t piece = ((size_t)b * a.G + g) * a.Qp + j;
+#pragma unroll
+  for (int p = 0; p < NPL; ++p)
+    *reinterpret_cast<u32x4*>(a.out + p * a.plane_elems + piece * 8) = __builtin_bit_cast(u32x4, pl[p]);
+}
+
+// ---- tile epilogue: bias, store (shared by the contraction kernel and the stream-K fix-up) ----
+template <int MB, int NB, int WM, int U, bool OUT_HI>
+__device__ __forceinline__ void bf2_store_tile(const CorrArgs& a,
+                                               const f32x16 (&acc)[MB / (32 * WM)][NB / (32 * (4 / WM))],
+                                               int m0, int n0, int wm, int h,
+                                               const int (&col_b)[NB / (32 * (4 / WM))],
+                                               const int (&col_t)[NB / (32 * (4 / WM))]) {
+  constexpr int S = 32 / U;
+  constexpr int WN = 4 / WM;
+  constexpr int NI = MB / (32 * WM);
+  constexpr int NJ = NB / (32 * WN);
+  constexpr int NPT = MB / S;
+  constexpr bool add_bias = true;
+  // ---- epilogue ----
+  // A bf16 tile spends 16x fewer matrix-pipe cycles per output element than an fp32 one, so the
+  // generic epilogue below (64-bit address arithmetic, row / destination tests and a bias load
+  // per element: ~30 VALU per stored value) cost as much as the tile's whole contraction.  Full
+  // interior tiles — all rows valid and in one destination, plain stores — take the fast form:
+  // buffer stores whose per-lane offsets are computed once per column (masked columns carry an
+  // out-of-range offset: the store is dropped), the row inside the tile goes through the scalar
+  // offset, no VALU per element.
+  if (!OUT_HI) {
+    float* fdst = m0 < a.OC0 ? a.out0 : a.out1;
+    const int foc = m0 < a.OC0 ? a.OC0 : a.OC1;
+    const int foch = m0 < a.OC0 ? m0 : m0 - a.OC0;
+    const long fbytes = (long)a.B * foc * a.Lout * 4;
+    const bool fast = a.act == SEGAN_ACT_NONE && m0 + MB <= a.Rvalid &&
+                      (m0 + MB <= a.OC0 || m0 >= a.OC0) && fdst != nullptr && fbytes < 0x7fffffffL;
+    if (fast) {
+      const __amdgpu_buffer_rsrc_t ors =
+          __builtin_amdgcn_make_buffer_rsrc(fdst, 0, (int)fbytes, 0x00020000);
+      int ovo[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        ovo[j] = col_b[j] < 0 ? (int)0x80000000u
+                              : ((col_b[j] * foc + foch + 32 * wm * NI + 4 * h) * a.Lout + col_t[j]) * 4;
+      const int rowstep = a.Lout * 4;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int rl = 32 * i + (e & 3) + 8 * (e >> 2);
+          float bs = 0.0f;
+          if (a.bias && add_bias) bs = a.bias[m0 + 32 * wm * NI + 4 * h + rl];
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[i][j][e] + bs), ors,
+                                                  ovo[j], rl * rowstep, 0);
+        }
+      }
+      return;
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + 32 * (wm * NI + i) + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (row >= a.Rvalid) continue;
+        float* dst;
+        int oc, och;
+        if (row < a.OC0) { dst = a.out0; oc = a.OC0; och = row; }
+        else { dst = a.out1; oc = a.OC1; och = row - a.OC0; }
+        if (dst == nullptr) continue;
+        const float bs = (a.bias && add_bias) ? a.bias[row] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          if (col_b[j] < 0) continue;
+          float v = acc[i][j][e] + bs;
+          float* o = dst + ((size_t)col_b[j] * oc + och) * (size_t)a.Lout + col_t[j];
+          if (a.act == SEGAN_ACT_TANH) v = tanhf(v);
+          *o = v;
+        }
+      }
+    }
+  } else {
+    constexpr bool QUAD = (S == 4 && WM == 1 && NI == 4);
+    const long obytes = (long)a.B * a.Nout * a.Lout * 4;
+    if (QUAD && a.act == SEGAN_ACT_NONE && a.o_padL == 0 && a.o_roll == 0 &&
+        a.halo == nullptr && n0 + NPT <= a.Nout && a.Lout == 4 * a.Tcols && obytes < 0x7fffffffL) {
+      // deconv forward: a lane's four phase accumulators are four consecutive output samples
+      const __amdgpu_buffer_rsrc_t ors =
+          __builtin_amdgcn_make_buffer_rsrc(a.out0, 0, (int)obytes, 0x00020000);
+      int ovo[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        ovo[j] = col_b[j] < 0 ? (int)0x80000000u
+                              : ((col_b[j] * a.Nout + n0 + 4 * h) * a.Lout + 4 * col_t[j]) * 4;
+      const int rowstep = a.Lout * 4;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int nl = (e & 3) + 8 * (e >> 2);
+        float bs = 0.0f;
+        if (a.bias && add_bias) bs = a.bias[n0 + 4 * h + nl];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const u32x4 o = {__builtin_bit_cast(unsigned, acc[0][j][e] + bs),
+                           __builtin_bit_cast(unsigned, acc[1][j][e] + bs),
+                           __builtin_bit_cast(unsigned, acc[2][j][e] + bs),
+                           __builtin_bit_cast(unsigned, acc[3][j][e] + bs)};
+          __builtin_amdgcn_raw_buffer_store_b128(o, ors, ovo[j], nl * rowstep, 0);
+        }
+      }
+      return;
+    }
+    const bool qfast = obytes < 0x7fffffffL;     // 32-bit byte offsets reach every output element
+    const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(
+        a.out0, 0, (int)(qfast ? obytes : 0), 0x00020000);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        if (col_b[j] < 0) continue;
+        const int q = col_t[j];
+        if (QUAD) {
+          const int n = n0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (n >= a.Nout) continue;
+          const float bs = (a.bias && add_bias) ? a.bias[n] : 0.0f;
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[r] = acc[r][j][e] + bs;
+            if (a.act == SEGAN_ACT_TANH) v[r] = tanhf(v[r]);
+          }
+          const size_t rowoff = (size_t)col_b[j] * a.Nout + n;
+          const int i0 = 4 * q - a.o_padL;
+          if (i0 >= 0 && i0 + 3 < a.Lout) {
+            // interior of the row (all but ~8 of its positions): the four phases are four
+            // consecutive samples, also after the roll unless they straddle its wrap point
+            int ib = i0 - a.o_roll;
+            if (ib < 0) ib += a.Lout;
+            if (ib >= a.Lout) ib -= a.Lout;
+            if (ib + 3 < a.Lout) {
+              const u32x4 o = {__builtin_bit_cast(unsigned, v[0]), __builtin_bit_cast(unsigned, v[1]),
+                               __builtin_bit_cast(unsigned, v[2]), __builtin_bit_cast(unsigned, v[3])};
+              if (qfast)
+                __builtin_amdgcn_raw_buffer_store_b128(o, qrs, (int)((rowoff * a.Lout + ib) * 4), 0, 0);
+              else
+                *reinterpret_cast<u32x4*>(a.out0 + rowoff * (size_t)a.Lout + ib) = o;
+              continue;
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int P = 4 * q + r;
+            int ii = P - a.o_padL;
+            if (ii >= 0 && ii < a.Lout) {
+              if (a.o_roll != 0) {
+                ii -= a.o_roll;
+                if (ii < 0) ii += a.Lout;
+                if (ii >= a.Lout) ii -= a.Lout;
+              }
+              float* o = a.out0 + rowoff * (size_t)a.Lout + ii;
+              *o = v[r];
+            } else if (a.halo != nullptr) {
+              const int hl = a.o_padL + a.o_padR;
+              float* o = nullptr;
+              if (ii < 0) o = a.halo + rowoff * hl + P;
+              else if (ii - a.Lout < a.o_padR) o = a.halo + rowoff * hl + a.o_padL + (ii - a.Lout);
+              if (o) { *o = v[r]; }
+            }
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < NI; ++i) {
+            const int rloc = 32 * (wm * NI + i) + (e & 3) + 8 * (e >> 2) + 4 * h;
+            const int r = rloc / NPT;
+            const int n = n0 + rloc % NPT;
+            if (n >= a.Nout) continue;
+            float v = acc[i][j][e] + ((a.bias && add_bias) ? a.bias[n] : 0.0f);
+            if (a.act == SEGAN_ACT_TANH) v = tanhf(v);
+            const int P = S * q + r;
+            int ii = P - a.o_padL;
+            const size_t rowoff = (size_t)col_b[j] * a.Nout + n;
+            if (ii >= 0 && ii < a.Lout) {
+              if (a.o_roll != 0) {
+                ii -= a.o_roll;
+                if (ii < 0) ii += a.Lout;
+                if (ii >= a.Lout) ii -= a.Lout;
+              }
+              float* o = a.out0 + rowoff * (size_t)a.Lout + ii;
+              *o = v;
+            } else if (a.halo != nullptr) {
+              const int hl = a.o_padL + a.o_padR;
+              float* o = nullptr;
+              if (ii < 0) o = a.halo + rowoff * hl + P;
+              else if (ii - a.Lout < a.o_padR) o = a.halo + rowoff * hl + a.o_padL + (ii - a.Lout);
+              if (o) { *o = v; }
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// accumulator slab of a stream-K piece: [NI*NJ*4][256] float4, thread-minor
+template <int NI, int NJ>
+__device__ __forceinline__ void bf2_slab_store(float* slab, const f32x16 (&acc)[NI][NJ], int tid) {
+  f32x4* s4 = reinterpret_cast<f32x4*>(slab);
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2],
+                         acc[i][j][4 * q + 3]};
+        s4[((i * NJ + j) * 4 + q) * 256 + tid] = v;
+      }
+}
+
+// ====================================================================================
+// contraction
+// ====================================================================================
+struct Bf2Extra {
+  const __bf16* wp3;    // packed weight planes
+  long w_plane;         // elements between weight planes
+  const __bf16* act;    // packed activation planes
+  long a_plane_bytes;   // bytes between activation planes
+  int ngroups;          // channel groups of 16
+  int G, Qp;            // groups of 8 per sample (= 2*ngroups), positions per row
+  int nld;              // DMA instructions per half of the activation tile (RLs' / 64)
+  int dbg;              // experiments (SEGAN_BF2_DBG): 1 = no DMA after a tile's first stage, 2 = no MFMA loop
+};
+
+template <int MB, int NB, int WM, int U, bool OUT_HI, int SHIFTMASK, int NPL, int TU>
+__global__ __launch_bounds__(256, (NPL == 1 && NB == 128) ? 3 : 2) void corr_bf2_kernel(const CorrArgs a, const Bf2Extra x) {
+  constexpr int S = 32 / U;
+  constexpr int WN = 4 / WM;
+  constexpr int NI = MB / (32 * WM);
+  constexpr int NJ = NB / (32 * WN);
+  constexpr int NPT = MB / S;
+  constexpr int TCH = U / TU;          // weight stages per channel group
+  constexpr int NSH = SHIFTMASK ? 2 : 1;
+  constexpr int KI = 3;                // activation DMA instructions per wave, plane and group: RLs' <= 6 * 64
+  static_assert(MB == 128, "weight tile: 2 DMA instructions per (tap, half)");
+  static_assert(!OUT_HI || WM == 1, "T form: one wave holds all phases");
+  constexpr int WPIECES = NPL * TU * 2 * MB;       // per buffer
+  constexpr int WINS = NPL * TU * 2 * 2;           // DMA instructions per weight stage
+  static_assert(WINS % 4 == 0, "weight instructions divide among the 4 waves");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int RLs = a.RLs;                 // padded to a multiple of 64
+  u32x4* Wl0 = reinterpret_cast<u32x4*>(smem_raw);       // [2][NPL][TU][2][MB]
+  u32x4* Il0 = Wl0 + 2 * WPIECES;                          // [2][NPL][2][RLs]
+  const int IPIECES = NPL * 2 * RLs;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, h = lane >> 5;
+
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<__bf16*>(x.wp3), 0, 0x7fffffff, 0x00020000);
+
+  const int nst = x.ngroups * TCH;     // weight stages per tile
+  int tileA = blockIdx.x;
+  long unit = (long)blockIdx.x * a.sk_units;
+  const long unit_end = min(unit + (long)a.sk_units, a.sk_total);
+  const int first_sk_tile = (int)(unit / nst);
+  for (;;) {
+  int tile, c0, c1;
+  if (tileA < a.sk_nfull) {
+    tile = tileA; c0 = 0; c1 = nst;
+    tileA += gridDim.x;
+  } else if (unit < unit_end) {
+    const int t = (int)(unit / nst);
+    c0 = (int)(unit - (long)t * nst);
+    c1 = min(nst, c0 + (int)(unit_end - unit));
+    unit += c1 - c0;
+    tile = a.sk_nfull + t;
+  } else {
+    break;
+  }
+  const bool partial = (c0 != 0) || (c1 != nst);
+  const int rowtile = a.rt0 + tile / a.ncoltiles;
+  const int coltile = tile % a.ncoltiles;
+  const int m0 = rowtile * MB;
+  const int n0 = rowtile * NPT;
+  if (!OUT_HI) {
+    if (a.out0 == nullptr && m0 + MB <= a.OC0) continue;
+    if (a.out1 == nullptr && m0 >= a.OC0) continue;
+  }
+  const ColTile ct = make_coltile(coltile * NB, a.Tcols, NB);
+
+  // ---- activation DMA: descriptor rebased to the tile's first sample, per-lane offsets of the
+  // positions lane + 64*i (constant for the tile; the channel group goes through the scalar offset)
+  const long sample_bytes = (long)x.G * x.Qp * 16;
+  const long left = (long)(a.B - ct.b0) * sample_bytes;
+  const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(reinterpret_cast<const char*>(x.act)) + (size_t)ct.b0 * sample_bytes, 0,
+      (int)(left + 2 * x.a_plane_bytes < 0x7fffffffL ? left + 2 * x.a_plane_bytes : 0x7fffffffL), 0x00020000);
+  // this wave stages half g = wave & 1, position blocks (wave >> 1) + 2k (static register indices)
+  const int ig = wave & 1, ib = wave >> 1;
+  int avo[KI];
+#pragma unroll
+  for (int k = 0; k < KI; ++k) {
+    const int j = lane + 64 * (ib + 2 * k);
+    avo[k] = (int)0x80000000u;          // out of range: the DMA writes zeros
+    if (ib + 2 * k < x.nld && j < a.RLv) {
+      int s, tau;
+      lds_pos_decode(ct, j, a.Tcols, a.H, s, tau);
+      if (ct.b0 + s < a.B) avo[k] = (int)(((long)s * x.G * x.Qp + tau) * 16);
+    }
+  }
+  // ---- weight DMA: per-lane byte offsets of rows 64*i + lane of the tile ----
+  int wvo[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int wr = 64 * i + lane;
+    const int wgrow = OUT_HI ? (wr / NPT) * a.NP + n0 + wr % NPT : m0 + wr;
+    wvo[i] = wgrow * 16;
+  }
+
+  // ---- per-lane operand offsets (in 16-B pieces) ----
+  int arow[NI], boff[NJ];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) arow[i] = 32 * (wm * NI + i) + l31;
+  int col_b[NJ], col_t[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int cl = wn * (NB / WN) + 32 * j + l31;
+    const int col = ct.col0 + cl;
+    if (col < a.Ctot) {
+      const int b = col / a.Tcols;
+      col_b[j] = b;
+      col_t[j] = col - b * a.Tcols;
+      boff[j] = cl + (b - ct.b0) * a.H;
+    } else {
+      col_b[j] = -1;
+      col_t[j] = 0;
+      boff[j] = 0;
+    }
+  }
+
+  f32x16 acc[NI][NJ];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+  // weight stage `st` -> buffer `buf`: instruction q = wave + 4*k covers (p, tu, g, i)
+  auto dma_w = [&](int st, int buf) __attribute__((always_inline)) {
+    u32x4* Wl = Wl0 + buf * WPIECES;
+#pragma unroll
+    for (int k = 0; k < WINS / 4; ++k) {
+      const int q = wave + 4 * k;
+      const int i = q & 1, g = (q >> 1) & 1, tu = (q >> 2) % TU, p = q / (4 * TU);
+      const long soff = (long)p * x.w_plane * 2 + ((long)((st * TU + tu) * 2 + g) * a.RP) * 16;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          wrs, (__attribute__((address_space(3))) void*)(Wl + ((p * TU + tu) * 2 + g) * MB + 64 * i),
+          16, wvo[i], (int)soff, 0, 0);
+    }
+  };
+  // activation tile of channel group cg -> buffer ibuf: this wave's half, its position blocks
+  auto dma_i = [&](int cg, int ibuf) __attribute__((always_inline)) {
+    u32x4* Il = Il0 + ibuf * IPIECES;
+#pragma unroll
+    for (int p = 0; p < NPL; ++p) {
+      const long soff = (long)p * x.a_plane_bytes + ((long)(2 * cg + ig) * x.Qp) * 16;
+#pragma unroll
+      for (int k = 0; k < KI; ++k) {
+        if (ib + 2 * k < x.nld)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(
+              ars, (__attribute__((address_space(3))) void*)(Il + (p * 2 + ig) * RLs + 64 * (ib + 2 * k)),
+              16, avo[k], (int)soff, 0, 0);
+      }
+    }
+  };
+
+  {
+    const int cg0 = c0 / TCH;
+    dma_i(cg0, cg0 & 1);
+    dma_w(c0, 0);
+    __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0)
+    __syncthreads();
+  }
+  for (int st = c0; st < c1; ++st) {
+    const int buf = (st - c0) & 1;
+    const int cg = st / TCH, tc = st - cg * TCH;
+    const bool more = st + 1 < c1;
+    if (more && !(x.dbg & 1)) {
+      dma_w(st + 1, buf ^ 1);
+      if ((st + 1) % TCH == 0) dma_i(cg + 1, (cg + 1) & 1);
+    }
+    const u32x4* Wl = Wl0 + buf * WPIECES;
+    const u32x4* Il = Il0 + (cg & 1) * IPIECES;
+    if (!(x.dbg & 2))
+#pragma unroll
+    for (int tu = 0; tu < TU; ++tu) {
+      const int u = tc * TU + tu;
+      bf16x8 af[NI][NPL], bf[NSH][NJ][NPL];
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int p = 0; p < NPL; ++p)
+          af[i][p] = __builtin_bit_cast(bf16x8, Wl[((p * TU + tu) * 2 + h) * MB + arow[i]]);
+#pragma unroll
+      for (int sh = 0; sh < NSH; ++sh)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int p = 0; p < NPL; ++p)
+            bf[sh][j][p] = __builtin_bit_cast(bf16x8, Il[(p * 2 + h) * RLs + boff[j] + u + sh]);
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int sh = SHIFTMASK ? ((SHIFTMASK >> ((32 * i) / NPT)) & 1) : 0;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          if (NPL == 1) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[sh][j][0], acc[i][j], 0, 0, 0);
+          } else {
+            // smallest partial products first
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[sh][j][1], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[sh][j][2], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[sh][j][0], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[sh][j][1], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[sh][j][0], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[sh][j][0], acc[i][j], 0, 0, 0);
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0f70);      // the next stage's DMA has landed
+    __syncthreads();
+  }
+
+  if (partial)
+    bf2_slab_store<NI, NJ>(a.sk_ws + (size_t)(blockIdx.x * 2 + (tile - a.sk_nfull - first_sk_tile)) * (MB * NB), acc, tid);
+  else
+    bf2_store_tile<MB, NB, WM, U, OUT_HI>(a, acc, m0, n0, wm, h, col_b, col_t);
+  }  // tile loop
+}
+
+// Stream-K second pass (as corr_fixup_kernel of the fp32 path): one workgroup per cut tile adds
+// the slabs of its pieces in stage order — a fixed order, no atomics, no zero-filled outputs —
+// and stores the tile.
+template <int MB, int NB, int WM, int U, bool OUT_HI>
+__global__ __launch_bounds__(256) void bf2_fixup_kernel(const CorrArgs a, int nst) {
+  constexpr int S = 32 / U;
+  constexpr int WN = 4 / WM;
+  constexpr int NI = MB / (32 * WM);
+  constexpr int NJ = NB / (32 * WN);
+  constexpr int NPT = MB / S;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int t = blockIdx.x;
+  const long u0 = (long)t * nst, u1 = u0 + nst - 1;
+  const int g_first = (int)(u0 / a.sk_units), g_last = (int)(u1 / a.sk_units);
+  if (g_first == g_last) return;          // held whole by one workgroup: already stored
+  const int tile = a.sk_nfull + t;
+  const int rowtile = a.rt0 + tile / a.ncoltiles;
+  const int coltile = tile % a.ncoltiles;
+  const int m0 = rowtile * MB, n0 = rowtile * NPT;
+  if (!OUT_HI) {
+    if (a.out0 == nullptr && m0 + MB <= a.OC0) return;
+    if (a.out1 == nullptr && m0 >= a.OC0) return;
+  }
+  const ColTile ct = make_coltile(coltile * NB, a.Tcols, NB);
+  int col_b[NJ], col_t[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int cl = wn * (NB / WN) + 32 * j + l31;
+    const int col = ct.col0 + cl;
+    if (col < a.Ctot) {
+      col_b[j] = col / a.Tcols;
+      col_t[j] = col - col_b[j] * a.Tcols;
+    } else {
+      col_b[j] = -1;
+      col_t[j] = 0;
+    }
+  }
+  f32x16 acc[NI][NJ];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+  constexpr int NV = NI * NJ * 4;
+  for (int g = g_first; g <= g_last; ++g) {
+    const int piece = t - (int)(((long)g * a.sk_units) / nst);
+    const f32x4* s4 = reinterpret_cast<const f32x4*>(a.sk_ws + (size_t)(g * 2 + piece) * (MB * NB));
+    f32x4 v[NV];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) v[q] = s4[q * 256 + tid];
+#pragma unroll
+    for (int q = 0; q < NV; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[q / (NJ * 4)][(q / 4) % NJ][4 * (q % 4) + e] += v[q][e];
+  }
+  bf2_store_tile<MB, NB, WM, U, OUT_HI>(a, acc, m0, n0, wm, h, col_b, col_t);
+}
+
+// ====================================================================================
+// launchers
+// ====================================================================================
+static inline int bf2_groups16(int Cv) { return ceil_div(Cv, 16); }
+
+// bytes of the packed activation operand of a launch (what the caller's scratch must hold)
+size_t segan_corr_bf2_scratch_bytes(int B, int Cv, int Tcols, int H, int planes) {
+  return (size_t)planes * B * (2 * bf2_groups16(Cv)) * (size_t)(Tcols + H) * 16;
+}
+
+template <int S, bool IN_HI>
+static int launch_pack(const PackArgs& pa, int planes, hipStream_t st) {
+  const dim3 grid((unsigned)ceil_div(pa.Qp, 256), (unsigned)pa.G, (unsigned)pa.B);
+  if (planes == 3) hipLaunchKernelGGL((act_pack_kernel<S, IN_HI, 3>), grid, dim3(256), 0, st, pa);
+  else hipLaunchKernelGGL((act_pack_kernel<S, IN_HI, 1>), grid, dim3(256), 0, st, pa);
+  return segan_check_launch("act_pack_kernel");
+}
+
+template <int NB, int WM, int U, bool IN_HI, bool OUT_HI, int SHIFTMASK, int NPL>
+static int launch_bf2(CorrArgs a, Bf2Extra x, hipStream_t st) {
+  constexpr int MB = 128;
+  constexpr int S = 32 / U;
+  constexpr int TU = (NPL == 3) ? 1 : (U >= 8 ? 4 : U);   // bf16x3: 3 planes per tap fill the LDS
+  constexpr int TCH = U / TU;
+  a.RLv = a.RLs;
+  a.RLs = round_up(a.RLs, 64);
+  x.nld = a.RLs / 64;
+  if (x.nld > 6) {
+    segan_set_error("corr_bf2: window of %d positions too long", a.RLv);
+    return SEGAN_EUNSUPPORTED;
+  }
+  const size_t lds = (size_t)(2 * NPL * TU * 2 * MB + 2 * NPL * 2 * a.RLs) * 16;
+  auto kern = corr_bf2_kernel<MB, NB, WM, U, OUT_HI, SHIFTMASK, NPL, TU>;
+  static bool attr_done[16];
+  static int occ[16];
+  static size_t occ_lds[16];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  dev &= 15;
+  if (!attr_done[dev]) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done[dev] = true;
+  }
+  const int nrowtiles = OUT_HI ? a.NP / (MB / S) : ceil_div(a.Rvalid, MB);
+  a.rt0 = (!OUT_HI && a.out0 == nullptr) ? a.OC0 / MB : 0;
+  const int ntiles = (nrowtiles - a.rt0) * a.ncoltiles;
+  const int nst = x.ngroups * TCH;
+  a.sk_nfull = ntiles;
+  a.sk_units = 0;
+  a.sk_total = 0;
+  unsigned grid = (unsigned)ntiles;
+  const double classic_eff = (double)ntiles / (256.0 * ceil_div(ntiles, 256));
+  static int sk_on = -1;
+  if (sk_on < 0) {
+    const char* e = getenv("SEGAN_BF2_SK");
+    sk_on = e ? atoi(e) : 1;
+  }
+  if (sk_on && a.act == SEGAN_ACT_NONE && ntiles >= 64 && nst >= 8 && classic_eff < 0.97) {
+    if (occ[dev] == 0 || occ_lds[dev] != lds) {
+      int nb = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), 256,
+                                                       lds) != hipSuccess || nb < 1)
+        nb = 1;
+      occ[dev] = nb > 4 ? 4 : nb;
+      occ_lds[dev] = lds;
+    }
+    const int G = 256 * occ[dev];
+    const int rem = ntiles - (ntiles / G) * G;
+    if (rem > 0 && a.sk_ws != nullptr && a.sk_ws_floats >= (size_t)G * 2 * MB * NB) {
+      a.sk_nfull = ntiles - rem;
+      a.sk_total = (long)rem * nst;
+      a.sk_units = (int)((a.sk_total + G - 1) / G);
+      grid = (unsigned)G;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a, x);
+  if (int e = segan_check_launch("corr_bf2_kernel")) return e;
+  if (a.sk_total > 0) {
+    hipLaunchKernelGGL((bf2_fixup_kernel<MB, NB, WM, U, OUT_HI>), dim3(ntiles - a.sk_nfull), dim3(256),
+                       0, st, a, nst);
+    return segan_check_launch("bf2_fixup_kernel");
+  }
+  return SEGAN_OK;
+}
+
+// shared front end: geometry, packing pass, extra arguments.  Returns SEGAN_EUNSUPPORTED (the
+// caller then runs round 1's kernel) when the scratch is missing or too small.
+// column-tile width: 256 halves the weight bytes streamed per MFMA (the L2 -> LDS stream is what
+// bounds these kernels), 128 keeps enough tiles in flight on the short layers
+static int bf2_pick_nb(const CorrArgs& a, int MB_rows) {
+  // measured (scripts/bench_layers.py, SEGAN_BF2_NB): 128-column tiles at three workgroups per CU
+  // beat 256-column tiles at two on every SEGAN+ layer; the wide variant stays selectable
+  (void)a; (void)MB_rows;
+  return 128;
+}
+
+template <bool IN_HI>
+static int bf2_prepare(CorrArgs& a, int U, int planes, void* scratch, size_t scratch_bytes,
+                       Bf2Extra& x, hipStream_t st, int NB) {
+  const int S = 32 / U;
+  a.ncoltiles = ceil_div(a.Ctot, NB);
+  a.RLs = NB + samples_per_tile(a.Tcols, NB) * a.H;
+  const size_t need = segan_corr_bf2_scratch_bytes(a.B, a.Cv, a.Tcols, a.H, planes);
+  if (scratch == nullptr || scratch_bytes < need) {
+    segan_set_error("corr_bf2: scratch of %zu bytes needed", need);
+    return SEGAN_EUNSUPPORTED;
+  }
+  // what follows the packed operand holds the stream-K slabs
+  const size_t pk = (need + 255) & ~(size_t)255;
+  a.sk_ws = scratch_bytes > pk ? (float*)((char*)scratch + pk) : nullptr;
+  a.sk_ws_floats = scratch_bytes > pk ? (scratch_bytes - pk) / sizeof(float) : 0;
+  const long in_elems = (long)a.B * (a.in.C0 + a.in.C1) * a.Lin;
+  const long sample_bytes = (long)2 * bf2_groups16(a.Cv) * (a.Tcols + a.H) * 16;
+  if (in_elems >= (1L << 31) || sample_bytes * 8 >= (1L << 30) || need >= (size_t)0x7fff0000) {
+    segan_set_error("corr_bf2: operand too large for 32-bit tile offsets");
+    return SEGAN_EUNSUPPORTED;
+  }
+  PackArgs pa;
+  pa.identity = (!a.in.scale && !a.in.shift && !a.in.slope) ? 1 : 0;
+  if (int e = segan_src_defaults(&a.in, st, "corr_bf2")) return e;
+  pa.in = a.in;
+  pa.out = (__bf16*)scratch;
+  pa.B = a.B; pa.Cv = a.Cv;
+  pa.G = 2 * bf2_groups16(a.Cv);
+  pa.Qp = a.Tcols + a.H;
+  pa.plane_elems = (size_t)a.B * pa.G * pa.Qp * 8;
+  pa.Lin = a.Lin; pa.padL = a.padL; pa.mode = a.mode; pa.roll = a.roll; pa.win_start = a.win_start;
+  int e;
+  if (IN_HI) e = S == 4 ? launch_pack<4, true>(pa, planes, st)
+                 : S == 2 ? launch_pack<2, true>(pa, planes, st) : launch_pack<1, true>(pa, planes, st);
+  else e = launch_pack<1, false>(pa, planes, st);
+  if (e) return e;
+  x.act = pa.out;
+  x.a_plane_bytes = (long)pa.plane_elems * 2;
+  x.ngroups = bf2_groups16(a.Cv);
+  x.G = pa.G;
+  x.Qp = pa.Qp;
+  x.nld = 0;
+  {
+    static int dbg = -1;
+    if (dbg < 0) {
+      const char* e = getenv("SEGAN_BF2_DBG");
+      dbg = e ? atoi(e) : 0;
+    }
+    x.dbg = dbg;
+  }
+  return SEGAN_OK;
+}
+
+static inline int bf_f_pitch2(int M) { return round_up(M, 128); }
+
+static int bf2_force_nb() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("SEGAN_BF2_NB");
+    v = e ? atoi(e) : 0;
+  }
+  return v;
+}
+
+int segan_corr_bf2_f(CorrArgs& a, int U, const void* wp3, int planes, void* scratch,
+                     size_t scratch_bytes, hipStream_t st) {
+  if (a.Rvalid <= 64 || (U != 8 && U != 16)) {
+    segan_set_error("corr_bf2: geometry stays on the other kernels");
+    return SEGAN_EUNSUPPORTED;
+  }
+  Bf2Extra x;
+  const int NB = bf2_force_nb() ? bf2_force_nb() : bf2_pick_nb(a, a.Rvalid);
+  if (int e = bf2_prepare<true>(a, U, planes, scratch, scratch_bytes, x, st, NB)) return e;
+  x.wp3 = (const __bf16*)wp3;
+  a.RP = bf_f_pitch2(a.Rvalid);
+  x.w_plane = (long)x.ngroups * U * 2 * a.RP * 8;
+  if (NB == 256) {
+    if (U == 8) return planes == 3 ? launch_bf2<256, 2, 8, true, false, 0, 3>(a, x, st)
+                                   : launch_bf2<256, 2, 8, true, false, 0, 1>(a, x, st);
+    return planes == 3 ? launch_bf2<256, 2, 16, true, false, 0, 3>(a, x, st)
+                       : launch_bf2<256, 2, 16, true, false, 0, 1>(a, x, st);
+  }
+  if (U == 8) return planes == 3 ? launch_bf2<128, 2, 8, true, false, 0, 3>(a, x, st)
+                                 : launch_bf2<128, 2, 8, true, false, 0, 1>(a, x, st);
+  return planes == 3 ? launch_bf2<128, 2, 16, true, false, 0, 3>(a, x, st)
+                     : launch_bf2<128, 2, 16, true, false, 0, 1>(a, x, st);
+}
+
+int segan_corr_bf2_t(CorrArgs& a, int U, const void* wp3, int planes, void* scratch,
+                     size_t scratch_bytes, hipStream_t st) {
+  const int mask = (a.rowshift[0] ? 1 : 0) | (a.rowshift[1] ? 2 : 0) | (a.rowshift[2] ? 4 : 0) |
+                   (a.rowshift[3] ? 8 : 0);
+  const bool ok = (U == 8 && (mask == 8 || mask == 0)) || (U == 16 && mask == 0);
+  if (!ok) {
+    segan_set_error("corr_bf2: unsupported T-form geometry (U=%d, shift mask %d)", U, mask);
+    return SEGAN_EUNSUPPORTED;
+  }
+  Bf2Extra x;
+  const int NB = bf2_force_nb() ? bf2_force_nb() : bf2_pick_nb(a, a.Rvalid);
+  if (int e = bf2_prepare<false>(a, U, planes, scratch, scratch_bytes, x, st, NB)) return e;
+  x.wp3 = (const __bf16*)wp3;
+  // a.RP = S*NP already (t_pitch)
+  x.w_plane = (long)x.ngroups * U * 2 * a.RP * 8;
+  if (NB == 256) {
+    if (U == 8 && mask == 8)
+      return planes == 3 ? launch_bf2<256, 1, 8, false, true, 8, 3>(a, x, st)
+                         : launch_bf2<256, 1, 8, false, true, 8, 1>(a, x, st);
+    if (U == 8)
+      return planes == 3 ? launch_bf2<256, 1, 8, false, true, 0, 3>(a, x, st)
+                         : launch_bf2<256, 1, 8, false, true, 0, 1>(a, x, st);
+    return planes == 3 ? launch_bf2<256, 1, 16, false, true, 0, 3>(a, x, st)
+                       : launch_bf2<256, 1, 16, false, true, 0, 1>(a, x, st);
+  }
+  if (U == 8 && mask == 8)
+    return planes == 3 ? launch_bf2<128, 1, 8, false, true, 8, 3>(a, x, st)
+                       : launch_bf2<128, 1, 8, false, true, 8, 1>(a, x, st);
+  if (U == 8)
+    return planes == 3 ? launch_bf2<128, 1, 8, false, true, 0, 3>(a, x, st)
+                       : launch_bf2<128, 1, 8, false, true, 0, 1>(a, x, st);
+  return planes == 3 ? launch_bf2<128, 1, 16, false, true, 0, 3>(a, x, st)
+                     : launch_bf2<128, 1, 16, false, true, 0, 1>(a, x, st);
+}

@@ -134,6 +134,13 @@ int segan_launch_fsmall(CorrArgs& a, int M, int N, int S, hipStream_t st);
 // split-bf16 entry points (segan_conv_bf.hip); `a` is filled exactly as for the fp32 kernels
 int segan_corr_bf_f(CorrArgs& a, int U, const void* wp3, int planes, hipStream_t st);
 int segan_corr_bf_t(CorrArgs& a, int U, const void* wp3, int planes, hipStream_t st);
+// round-3 bf16 forms (segan_conv_bf2.hip): activations pre-packed into `scratch`, both operands by
+// LDS-DMA; SEGAN_EUNSUPPORTED when the scratch is missing / too small or the geometry is not covered
+int segan_corr_bf2_f(CorrArgs& a, int U, const void* wp3, int planes, void* scratch,
+                     size_t scratch_bytes, hipStream_t st);
+int segan_corr_bf2_t(CorrArgs& a, int U, const void* wp3, int planes, void* scratch,
+                     size_t scratch_bytes, hipStream_t st);
+size_t segan_corr_bf2_scratch_bytes(int B, int Cv, int Tcols, int H, int planes);
 // wgrad on the bf16 matrix cores (segan_wgrad_bf.hip); planes = 1 (bf16) or 3 (bf16x3)
 int segan_wgrad_bf(WgradArgs& a, int U, int planes, hipStream_t st);
 size_t segan_wgrad_bf_scratch_bytes(int B, int M, int Ls, int planes);

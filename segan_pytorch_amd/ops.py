@@ -156,6 +156,18 @@ def last_wgrad_launch():
                     list(arr)))
 
 
+def _bf_scratch(op, B, N, M, L, K, S, pad, device):
+    """(pointer, bytes) of the packed-activation scratch of a bf16 / bf16x3 contraction call
+    (segan_bf16_scratch_bytes); the buffer must stay alive until the call is enqueued — the
+    caching allocator keeps it stream-ordered after that."""
+    planes = 3 if _precision == PREC_BF16X3 else 1
+    nbytes = _lib.load().segan_bf16_scratch_bytes(op, B, N, M, L, K, S, pad, planes)
+    if nbytes == 0:
+        return None, None, 0
+    buf = torch.empty(nbytes, device=device, dtype=torch.uint8)
+    return buf, ctypes.c_void_p(buf.data_ptr()), nbytes
+
+
 def conv_pad(K, S):
     return layout.conv_pad(K, S)
 
@@ -280,9 +292,10 @@ def conv1d_fwd(src, w, bias, S, roll=0, pad_mode=PAD_REFLECT, padL=None, pack=No
     pack = pack or WeightPack()
     lib = _lib.load()
     if _precision and pad_mode == PAD_REFLECT:
+        keep, sp, sn = _bf_scratch(0, B, N, M, L, K, S, padL, w.device)
         rc = lib.segan_conv1d_fwd(ctypes.byref(cs), _ptr(pack.bf(w, S, 0, 0, _precision)),
                                   _ptr(bias), _ptr(out), B, N, M, L, K, S, padL, pad_mode, roll,
-                                  _precision, None, 0, _stream())
+                                  _precision, sp, sn, _stream())
         if rc != _EUNSUPPORTED:
             check(rc, 'conv1d_fwd')
             return out
@@ -318,8 +331,9 @@ def conv1d_dgrad(da, w, L, S, roll=0, padL=None, pack=None):
               'conv1d_dgrad')
         return dx
     if _precision:
+        keep, sp, sn = _bf_scratch(1, B, N, M, L, K, S, padL, da.device)
         rc = lib.segan_conv1d_dgrad(_ptr(da), _ptr(pack.bf(w, S, 0, 1, _precision)), None, _ptr(dx),
-                                    _ptr(halo), B, N, M, L, K, S, padL, roll, _precision, None, 0,
+                                    _ptr(halo), B, N, M, L, K, S, padL, roll, _precision, sp, sn,
                                     _stream())
         if rc != _EUNSUPPORTED:
             check(rc, 'conv1d_dgrad')
@@ -410,9 +424,10 @@ def deconv1d_fwd(src, w, bias, S, act=ACT_NONE, pack=None):
               'deconv1d_fwd')
         return y
     if _precision and act == ACT_NONE:
+        keep, sp, sn = _bf_scratch(2, B, N, M, S * Ls, K, S, pad, w.device)
         rc = lib.segan_deconv1d_fwd(ctypes.byref(cs), _ptr(pack.bf(w, S, pad, 1, _precision)), None,
                                     _ptr(bias), _ptr(y), B, M, N, Ls, K, S, pad, act, _precision,
-                                    None, 0, _stream())
+                                    sp, sn, _stream())
         if rc != _EUNSUPPORTED:
             check(rc, 'deconv1d_fwd')
             return y
@@ -442,8 +457,9 @@ def deconv1d_dgrad(dy, w, S, M0=0, need0=True, need1=True, pack=None):
     pack = pack or WeightPack()
     lib = _lib.load()
     if _precision:
+        keep, sp, sn = _bf_scratch(3, B, N, M, S * Ls, K, S, pad, dy.device)
         rc = lib.segan_deconv1d_dgrad(_ptr(dy), _ptr(pack.bf(w, S, 0, 0, _precision)), _ptr(dx0),
-                                      _ptr(dx1), B, M, M0, N, Ls, K, S, pad, _precision, None, 0,
+                                      _ptr(dx1), B, M, M0, N, Ls, K, S, pad, _precision, sp, sn,
                                       _stream())
         if rc != _EUNSUPPORTED:
             check(rc, 'deconv1d_dgrad')

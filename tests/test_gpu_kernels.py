@@ -815,6 +815,79 @@ def test_deconv_layers_at_batch_scale(name, M0, M1, N, Ls, B):
     assert info_t['kernel'] == 2 and info_f['kernel'] == 2
 
 
+@pytest.mark.parametrize('prec', ['bf16x3', 'bf16'])
+@pytest.mark.parametrize('name,N,M,L,roll,B', [('enc1', 64, 128, 4096, 3, 80), ('enc2', 128, 256, 1024, -2, 80),
+                                               ('enc4', 512, 1024, 64, 1, 300)])
+def test_conv_layers_at_batch_scale_bf16(prec, name, N, M, L, roll, B):
+    """The bf16 / bf16x3 forms on real layer shapes at batch scale (packed activations, both
+    operands by LDS-DMA, slab stream-K tail): forward and data gradient vs fp64 at the restated
+    tolerances, and bit-reproducible (no atomics anywhere in these forms)."""
+    ops = _ops()
+    S, K = 4, 31
+    x = rnd(B, N, L, seed=11)
+    sl = rnd(N, seed=12).abs() * 0.3
+    w = rnd(M, N, K, seed=13, scale=0.05)
+    b = rnd(M, seed=14)
+    hd = xform_ref(x, slope=sl).requires_grad_(True)
+    wd = w.double().requires_grad_(True)
+    ref = conv_ref(hd, wd, b.double(), S, roll)
+    da = rnd(*ref.shape, seed=15)
+    ref.backward(da.double())
+    xg, wg, bg, slg, dag = x.to(DEV), w.to(DEV), b.to(DEV), sl.to(DEV), da.to(DEV)
+    src = ops.Src(xg, slope=slg)
+    ops.set_precision(prec)
+    try:
+        out = ops.conv1d_fwd(src, wg, bg, S, roll=roll)
+        out2 = ops.conv1d_fwd(src, wg, bg, S, roll=roll)
+        dx = ops.conv1d_dgrad(dag, wg, L, S, roll=roll)
+        dx2 = ops.conv1d_dgrad(dag, wg, L, S, roll=roll)
+    finally:
+        ops.set_precision('fp32')
+    tol = PREC_TOL[prec]
+    assert max_rel(out, ref) < tol and max_rel(dx, hd.grad) < tol
+    assert torch.equal(out, out2) and torch.equal(dx, dx2)
+
+
+@pytest.mark.parametrize('prec', ['bf16x3', 'bf16'])
+@pytest.mark.parametrize('name,M0,M1,N,Ls,B', [('dec0', 1024, 1024, 512, 16, 300), ('dec2', 256, 256, 128, 256, 80),
+                                               ('dec3', 128, 128, 64, 1024, 80)])
+def test_deconv_layers_at_batch_scale_bf16(prec, name, M0, M1, N, Ls, B):
+    """Decoder layers in the bf16 / bf16x3 forms at batch scale: two-pointer input with alpha /
+    PReLU applied by the packing pass, data gradient split at the segment boundary."""
+    ops = _ops()
+    S, K = 4, 31
+    M = M0 + M1
+    x0, x1 = rnd(B, M0, Ls, seed=21), rnd(B, M1, Ls, seed=22)
+    scale = torch.cat((torch.ones(M0), rnd(M1, seed=23)))
+    slope = torch.cat((rnd(M0, seed=24).abs() * 0.3, torch.ones(M1)))
+    w = rnd(M, N, K, seed=25, scale=0.05)
+    b = rnd(N, seed=26)
+    xin = xform_ref(torch.cat((x0, x1), 1), scale, None, slope).requires_grad_(True)
+    wd = w.double().requires_grad_(True)
+    pad = ops.deconv_pad(K, S)
+    ref = F.conv_transpose1d(xin, wd, b.double(), stride=S, padding=pad)[:, :, :S * Ls]
+    dy = rnd(*ref.shape, seed=27)
+    ref.backward(dy.double())
+    src = ops.Src(x0.to(DEV), x1.to(DEV), scale=scale.to(DEV), slope=slope.to(DEV))
+    wg, bg, dyg = w.to(DEV), b.to(DEV), dy.to(DEV)
+    need0 = name != 'dec0'
+    ops.set_precision(prec)
+    try:
+        y = ops.deconv1d_fwd(src, wg, bg, S)
+        y2 = ops.deconv1d_fwd(src, wg, bg, S)
+        dx0, dx1 = ops.deconv1d_dgrad(dyg, wg, S, M0, need0=need0)
+        dx0b, dx1b = ops.deconv1d_dgrad(dyg, wg, S, M0, need0=need0)
+    finally:
+        ops.set_precision('fp32')
+    tol = PREC_TOL[prec]
+    assert max_rel(y, ref) < tol and torch.equal(y, y2)
+    assert max_rel(dx1, xin.grad[:, M0:]) < tol and torch.equal(dx1, dx1b)
+    if need0:
+        assert max_rel(dx0, xin.grad[:, :M0]) < tol
+    else:
+        assert dx0 is None
+
+
 def l2_rel(a, b):
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
     return ((a - b).norm() / b.norm().clamp_min(1e-300)).item()
