@@ -49,33 +49,73 @@ struct PackArgs {
 };
 
 // one thread = one 16-byte piece (b, g, j); lanes run along j (coalesced reads of each of the
-// piece's rows, coalesced 16-byte writes)
+// piece's rows, coalesced 16-byte writes).  F form: a piece holds 8/S real channels x S phases,
+// and the S padded samples S*wq .. S*wq + S-1 of a channel are consecutive in memory except at
+// the reflected ends and the roll's wrap point: one vector load per channel there.
 template <int S, bool IN_HI, int NPL>
 __global__ __launch_bounds__(256) void act_pack_kernel(const PackArgs a) {
   const int j = blockIdx.x * 256 + threadIdx.x;
   const int g = blockIdx.y, b = blockIdx.z;
   if (j >= a.Qp) return;
   const int wq = j + a.win_start;
+  float v[8];
+  if (IN_HI) {
+    int idx[S];
+#pragma unroll
+    for (int r = 0; r < S; ++r) idx[r] = segan_hi_index(S * wq + r, a.Lin, a.padL, a.mode, a.roll);
+    bool run = idx[0] >= 0;
+#pragma unroll
+    for (int r = 1; r < S; ++r) run = run && idx[r] == idx[0] + r;
+#pragma unroll
+    for (int c = 0; c < 8 / S; ++c) {
+      const int n = (8 * g) / S + c;
+      const bool cok = n * S < a.Cv;
+      const float* row = segan_src_row(a.in, b, cok ? n : 0, a.Lin);
+      float t[S];
+      if (run) {
+        if (S == 4) {
+          typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+          const f4u x4 = *reinterpret_cast<const f4u*>(row + idx[0]);
+          t[0] = x4[0]; t[1 % S] = x4[1]; t[2 % S] = x4[2]; t[3 % S] = x4[3];
+        } else if (S == 2) {
+          typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+          const f2u x2 = *reinterpret_cast<const f2u*>(row + idx[0]);
+          t[0] = x2[0]; t[1 % S] = x2[1];
+        } else {
+          t[0] = row[idx[0]];
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < S; ++r) t[r] = idx[r] >= 0 ? row[idx[r]] : 0.0f;
+      }
+      ChanXf xf;
+      if (!a.identity) xf = segan_chan_xf(a.in, cok ? n : 0);
+#pragma unroll
+      for (int r = 0; r < S; ++r) {
+        float x = t[r];
+        if (!a.identity) x = segan_apply_xf(xf, x);
+        v[c * S + r] = (cok && (run || idx[r] >= 0)) ? x : 0.0f;
+      }
+    }
+  } else {
+    const bool pok = wq >= 0 && wq < a.Lin;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int cv = 8 * g + e;
+      const bool ok = pok && cv < a.Cv;
+      float x = 0.0f;
+      if (ok) {
+        x = segan_src_row(a.in, b, cv, a.Lin)[wq];
+        if (!a.identity) x = segan_apply_xf(segan_chan_xf(a.in, cv), x);
+      }
+      v[e] = x;
+    }
+  }
   bf16x8 pl[3];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    const int cv = 8 * g + e;
-    const int n = IN_HI ? cv / S : cv;
-    const int r = IN_HI ? cv % S : 0;
-    int idx;
-    if (IN_HI) idx = segan_hi_index(S * wq + r, a.Lin, a.padL, a.mode, a.roll);
-    else idx = (wq >= 0 && wq < a.Lin) ? wq : -1;
-    const bool ok = cv < a.Cv && idx >= 0;
-    float v = 0.0f;
-    if (ok) {
-      v = segan_src_row(a.in, b, n, a.Lin)[idx];
-      if (!a.identity) {
-        const ChanXf xf = segan_chan_xf(a.in, n);
-        v = segan_apply_xf(xf, v);
-      }
-    }
     __bf16 p1, p2, p3;
-    split3b(v, p1, p2, p3);
+    split3b(v[e], p1, p2, p3);
     pl[0][e] = p1; pl[1][e] = p2; pl[2][e] = p3;
   }
   const size_t piece = ((size_t)b * a.G + g) * a.Qp + j;

@@ -144,3 +144,6 @@ size_t segan_corr_bf2_scratch_bytes(int B, int Cv, int Tcols, int H, int planes)
 // wgrad on the bf16 matrix cores (segan_wgrad_bf.hip); planes = 1 (bf16) or 3 (bf16x3)
 int segan_wgrad_bf(WgradArgs& a, int U, int planes, hipStream_t st);
 size_t segan_wgrad_bf_scratch_bytes(int B, int M, int Ls, int planes);
+// round-3 form (segan_wgrad_bf2.hip): both operands pre-packed into `scratch`, LDS-DMA
+int segan_wgrad_bf2(WgradArgs& a, int U, int planes, void* scratch, size_t scratch_bytes, hipStream_t st);
+size_t segan_wgrad_bf2_scratch_bytes(int B, int M, int N, int Ls, int S, int planes);

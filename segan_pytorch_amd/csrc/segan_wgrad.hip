@@ -858,8 +858,12 @@ static int launch_wgrad_fp32(WgradArgs& a, hipStream_t st, bool deterministic, f
 extern "C" size_t segan_wgrad_scratch_bytes(int B, int M, int N, int Ls, int S, int precision,
                                             int flags) {
   if (B <= 0 || M <= 0 || N <= 0 || Ls <= 0 || !stride_ok(S)) return 0;
-  if (precision != SEGAN_PREC_FP32)
-    return segan_wgrad_bf_scratch_bytes(B, M, Ls, precision == SEGAN_PREC_BF16 ? 1 : 3);
+  if (precision != SEGAN_PREC_FP32) {
+    const int planes = precision == SEGAN_PREC_BF16 ? 1 : 3;
+    const size_t r1 = segan_wgrad_bf_scratch_bytes(B, M, Ls, planes);
+    const size_t r3 = segan_wgrad_bf2_scratch_bytes(B, M, N, Ls, S, planes);
+    return r1 > r3 ? r1 : r3;
+  }
   // room for a materialised lo, plus (deterministic mode) the partial tiles of every split:
   // at most max(tiles, 4 rounds of 1024 resident workgroups) tiles of 128 x 128
   size_t bytes = (size_t)B * M * Ls * sizeof(float);
@@ -891,8 +895,12 @@ extern "C" int segan_wgrad(const segan_src* lo, const segan_src* hi, float* dw, 
   a.Ctot = B * Ls;
   hipStream_t st = (hipStream_t)stream;
   if (precision != SEGAN_PREC_FP32) {
+    const int planes = precision == SEGAN_PREC_BF16 ? 1 : 3;
+    WgradArgs a2 = a;
+    const int e = segan_wgrad_bf2(a2, 32 / S, planes, scratch, scratch_bytes, st);
+    if (e != SEGAN_EUNSUPPORTED) return e;
     a.lo_pk = scratch;
-    return segan_wgrad_bf(a, 32 / S, precision == SEGAN_PREC_BF16 ? 1 : 3, st);
+    return segan_wgrad_bf(a, 32 / S, planes, st);
   }
   const bool det = (flags & SEGAN_WGRAD_DETERMINISTIC) != 0;
   float* sc = (float*)scratch;
