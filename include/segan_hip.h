@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SEGAN_ABI_VERSION 9
+#define SEGAN_ABI_VERSION 10
 
 #define SEGAN_PAD_REFLECT 0
 #define SEGAN_PAD_ZERO 1
@@ -245,12 +245,16 @@ int segan_tanh_bwd(const float* y, const float* dy, const float* clean, float l1
 /* ---- dense layers of the discriminator head (discriminator.py:111-117) ------------ */
 
 /* C[M,N] (+)= op(A)[M,K] * op(B)[K,N] with explicit element strides; exact fp32 on
- * MFMA.  beta0 != 0 overwrites C (C is zeroed first), otherwise accumulates.  Small outputs
- * split the contraction across workgroups (fp32 atomics); SEGAN_GEMM_DETERMINISTIC in `flags`
- * keeps it whole (bit-reproducible). */
+ * MFMA.  beta0 != 0 overwrites C, otherwise accumulates.  Small outputs split the contraction
+ * across workgroups: partials are added with fp32 atomics, or — SEGAN_GEMM_DETERMINISTIC in
+ * `flags` — written as slabs into `scratch` (segan_gemm_scratch_bytes, 16-byte aligned) and
+ * added in split order by a second kernel (bit-reproducible); deterministic without scratch keeps
+ * the contraction whole in one workgroup per tile. */
 #define SEGAN_GEMM_DETERMINISTIC 1
+size_t segan_gemm_scratch_bytes(int M, int N, int K);
 int segan_gemm(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn,
-               float* C, int64_t ldc, int M, int N, int K, int beta0, int flags, void* stream);
+               float* C, int64_t ldc, int M, int N, int K, int beta0, int flags, void* scratch,
+               size_t scratch_bytes, void* stream);
 
 /* y[r,c] = prelu(x[r,c] + bias[c], slope[c]) (slope NULL = identity), rows x cols. */
 int segan_bias_prelu_rows(const float* x, const float* bias, const float* slope, float* y,

@@ -14,7 +14,7 @@ PAD_REFLECT = 0
 PAD_ZERO = 1
 ACT_NONE = 0
 ACT_TANH = 1
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class SeganSrc(Structure):
@@ -64,8 +64,9 @@ SIGNATURES = {
     'segan_bce_logits_const': (c_int, [_P, c_float, _P, _P, _P, c_float, c_int, _P]),
     'segan_act_bwd': (c_int, [_P] * 16 + [c_int, c_int, c_int, _P]),
     'segan_tanh_bwd': (c_int, [_P, _P, _P, c_float, _P, _P, _P, c_int, c_int, c_int, _P]),
+    'segan_gemm_scratch_bytes': (c_size_t, [c_int, c_int, c_int]),
     'segan_gemm': (c_int, [_P, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int64, c_int, c_int,
-                           c_int, c_int, c_int, _P]),
+                           c_int, c_int, c_int, _P, c_size_t, _P]),
     'segan_bias_prelu_rows': (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
     'segan_bias_prelu_rows_bwd': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
     'segan_mse_const': (c_int, [_P, c_float, _P, _P, _P, c_float, c_int, _P]),

@@ -81,7 +81,8 @@ template <bool AK, bool BKC>
 __global__ __launch_bounds__(256, 2) void gemm128_kernel(const float* __restrict__ A, long lda,
                                                          const float* __restrict__ B, long ldb,
                                                          float* __restrict__ C, long ldc, int M,
-                                                         int N, int K, int kper) {
+                                                         int N, int K, int kper,
+                                                         float* __restrict__ slabs) {
   __shared__ __attribute__((aligned(16))) float Al[2][G2K][G2P];
   __shared__ __attribute__((aligned(16))) float Bl[2][G2K][G2P];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -185,6 +186,10 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const float* __restrict
         const int m = m0 + wm * 64 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
         const int n = n0 + wn * 64 + 32 * j + l31;
         if (m < M && n < N) {
+          if (slabs) {      // deterministic split-K: this split's partial, added in split order later
+            slabs[((size_t)blockIdx.z * M + m) * N + n] = acc[i][j][e];
+            continue;
+          }
           float* c = C + (long)m * ldc + n;
           if (atomic) atomicAdd(c, acc[i][j][e]);
           else *c += acc[i][j][e];
@@ -192,16 +197,43 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const float* __restrict
       }
 }
 
+// C (+)= sum over the contraction splits, in split order (bit-reproducible)
+__global__ void gemm_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ C, long ldc,
+                                   int M, int N, int nsplit, int beta0) {
+  const size_t total = (size_t)M * N;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    float s = 0.0f;
+    for (int z = 0; z < nsplit; ++z) s += slabs[(size_t)z * total + i];
+    float* c = C + (i / N) * ldc + i % N;
+    *c = beta0 ? s : *c + s;
+  }
+}
+
+extern "C" size_t segan_gemm_scratch_bytes(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  const int tm = ceil_div(M, G2T), tn = ceil_div(N, G2T);
+  int nsplit = ceil_div(512, tm * tn);
+  const int kchunks = ceil_div(K, G2K);
+  if (nsplit > kchunks / 4) nsplit = kchunks / 4;
+  if (nsplit < 1) nsplit = 1;
+  return (size_t)nsplit * M * N * sizeof(float);
+}
+
 extern "C" int segan_gemm(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk,
                           int64_t sbn, float* C, int64_t ldc, int M, int N, int K, int beta0,
-                          int flags, void* stream) {
+                          int flags, void* scratch, size_t scratch_bytes, void* stream) {
   SEGAN_REQUIRE(A && B && C, "gemm: NULL pointer");
   SEGAN_REQUIRE(M > 0 && N > 0 && K > 0 && ldc >= N, "gemm: bad sizes");
   hipStream_t st = (hipStream_t)stream;
-  // split-K partials are combined with fp32 atomics; SEGAN_GEMM_DETERMINISTIC keeps the whole
-  // contraction in one workgroup per tile (bit-reproducible)
-  const bool nosplit = (flags & SEGAN_GEMM_DETERMINISTIC) != 0;
-  if (beta0) {
+  // split-K partials are combined with fp32 atomics; with SEGAN_GEMM_DETERMINISTIC they are written
+  // as slabs into the caller's scratch and added in split order (bit-reproducible) — without
+  // scratch the whole contraction stays in one workgroup per tile
+  const bool det = (flags & SEGAN_GEMM_DETERMINISTIC) != 0;
+  const bool det_slabs = det && scratch != nullptr &&
+                         scratch_bytes >= segan_gemm_scratch_bytes(M, N, K) && ((uintptr_t)scratch & 15) == 0;
+  const bool nosplit = det && !det_slabs;
+  if (beta0 && !det_slabs) {
     if (ldc == N) {
       if (hipMemsetAsync(C, 0, (size_t)M * N * sizeof(float), st) != hipSuccess) {
         segan_set_error("gemm: memset failed");
@@ -230,18 +262,38 @@ extern "C" int segan_gemm(const float* A, int64_t sam, int64_t sak, const float*
       const int kper = ceil_div(kchunks, nsplit) * G2K;
       nsplit = ceil_div(K, kper);
       const dim3 grid(tn, tm, nsplit);
-#define G2(AKF, BKF) hipLaunchKernelGGL((gemm128_kernel<AKF, BKF>), grid, dim3(256), 0, st, A, lda, B, ldb, C, (long)ldc, M, N, K, kper)
+      float* slabs = (det_slabs && nsplit > 1) ? (float*)scratch : nullptr;
+      if (det_slabs && nsplit == 1 && beta0) {      // unsplit: the kernel adds into a zeroed C
+        if (hipMemset2DAsync(C, ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, st) != hipSuccess) {
+          segan_set_error("gemm: memset2d failed");
+          return SEGAN_ELAUNCH;
+        }
+      }
+#define G2(AKF, BKF) hipLaunchKernelGGL((gemm128_kernel<AKF, BKF>), grid, dim3(256), 0, st, A, lda, B, ldb, C, (long)ldc, M, N, K, kper, slabs)
       // a k-contiguous view is preferred when both strides are 1 (degenerate 1-wide operands)
       if (ak && bk) G2(true, true); else if (ak) G2(true, false); else if (bk) G2(false, true); else G2(false, false);
 #undef G2
-      return segan_check_launch("gemm128");
+      if (int e = segan_check_launch("gemm128")) return e;
+      if (slabs) {
+        const size_t total = (size_t)M * N;
+        hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256)),
+                           dim3(256), 0, st, slabs, C, (long)ldc, M, N, nsplit, beta0);
+        return segan_check_launch("gemm_reduce");
+      }
+      return SEGAN_OK;
+    }
+  }
+  if (beta0 && det_slabs) {     // (the generic kernel has no slab form: unsplit into a zeroed C)
+    if (hipMemset2DAsync(C, ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, st) != hipSuccess) {
+      segan_set_error("gemm: memset2d failed");
+      return SEGAN_ELAUNCH;
     }
   }
   const int tm = ceil_div(M, GT), tn = ceil_div(N, GT);
   int nsplit = ceil_div(512, tm * tn);
   const int kchunks = ceil_div(K, GK);
   if (nsplit > kchunks) nsplit = kchunks;
-  if (nsplit < 1 || nosplit) nsplit = 1;
+  if (nsplit < 1 || det) nsplit = 1;
   int kper = ceil_div(kchunks, nsplit) * GK;
   nsplit = ceil_div(K, kper);
   hipLaunchKernelGGL(gemm_kernel, dim3(tn, tm, nsplit), dim3(256), 0, st, A, (long)sam, (long)sak,

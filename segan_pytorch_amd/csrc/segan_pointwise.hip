@@ -61,13 +61,29 @@ __device__ __forceinline__ ChanRange chan_range(int B, int nsplit) {
 // ---------------------------------------------------------------------------------
 // BatchNorm statistics
 // ---------------------------------------------------------------------------------
+// Chan et al. combination of two (count, mean, M2) partials
+__device__ __forceinline__ void chan_combine(float& n, float& mean, float& m2, float nb, float mb,
+                                             float qb) {
+  const float tot = n + nb;
+  if (tot <= 0.0f) return;
+  const float d = mb - mean;
+  const float f = nb / tot;
+  mean = fmaf(d, f, mean);
+  m2 = m2 + qb + d * d * n * f;
+  n = tot;
+}
+
+// ONE pass over the slice (round 2 read it twice: mean, then squared deviations).  Every thread
+// keeps shifted sums s1 = sum(x - K), s2 = sum((x - K)^2) with K = the FIRST element it visits —
+// a sample of the very distribution, so |mean - K| is of the order of the spread and
+// M2 = s2 - s1^2/n loses at most a bit or two (a shift far from the data, e.g. zero or a running
+// mean, is what makes one-pass variances cancel) — then the threads' (count, mean, M2) are merged
+// with Chan's formula in a fixed tree: lanes by shuffles, waves through LDS.
 __global__ void bn_partial_kernel(const float* __restrict__ x, float* __restrict__ ws, int B, int C,
                                   int L, int nsplit) {
-  __shared__ float sm[16];
-  __shared__ float s_mean;
+  __shared__ float sm[3 * (PW_THREADS / 64)];
   const ChanRange cr = chan_range(B, nsplit);
   const int nb = cr.b_end - cr.b_beg;
-  const long cnt = (long)(nb > 0 ? nb : 0) * L;
   // slice = rows (b, cr.c, :) for b in [b_beg, b_end): `tr` threads walk a row (float4 when
   // 4 | L), PW_THREADS/tr rows at a time; 32-bit index math only
   const float* base = x + ((size_t)cr.b_beg * C + cr.c) * L;
@@ -78,23 +94,8 @@ __global__ void bn_partial_kernel(const float* __restrict__ x, float* __restrict
   while (tr > Lv && tr > 1) tr >>= 1;
   const int rp = PW_THREADS / tr;
   const int t0 = threadIdx.x % tr, r0 = threadIdx.x / tr;
-  float v[1] = {0.f};
-  for (int b = r0; b < nb; b += rp) {
-    const float* row = base + b * sstride;
-    if (vec) {
-      for (int t = t0; t < Lv; t += tr) {
-        const f32x4 u = *reinterpret_cast<const f32x4*>(row + 4 * t);
-        v[0] += (u[0] + u[1]) + (u[2] + u[3]);
-      }
-    } else {
-      for (int t = t0; t < Lv; t += tr) v[0] += row[t];
-    }
-  }
-  block_sum<1>(v, sm);
-  if (threadIdx.x == 0) s_mean = cnt > 0 ? v[0] / (float)cnt : 0.f;
-  __syncthreads();
-  const float mean = s_mean;
-  float q[1] = {0.f};
+  float K = 0.0f, s1 = 0.0f, s2 = 0.0f, n = 0.0f;
+  if (r0 < nb && t0 < Lv) K = base[(size_t)r0 * sstride + (vec ? 4 * t0 : t0)];
   for (int b = r0; b < nb; b += rp) {
     const float* row = base + b * sstride;
     if (vec) {
@@ -102,23 +103,44 @@ __global__ void bn_partial_kernel(const float* __restrict__ x, float* __restrict
         const f32x4 u = *reinterpret_cast<const f32x4*>(row + 4 * t);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float d = u[e] - mean;
-          q[0] = fmaf(d, d, q[0]);
+          const float d = u[e] - K;
+          s1 += d;
+          s2 = fmaf(d, d, s2);
         }
+        n += 4.0f;
       }
     } else {
       for (int t = t0; t < Lv; t += tr) {
-        const float d = row[t] - mean;
-        q[0] = fmaf(d, d, q[0]);
+        const float d = row[t] - K;
+        s1 += d;
+        s2 = fmaf(d, d, s2);
+        n += 1.0f;
       }
     }
   }
-  block_sum<1>(q, sm);
+  float mean = 0.0f, m2 = 0.0f;
+  if (n > 0.0f) {
+    const float r = s1 / n;
+    mean = K + r;
+    m2 = fmaxf(s2 - s1 * r, 0.0f);
+  }
+  // lanes: butterfly-free fixed tree (lane i takes lane i + o)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float nb2 = __shfl_down(n, o, 64), mb2 = __shfl_down(mean, o, 64), qb2 = __shfl_down(m2, o, 64);
+    chan_combine(n, mean, m2, nb2, mb2, qb2);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    sm[3 * wave] = n; sm[3 * wave + 1] = mean; sm[3 * wave + 2] = m2;
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
+    for (int w = 1; w < PW_THREADS / 64; ++w) chan_combine(n, mean, m2, sm[3 * w], sm[3 * w + 1], sm[3 * w + 2]);
     float* w = ws + ((size_t)blockIdx.y * C + cr.c) * 3;
-    w[0] = (float)cnt;
+    w[0] = n;
     w[1] = mean;
-    w[2] = q[0];
+    w[2] = m2;
   }
 }
 

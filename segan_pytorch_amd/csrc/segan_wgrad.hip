@@ -29,8 +29,29 @@ __device__ __forceinline__ void wgrad_slab_store(float* slab, const f32x16 (&acc
 }
 
 // deterministic mode: dw[m][n][k] += sum over the contraction splits, in split order
+// first level of a two-level reduction (edge layers: thousands of splits of a single tile): each
+// workgroup adds a GROUP of consecutive slabs, in order, into the group's first slab
+template <int MB, int NBT>
+__global__ __launch_bounds__(256) void wgrad_group_kernel(float* slabs, int nsplit, int gsz) {
+  constexpr int NV = (MB / 64) * (NBT / 64) * 4;
+  const int tid = threadIdx.x;
+  const size_t tile = (size_t)blockIdx.y * gridDim.x + blockIdx.x, ntiles = (size_t)gridDim.x * gridDim.y;
+  const int z0 = blockIdx.z * gsz, z1 = min(nsplit, z0 + gsz);
+  f32x4 acc[NV];
+#pragma unroll
+  for (int q = 0; q < NV; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int z = z0; z < z1; ++z) {
+    const f32x4* s4 = reinterpret_cast<const f32x4*>(slabs + ((size_t)z * ntiles + tile) * (MB * NBT));
+#pragma unroll
+    for (int q = 0; q < NV; ++q) acc[q] += s4[q * 256 + tid];
+  }
+  f32x4* d4 = reinterpret_cast<f32x4*>(slabs + ((size_t)z0 * ntiles + tile) * (MB * NBT));
+#pragma unroll
+  for (int q = 0; q < NV; ++q) d4[q * 256 + tid] = acc[q];
+}
+
 template <int U, int MB, int NBT>
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs a, int nsplit) {
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs a, int nsplit, int zstep = 1) {
   constexpr int S = 32 / U;
   constexpr int CVW = NBT / U, NI = MB / 64, NJ = NBT / 64;
   const int tid = threadIdx.x;
@@ -45,7 +66,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs a, in
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-  for (int z = 0; z < nsplit; ++z) {
+  for (int z = 0; z < nsplit; z += zstep) {
     const f32x4* s4 = reinterpret_cast<const f32x4*>(
         a.w2_slabs + ((size_t)(z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (MB * NBT));
 #pragma unroll
@@ -705,6 +726,8 @@ static int launch_wgrad2(WgradArgs& a, hipStream_t st, bool deterministic, float
   a.w2_cps = cps;
   a.w2_nch = nch;
   a.w2_slabs = nullptr;
+  // an unsplit contraction touches every dw element exactly once: nothing to order
+  if (nsplit == 1) deterministic = false;
   if (deterministic) {
     if (slabs == nullptr || slab_floats_avail < wgrad2_slab_floats(tiles, nsplit)) {
       segan_set_error("wgrad: deterministic mode needs %zu bytes of scratch for the partial tiles",
@@ -719,7 +742,7 @@ static int launch_wgrad2(WgradArgs& a, hipStream_t st, bool deterministic, float
   hipLaunchKernelGGL(kern, dim3(ncol, nrow, nsplit), dim3(256), lds, st, a);
   if (int e = segan_check_launch("wgrad2_kernel")) return e;
   if (deterministic) {
-    hipLaunchKernelGGL((wgrad_reduce_kernel<U, 128, 128>), dim3(ncol, nrow), dim3(256), 0, st, a, nsplit);
+    hipLaunchKernelGGL((wgrad_reduce_kernel<U, 128, 128>), dim3(ncol, nrow), dim3(256), 0, st, a, nsplit, 1);
     return segan_check_launch("wgrad_reduce_kernel");
   }
   return SEGAN_OK;
@@ -770,6 +793,7 @@ static int launch_wgrad_tile(WgradArgs& a, hipStream_t st, float* slabs, size_t 
     attr_done[d] = true;
   }
   a.w2_slabs = nullptr;
+  if (nsplit == 1) slabs = nullptr;      // unsplit: every dw element is touched exactly once
   if (slabs) {
     if (slab_floats < (size_t)tiles * nsplit * MB * NBT) {
       segan_set_error("wgrad: deterministic mode needs %zu bytes of scratch for the partial tiles",
@@ -783,7 +807,17 @@ static int launch_wgrad_tile(WgradArgs& a, hipStream_t st, float* slabs, size_t 
   hipLaunchKernelGGL(kern, dim3(ncol, nrow, nsplit), dim3(256), lds, st, a);
   if (int e = segan_check_launch("wgrad_kernel")) return e;
   if (slabs) {
-    hipLaunchKernelGGL((wgrad_reduce_kernel<U, MB, NBT>), dim3(ncol, nrow), dim3(256), 0, st, a, nsplit);
+    // few tiles, many splits (the 1-2 channel edge layers): a fixed two-level tree, so that the
+    // reduction runs on many workgroups; the grouping depends only on the geometry
+    int zstep = 1;
+    if (nsplit >= 128 && tiles <= 8) {
+      zstep = 32;
+      hipLaunchKernelGGL((wgrad_group_kernel<MB, NBT>), dim3(ncol, nrow, ceil_div(nsplit, zstep)),
+                         dim3(256), 0, st, slabs, nsplit, zstep);
+      if (int e = segan_check_launch("wgrad_group_kernel")) return e;
+    }
+    hipLaunchKernelGGL((wgrad_reduce_kernel<U, MB, NBT>), dim3(ncol, nrow), dim3(256), 0, st, a, nsplit,
+                       zstep);
     return segan_check_launch("wgrad_reduce_kernel");
   }
   return SEGAN_OK;

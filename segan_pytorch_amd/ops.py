@@ -625,8 +625,14 @@ def tanh_bwd(y, dy, clean=None, l1_scale=0.0, dbias=None):
 # dense head
 # ---------------------------------------------------------------------------------
 def gemm(A, sam, sak, Bm, sbk, sbn, C, M, N, K, overwrite):
-    check(_lib.load().segan_gemm(_ptr(A), sam, sak, _ptr(Bm), sbk, sbn, _ptr(C), C.stride(0), M, N,
-                                 K, 1 if overwrite else 0, 1 if _deterministic else 0, _stream()),
+    lib = _lib.load()
+    sp, sn = None, 0
+    if _deterministic:      # split-K partials as slabs, added in split order
+        sn = lib.segan_gemm_scratch_bytes(M, N, K)
+        keep = torch.empty(sn, device=C.device, dtype=torch.uint8)
+        sp = ctypes.c_void_p(keep.data_ptr())
+    check(lib.segan_gemm(_ptr(A), sam, sak, _ptr(Bm), sbk, sbn, _ptr(C), C.stride(0), M, N,
+                         K, 1 if overwrite else 0, 1 if _deterministic else 0, sp, sn, _stream()),
           'gemm')
 
 

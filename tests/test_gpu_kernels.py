@@ -221,6 +221,26 @@ def test_bn_stats_and_affine_prelu():
     assert max_rel(h, F.prelu(ref, slope.double())) < 1e-5
 
 
+@pytest.mark.parametrize('B,C,L,mu,sd', [(300, 8, 4096, 10.0, 0.1), (300, 64, 16, -3.0, 0.02),
+                                         (7, 5, 1001, 0.5, 2.0), (80, 16, 256, 50.0, 1.0)])
+def test_bn_stats_one_pass_is_accurate(B, C, L, mu, sd):
+    """The BatchNorm statistics are taken in ONE pass (shifted sums per thread, Chan merges): mean
+    and variance against fp64 also where the mean is 100 x the spread — the regime in which a
+    one-pass variance with a badly chosen shift cancels."""
+    ops = _ops()
+    x = (rnd(B, C, L, seed=31) * sd + mu + rnd(C, seed=32).view(1, C, 1) * sd).float()
+    xd = x.double()
+    mean_ref = xd.mean((0, 2))
+    var_ref = xd.var((0, 2), unbiased=False)
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    mean, rstd, scale, shift = ops.bn_stats(x.to(DEV), None, None, 0.0, 1.0, rm, rv)
+    var = 1.0 / (rstd.double().cpu() ** 2)
+    assert ((mean.double().cpu() - mean_ref).abs() / var_ref.sqrt()).max().item() < 5e-5   # fp32 data at |mean| = 150 x spread
+    assert ((var - var_ref).abs() / var_ref).max().item() < 2e-4
+    n = B * L
+    assert max_rel(rv, var_ref * n / (n - 1)) < 2e-4      # momentum 1: the unbiased batch variance
+
+
 @pytest.mark.parametrize('B,C,L', [(6, 24, 32), (300, 8, 16), (3, 70, 1000)])
 def test_act_bwd_bn_prelu(B, C, L):
     """Backward through BatchNorm(train) + PReLU incl. gamma/beta/slope/bias grads."""
