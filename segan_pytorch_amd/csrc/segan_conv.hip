@@ -68,7 +68,12 @@ struct TileIter {
   }
   __device__ __forceinline__ bool next(const CorrArgs& a, int nch, TileWork& w) {
     if (tileA < a.sk_nfull) {
-      w.tile = tileA; w.c0 = 0; w.c1 = nch; w.partial = false; w.piece = 0;
+      // whole tiles, one round of gridDim.x (a multiple of 8, or the whole launch) at a time,
+      // each XCD on a contiguous range of the round
+      const int rd = tileA / (int)gridDim.x;
+      const int left = a.sk_nfull - rd * (int)gridDim.x;
+      w.tile = rd * (int)gridDim.x + xcd_remap(blockIdx.x, left < (int)gridDim.x ? left : (int)gridDim.x);
+      w.c0 = 0; w.c1 = nch; w.partial = false; w.piece = 0;
       tileA += gridDim.x;
       return true;
     }
@@ -793,7 +798,8 @@ __global__ __launch_bounds__(256, 2) void conv_dgrad_short_kernel(const ShortArg
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, h = lane >> 5;
-  const int rowtile = blockIdx.x / a.ncoltiles, coltile = blockIdx.x - rowtile * a.ncoltiles;
+  const int vb = xcd_remap(blockIdx.x, gridDim.x);     // every XCD its own range of row tiles
+  const int rowtile = vb / a.ncoltiles, coltile = vb - rowtile * a.ncoltiles;
   const int Ls = a.Ls, L = a.L;
   const int n0 = rowtile * 4;
   const int b0 = coltile * (NB / Ls);

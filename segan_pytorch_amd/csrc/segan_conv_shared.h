@@ -40,6 +40,17 @@ __device__ __forceinline__ void lds_pos_decode(const ColTile& ct, int j, int Tco
   }
 }
 
+// XCD-aware work order.  The hardware places workgroup b of a launch on XCD b % 8, each XCD has
+// its own L2, and consecutive tile indices share a weight row tile: left alone, every XCD's L2
+// fetches every weight tile.  xcd_remap gives XCD x the CONTIGUOUS range of the index space
+// [x*n/8, (x+1)*n/8) instead (a bijection on [0, n) for any n), so a weight row tile is streamed
+// by one XCD (two at a range boundary).  Placement is a speed matter only; nothing depends on it.
+__device__ __forceinline__ int xcd_remap(int b, int n) {
+  const int q = n >> 3, r = n & 7;
+  const int x = b & 7, k = b >> 3;
+  return x * q + (x < r ? x : r) + k;
+}
+
 // ====================================================================================
 // corr kernel
 // ====================================================================================

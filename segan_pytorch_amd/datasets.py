@@ -188,7 +188,8 @@ def build_pcm_shard(clean_dir, noisy_dir, out_prefix, slice_size=2 ** 14, stride
 class PCMShardDataset(Dataset):
     """Items of a pcm16 shard: (uttname, int16 [2, T+1], first flag, slice_idx).  Use with
     `PCMShardCollate`, which turns a batch into the loader's [uttnames, clean, noisy,
-    slice_idx] format with clean/noisy already on the GPU as fp32."""
+    slice_idx] format with clean/noisy already on the GPU as fp32 — or, for the full-rate
+    training loop, with `pcm_shard_loader`, which gathers whole batches in worker processes."""
 
     def __init__(self, prefix):
         with open(prefix + '.json') as f:
@@ -197,8 +198,22 @@ class PCMShardDataset(Dataset):
             raise ValueError('{}.json is not a {} index'.format(prefix, SHARD_MAGIC))
         T = self.meta['slice_size']
         self.slice_size = T
-        self.data = np.memmap(prefix + '.pcm16', dtype=np.int16, mode='r',
-                              shape=(self.meta['n_items'], 2, T + 1))
+        self.prefix = prefix
+        self._data = None
+        self._first = np.asarray(self.meta['first'], dtype=np.uint8)
+        self._sidx = np.asarray(self.meta['slice_idx'], dtype=np.int64)
+
+    @property
+    def data(self):
+        if self._data is None:      # opened lazily: every loader worker maps the file itself
+            self._data = np.memmap(self.prefix + '.pcm16', dtype=np.int16, mode='r',
+                                   shape=(self.meta['n_items'], 2, self.slice_size + 1))
+        return self._data
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d['_data'] = None
+        return d
 
     def __len__(self):
         return self.meta['n_items']
@@ -206,6 +221,64 @@ class PCMShardDataset(Dataset):
     def __getitem__(self, i):
         return (self.meta['names'][i], torch.from_numpy(np.array(self.data[i])),
                 self.meta['first'][i], self.meta['slice_idx'][i])
+
+    def gather(self, indices):
+        """One batch as host tensors [names, int16 pcm [B, 2, T+1], uint8 first [B], slice_idx [B]]
+        in ONE vectorised gather from the memory map (no per-item python work)."""
+        idx = np.asarray(indices, dtype=np.int64)
+        order = np.argsort(idx, kind='stable')          # ascending file offsets, then un-permute
+        pcm = np.empty((len(idx), 2, self.slice_size + 1), dtype=np.int16)
+        pcm[order] = self.data[idx[order]]
+        names = self.meta['names']
+        return [[names[i] for i in idx], torch.from_numpy(pcm), torch.from_numpy(self._first[idx]),
+                torch.from_numpy(self._sidx[idx])]
+
+
+class _BatchIndexDataset(Dataset):
+    """Adapter: DataLoader(batch_size=None) hands a LIST of indices to __getitem__."""
+
+    def __init__(self, shard):
+        self.shard = shard
+
+    def __len__(self):
+        return len(self.shard)
+
+    def __getitem__(self, indices):
+        return self.shard.gather(indices)
+
+
+class PCMShardLoader(object):
+    """The full-rate input pipeline of `train.py --pcm_shard`: whole
+    batches are gathered from the int16 shard by DataLoader WORKER processes (one vectorised
+    gather each, prefetched two batches ahead, pinned by the loader's pin thread); the training
+    process only issues the H2D copy of 20 MB of int16 and the `segan_pcm16_prep` kernel
+    (normalisation + pre-emphasis on the GPU, bit-exact against the reference's host pipeline).
+    Iterates [uttnames, clean[B,T], noisy[B,T], slice_idx[B]] with clean / noisy on the device,
+    like the reference's loader plus its .to(device).  Same shuffling as DataLoader(shuffle=True)
+    (a RandomSampler seeded from torch's global generator), or a DistributedSampler per rank."""
+
+    def __init__(self, shard, batch_size, preemph, device, sampler=None, drop_last=False,
+                 num_workers=2):
+        from torch.utils.data import BatchSampler, DataLoader, RandomSampler
+        self.shard = shard
+        self.sampler = sampler if sampler is not None else RandomSampler(shard)
+        self.preemph = float(preemph)
+        self.device = torch.device(device)
+        self.loader = DataLoader(_BatchIndexDataset(shard), batch_size=None,
+                                 sampler=BatchSampler(self.sampler, batch_size, drop_last),
+                                 num_workers=num_workers, pin_memory=True,
+                                 prefetch_factor=2 if num_workers > 0 else None,
+                                 persistent_workers=num_workers > 0)
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        from . import ops
+        for names, pcm, first, idx in self.loader:
+            clean, noisy = ops.pcm16_prep(pcm.to(self.device, non_blocking=True),
+                                          first.to(self.device, non_blocking=True), self.preemph)
+            yield [names, clean, noisy, idx]
 
 
 class PCMShardCollate(object):

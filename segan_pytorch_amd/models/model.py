@@ -372,8 +372,13 @@ class SEGAN(Model):
                             print('STOPPING SEGAN TRAIN: OUT OF PATIENCE.')
                         break
             if is_main:
+                # asynchronous (core.Saver): the next epoch starts while the files are written
                 self.G.save(self.save_path, iteration, saver=eoe_g_saver)
                 self.D.save(self.save_path, iteration, saver=eoe_d_saver)
+        for sv in (eoe_g_saver, eoe_d_saver):
+            sv.wait()
+        self.G.wait_for_checkpoints()
+        self.D.wait_for_checkpoints()
 
     def evaluate(self, opts, dloader, log_freq, do_noisy=False, max_samples=1, device='cpu'):
         """Objective evaluation on a validation loader (model.py:440-507), on the GPU: G in eval
@@ -567,6 +572,8 @@ class WSEGAN(SEGAN):
             if is_main and iteration % len(dloader) == 0:
                 self.G.save(self.save_path, iteration, saver=eoe_g_saver)
                 self.D.save(self.save_path, iteration, saver=eoe_d_saver)
+        for sv in (eoe_g_saver, eoe_d_saver):
+            sv.wait()
 
     def generate(self, inwav, z=None, device=None):
         """Whole-utterance inference in one fully-convolutional pass (model.py:755-766)."""

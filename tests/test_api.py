@@ -158,6 +158,7 @@ def test_saver_rotation_matches_reference_format(tmp_path):
     sv = Saver(g, str(tmp_path), max_ckpts=2, prefix='EOE_G-')
     for step in (1, 2, 3, 4, 5):
         sv.save('Generator', step)
+    sv.wait()       # writing is asynchronous: join the writer before looking at the files
     idx = json.load(open(os.path.join(str(tmp_path), 'EOE_G-checkpoints')))
     assert idx['current'] == 'EOE_G-Generator-5.ckpt'
     files = sorted(f for f in os.listdir(str(tmp_path)) if f.startswith('weights_'))
@@ -199,3 +200,27 @@ def test_weight_pack_cache_follows_the_optimizer_epoch(monkeypatch):
     ops.bump_weights_epoch()                                 # global invalidation (DP broadcast)
     pack.g(w, 4)
     assert len(calls) == 4
+
+
+def test_async_checkpoint_snapshot_is_taken_at_save_time(tmp_path):
+    """Saver.save returns before the file is written; what is written is the state AT THE CALL,
+    whatever happens to the weights afterwards, in exactly the synchronous format."""
+    import torch
+    from segan_pytorch_amd.models import Generator, Saver
+    g = Generator(1, [4, 8], 31, [4, 4], z_dim=8, skip_merge='concat')
+    want = {k: v.clone() for k, v in g.state_dict().items()}
+    sv = Saver(g, str(tmp_path), prefix='A-')
+    sv.save('Generator', 7)
+    with torch.no_grad():
+        for p in g.parameters():
+            p.add_(1.0)                      # training goes on
+    sv.wait()
+    ck = torch.load(os.path.join(str(tmp_path), 'weights_A-Generator-7.ckpt'), weights_only=False)
+    assert ck['step'] == 7 and list(ck['state_dict'].keys()) == list(want.keys())
+    for k, v in want.items():
+        assert torch.equal(ck['state_dict'][k], v), k
+    sync = Saver(g, str(tmp_path), prefix='S-', async_save=False)
+    sync.save('Generator', 8)
+    ck2 = torch.load(os.path.join(str(tmp_path), 'weights_S-Generator-8.ckpt'), weights_only=False)
+    assert list(ck2['state_dict'].keys()) == list(ck['state_dict'].keys())
+    assert not [f for f in os.listdir(str(tmp_path)) if f.endswith('.tmp')]

@@ -153,11 +153,11 @@ def test_tiny_no_bias_gan_step_matches_reference():
 
 
 @pytest.mark.parametrize('golden', ['tiny_step.pt', 'tiny_s2.pt', 'tiny_nobias.pt'])
-def test_gan_step_in_the_default_reduction_mode(golden):
-    """The same reference steps with the kernels in their DEFAULT mode — the one bench.py times:
-    weight-gradient and dense-head contraction splits added with fp32 atomics instead of in a
-    fixed order (this file's autouse fixture pins everything else to the deterministic mode).
-    Same tolerances: the atomics change only the association of fp32 sums."""
+def test_gan_step_in_the_atomics_reduction_mode(golden):
+    """The same reference steps with the OTHER reduction mode (ops.set_deterministic(False),
+    train.py --atomics): weight-gradient and dense-head contraction splits added with fp32 atomics
+    instead of in a fixed order (the default, which this file's autouse fixture pins).  Same
+    tolerances: the atomics change only the association of fp32 sums."""
     from segan_pytorch_amd import ops
     ops.set_deterministic(False)
     try:
@@ -238,10 +238,10 @@ def _chk(t, c, tol):
 
 @pytest.fixture(autouse=True)
 def deterministic():
-    """Bit-reproducible kernels (ops.set_deterministic) for every test of this file: the
-    comparisons with the reference then give the same numbers on every run and every box — no
-    tolerance is ever met by luck.  The default mode (fp32 atomics in the weight-gradient tail) is
-    what tests/test_gpu_kernels.py and bench.py run."""
+    """Bit-reproducible kernels (ops.set_deterministic, the product default) for every test of
+    this file: the comparisons with the reference then give the same numbers on every run and every
+    box — no tolerance is ever met by luck.  The atomics mode is covered by
+    test_gan_step_in_the_atomics_reduction_mode and tests/test_gpu_kernels.py."""
     from segan_pytorch_amd import ops
     old = ops.get_deterministic()
     ops.set_deterministic(True)
@@ -666,3 +666,36 @@ def test_generator_spectral_norm_matches_reference(tiny_snorm):
         assert max_rel(named[k].grad, gr) < GRAD_TOL, k
     for k, v in g['G_after_fwd'].items():
         assert max_rel(G.state_dict()[k], v) < ACT_TOL, k
+
+
+def test_async_checkpoint_overlaps_training(tiny_step, tmp_path):
+    """Saver.save on a CUDA model returns at once (device-side snapshot + D2H on a side stream +
+    writer thread); GAN steps issued right after it must not leak into the file: it holds the
+    weights and the RMSprop state of the moment of the call, in the reference's payload layout."""
+    import os
+    from segan_pytorch_amd import losses
+    from segan_pytorch_amd.models import Saver
+    fx = tiny_step
+    m = build(fx)
+    Gopt, Dopt = m.build_optimizers(SimpleNamespace(**fx['opts']))
+    m.G.train(); m.D.train()
+    crit = losses.MSELoss()
+    c, n, z = fx['clean'].to(DEV), fx['noisy'].to(DEV), fx['z'].to(DEV)
+    m.gan_step(c, n, Gopt, Dopt, crit, 100.0, z=z)
+    torch.cuda.synchronize()
+    want = {k: v.detach().cpu().clone() for k, v in m.G.state_dict().items()}
+    want_opt = [st['square_avg'].detach().cpu().clone() for st in Gopt.state_dict()['state'].values()]
+    sv = Saver(m.G, str(tmp_path), optimizer=Gopt, prefix='EOE_G-')
+    sv.save('Generator', 3)
+    for _ in range(3):                                   # training goes on while the file is written
+        m.gan_step(c, n, Gopt, Dopt, crit, 100.0, z=z)
+    sv.wait()
+    ck = torch.load(os.path.join(str(tmp_path), 'weights_EOE_G-Generator-3.ckpt'), weights_only=False)
+    assert set(ck.keys()) == {'step', 'state_dict', 'optimizer'} and ck['step'] == 3
+    moved = False
+    for k, v in want.items():
+        assert torch.equal(ck['state_dict'][k], v), k
+        moved = moved or not torch.equal(m.G.state_dict()[k].cpu(), v)
+    assert moved                                          # the live weights did change meanwhile
+    for got, w in zip(ck['optimizer']['state'].values(), want_opt):
+        assert torch.equal(got['square_avg'], w)

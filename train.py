@@ -105,8 +105,11 @@ FLAGS = [
                              'host like the reference (generator.py:197): no host randn + copy per step, '
                              'but not the reference\'s RNG stream')),
     ('--deterministic', dict(action='store_true', default=False,
-                             help='bit-reproducible kernels: ordered reductions instead of fp32 atomics '
-                                  'in the weight gradients (a few percent slower)')),
+                             help='(the default since round 3; kept for old command lines) '
+                                  'bit-reproducible kernels: every reduction in a fixed order')),
+    ('--atomics', dict(action='store_true', default=False,
+                       help='add the weight-gradient / dense-head contraction splits with fp32 atomics '
+                            'instead of in a fixed order: 0.6 %% faster, not run-to-run reproducible')),
     ('--pcm_shard', dict(type=str, default=None,
                          help='prefix of a pre-sliced int16 shard (scripts/make_pcm_shard.py): batches '
                               'are normalised and pre-emphasised on the GPU')),
@@ -142,9 +145,8 @@ def main(opts):
     segan = (WSEGAN if opts.wsegan else SEGAN)(opts)
     if getattr(opts, 'device_z', False):
         segan.G.z_generator = torch.Generator(device=device).manual_seed(opts.seed + rank)
-    if getattr(opts, 'deterministic', False):
-        from segan_pytorch_amd import ops as _ops
-        _ops.set_deterministic(True)
+    from segan_pytorch_amd import ops as _ops
+    _ops.set_deterministic(not getattr(opts, 'atomics', False))
     segan.to(device)
     print('Total model parameters: ', segan.get_n_params())
     if opts.g_pretrained_ckpt is not None:
@@ -154,6 +156,7 @@ def main(opts):
     if opts.h5:
         raise NotImplementedError('--h5 datasets are not implemented')
     collate, workers, pin = collate_fn, opts.num_workers, True
+    pcm_loader = False
     if opts.synthetic > 0:
         dset = SyntheticSEDataset(opts.synthetic, opts.slice_size, seed=opts.seed)
     elif opts.pcm_shard is not None:
@@ -161,8 +164,8 @@ def main(opts):
             raise NotImplementedError('--pcm_shard supports the default pipeline only '
                                       '(no --preemph_norm, no --random_scale)')
         dset = PCMShardDataset(opts.pcm_shard)
-        # the collate launches the GPU normalise/pre-emphasis kernel: main process only
-        collate, workers, pin = PCMShardCollate(opts.preemph, device), 0, False
+        # whole batches gathered by worker processes; the GPU prep kernel runs in this process
+        pcm_loader = True
     else:
         dset = SEDataset(opts.clean_trainset, opts.noisy_trainset, opts.preemph,
                          cache_dir=opts.cache_dir, split='train', stride=opts.data_stride,
@@ -173,9 +176,14 @@ def main(opts):
         from torch.utils.data.distributed import DistributedSampler
         sampler = DistributedSampler(dset, num_replicas=world, rank=rank, shuffle=True,
                                      seed=opts.seed, drop_last=True)
-    dloader = DataLoader(dset, batch_size=opts.batch_size, shuffle=(sampler is None),
-                         sampler=sampler, num_workers=workers, pin_memory=pin,
-                         collate_fn=collate, drop_last=(world > 1))
+    if pcm_loader:
+        from segan_pytorch_amd.datasets import PCMShardLoader
+        dloader = PCMShardLoader(dset, opts.batch_size, opts.preemph, device, sampler=sampler,
+                                 drop_last=(world > 1), num_workers=max(1, min(2, opts.num_workers)))
+    else:
+        dloader = DataLoader(dset, batch_size=opts.batch_size, shuffle=(sampler is None),
+                             sampler=sampler, num_workers=workers, pin_memory=pin,
+                             collate_fn=collate, drop_last=(world > 1))
     va_dloader = None
     if opts.clean_valset is not None:
         # reference train.py:70-91: one pass over a batch of 300 validation slices per epoch.  The
