@@ -23,7 +23,7 @@ python scripts/bench_layers.py --iters 3 > $O/layers_fp32.txt 2>&1
 SEGAN_PRECISION=bf16 python scripts/bench_layers.py --iters 3 > $O/layers_bf16.txt 2>&1
 # SQ counters of single layers (two passes of 8 counters each)
 for p in fp32 bf16; do
-  SEGAN_PRECISION=$p bash scripts/pmc_sq.sh $O/sq_$p enc2 dec2 > /dev/null 2>&1
+  mkdir -p $O/sq_$p; SEGAN_PRECISION=$p bash scripts/pmc_sq.sh $O/sq_$p enc2 dec2 > /dev/null 2>&1
   python scripts/pmc_sq_summary.py $O/sq_$p enc2 dec2 > $O/sq_counters_$p.json 2>/dev/null
   rm -rf $O/sq_$p
 done

@@ -448,37 +448,83 @@ __global__ __launch_bounds__(256, NPL == 1 ? 3 : 2) void corr_bf_kernel(const Co
 // ====================================================================================
 // F: piece (cg,u,g,row) holds channels cv = 16cg+8g+e = (n,r): w[row][n][S*u+r]
 // T: piece (cg,u',g,row=(r,nn)) holds channels m = 16cg+8g+e: w[m][nn][S*(U-1-u')+rho(r)]
-__global__ void pack_bf_kernel(const float* __restrict__ w, __bf16* __restrict__ out,
-                               long plane_stride, int planes, int M, int N, int K, int S, int U,
-                               int RP, int NP, int ngroups, int tform, int pad) {
-  const long npieces = (long)ngroups * U * 2 * RP;
-  for (long pc = blockIdx.x * (long)blockDim.x + threadIdx.x; pc < npieces;
-       pc += (long)gridDim.x * blockDim.x) {
-    const int row = (int)(pc % RP);
-    long t = pc / RP;
-    const int g = (int)(t % 2);
-    t /= 2;
-    const int u = (int)(t % U);
-    const int cg = (int)(t / U);
+//
+// Both are transposes through LDS so that the global reads run along the K taps of consecutive
+// (m, n) rows and the 16-byte piece writes along consecutive rows (round 1's one-thread-per-piece
+// kernel read 8 floats at a stride of N*K per lane: 0.96 ms per step for 1.1 GB of traffic).
+//
+// F form: one block = 64 rows m x one half-group g (8 virtual channels = 8/S real channels),
+// all U taps: reads w[m][n0 .. n0 + 8/S)[0..K) (contiguous per row), writes U x 64 pieces.
+__global__ __launch_bounds__(256) void pack_bf_f_kernel(const float* __restrict__ w,
+                                                        __bf16* __restrict__ out, long plane_stride,
+                                                        int planes, int M, int N, int K, int S, int U,
+                                                        int RP) {
+  extern __shared__ float tf[];                    // [RT rows][W + 1]: (channel in group, tap)
+  const int hg = blockIdx.y;                       // 2*cg + g
+  const int NC = 8 / S;                            // real channels of this half-group
+  const int n0 = hg * NC;
+  const int tid = threadIdx.x;
+  const int W = NC * 32;                           // floats staged per row (taps padded to 32)
+  const int RT = S == 1 ? 32 : 64;                 // rows per block (LDS: RT * (W + 1) floats)
+  const int m0 = blockIdx.x * RT;
+  auto t = [&](int ml, int x) -> float& { return tf[ml * (W + 1) + x]; };
+  for (int e = tid; e < RT * W; e += 256) {
+    const int ml = e / W, x = e - ml * W;
+    const int c = x >> 5, k = x & 31;
+    const int m = m0 + ml, n = n0 + c;
+    t(ml, x) = (m < M && n < N && k < K) ? w[((size_t)m * N + n) * K + k] : 0.0f;
+  }
+  __syncthreads();
+  for (int e = tid; e < U * RT; e += 256) {
+    const int u = e / RT, ml = e - u * RT;
+    if (m0 + ml >= RP) continue;
     bf16x8 pl[3];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int cv = 16 * cg + 8 * g + e;
-      float v = 0.0f;
-      if (!tform) {
-        const int n = cv / S, r = cv % S;
-        const int k = S * u + r;
-        if (row < M && n < N && k < K) v = w[((size_t)row * N + n) * K + k];
-      } else {
-        const int r = row / NP, nn = row % NP;
-        const int rho = (r + pad) % S;
-        const int k = S * (U - 1 - u) + rho;
-        if (r < S && cv < M && nn < N && k < K) v = w[((size_t)cv * N + nn) * K + k];
-      }
+    for (int q = 0; q < 8; ++q) {
+      const int c = q / S, r = q % S;              // virtual channel q of the half-group = (c, r)
       __bf16 p1, p2, p3;
-      split3(v, p1, p2, p3);
-      pl[0][e] = p1; pl[1][e] = p2; pl[2][e] = p3;
+      split3(t(ml, c * 32 + S * u + r), p1, p2, p3);
+      pl[0][q] = p1; pl[1][q] = p2; pl[2][q] = p3;
     }
+    const long pc = ((long)((hg >> 1) * U + u) * 2 + (hg & 1)) * RP + m0 + ml;
+    for (int p = 0; p < planes; ++p)
+      *reinterpret_cast<u32x4*>(out + p * plane_stride + pc * 8) = __builtin_bit_cast(u32x4, pl[p]);
+  }
+}
+
+// T form: one block = 8 channels m (one half-group) x 64 output channels nn, all taps: reads
+// w[m][nn0 .. nn0+64)[0..K) (one contiguous run per m), writes (U taps x S phases) x 64 pieces.
+__global__ __launch_bounds__(256) void pack_bf_t_kernel(const float* __restrict__ w,
+                                                        __bf16* __restrict__ out, long plane_stride,
+                                                        int planes, int M, int N, int K, int S, int U,
+                                                        int RP, int NP, int pad) {
+  __shared__ float t[8][32 * 33];                 // [m][nn (pitch 33)][tap]
+  const int hg = blockIdx.y;
+  const int nn0 = blockIdx.x * 32;
+  const int tid = threadIdx.x;
+  for (int e = tid; e < 8 * 32 * 32; e += 256) {
+    const int ml = e >> 10, x = e & 1023;
+    const int nl = x >> 5, k = x & 31;
+    const int m = 8 * hg + ml, nn = nn0 + nl;
+    t[ml][nl * 33 + k] = (m < M && nn < N && k < K) ? w[((size_t)m * N + nn) * K + k] : 0.0f;
+  }
+  __syncthreads();
+  for (int e = tid; e < U * S * 32; e += 256) {
+    const int nl = e & 31;
+    const int ur = e >> 5;                        // u' * S + r
+    const int up = ur / S, r = ur - up * S;
+    const int nn = nn0 + nl;
+    if (nn >= NP) continue;
+    const int rho = (r + pad) % S;
+    const int k = S * (U - 1 - up) + rho;
+    bf16x8 pl[3];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      __bf16 p1, p2, p3;
+      split3(t[q][nl * 33 + k], p1, p2, p3);
+      pl[0][q] = p1; pl[1][q] = p2; pl[2][q] = p3;
+    }
+    const long pc = ((long)((hg >> 1) * U + up) * 2 + (hg & 1)) * RP + (long)r * NP + nn;
     for (int p = 0; p < planes; ++p)
       *reinterpret_cast<u32x4*>(out + p * plane_stride + pc * 8) = __builtin_bit_cast(u32x4, pl[p]);
   }
@@ -509,9 +555,16 @@ extern "C" int segan_pack_weights_bf(const float* w, void* out, int M, int N, in
   const int ng = tform ? ceil_div(M, 16) : ceil_div(N * S, 16);
   const long npieces = (long)ng * U * 2 * RP;
   const long plane_stride = npieces * 8;
-  const int blocks = (int)((npieces + 255) / 256 > 8192 ? 8192 : (npieces + 255) / 256);
-  hipLaunchKernelGGL(pack_bf_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w,
-                     (__bf16*)out, plane_stride, planes, M, N, K, S, U, RP, NP, ng, tform, pad_t);
+  hipStream_t st = (hipStream_t)stream;
+  if (!tform) {
+    const int RT = S == 1 ? 32 : 64;
+    const size_t lds = (size_t)RT * ((8 / S) * 32 + 1) * sizeof(float);
+    hipLaunchKernelGGL(pack_bf_f_kernel, dim3(RP / RT, 2 * ng), dim3(256), lds, st, w, (__bf16*)out,
+                       plane_stride, planes, M, N, K, S, U, RP);
+  } else {
+    hipLaunchKernelGGL(pack_bf_t_kernel, dim3(ceil_div(NP, 32), 2 * ng), dim3(256), 0, st, w,
+                       (__bf16*)out, plane_stride, planes, M, N, K, S, U, RP, NP, pad_t);
+  }
   return segan_check_launch("pack_weights_bf");
 }
 
