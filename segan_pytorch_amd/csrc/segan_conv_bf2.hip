@@ -349,6 +349,30 @@ struct Bf2Extra {
   int dbg;              // experiments (SEGAN_BF2_DBG): 1 = no DMA after a tile's first stage, 2 = no MFMA loop
 };
 
+// stages the DMA runs ahead of the MFMAs.  Measured (scripts/bench_layers.py, bf16): 2 stages ahead
+// with three weight buffers (two workgroups per CU) or with half-size stages (four per CU) give the
+// same total as 1 stage ahead at three per CU — the loop is not latency-bound — so the shallow form stays
+#define BF2_LOOK(NPL) 1
+
+// s_waitcnt vmcnt(n) for a run-time n (the instruction takes an immediate): loads — LDS-DMA
+// included — return in order, so "at most n outstanding" = all but the newest n have landed
+__device__ __forceinline__ void bf2_wait_vm(int n) {
+  switch (n) {
+    case 0: __builtin_amdgcn_s_waitcnt(0x0f70); break;
+    case 1: __builtin_amdgcn_s_waitcnt(0x0f71); break;
+    case 2: __builtin_amdgcn_s_waitcnt(0x0f72); break;
+    case 3: __builtin_amdgcn_s_waitcnt(0x0f73); break;
+    case 4: __builtin_amdgcn_s_waitcnt(0x0f74); break;
+    case 5: __builtin_amdgcn_s_waitcnt(0x0f75); break;
+    case 6: __builtin_amdgcn_s_waitcnt(0x0f76); break;
+    case 7: __builtin_amdgcn_s_waitcnt(0x0f77); break;
+    case 8: __builtin_amdgcn_s_waitcnt(0x0f78); break;
+    case 9: __builtin_amdgcn_s_waitcnt(0x0f79); break;
+    case 10: __builtin_amdgcn_s_waitcnt(0x0f7a); break;
+    default: __builtin_amdgcn_s_waitcnt(0x0f70); break;
+  }
+}
+
 template <int MB, int NB, int WM, int U, bool OUT_HI, int SHIFTMASK, int NPL, int TU>
 __global__ __launch_bounds__(256, (NPL == 1 && NB == 128) ? 3 : 2) void corr_bf2_kernel(const CorrArgs a, const Bf2Extra x) {
   constexpr int S = 32 / U;
@@ -363,12 +387,15 @@ __global__ __launch_bounds__(256, (NPL == 1 && NB == 128) ? 3 : 2) void corr_bf2
   static_assert(!OUT_HI || WM == 1, "T form: one wave holds all phases");
   constexpr int WPIECES = NPL * TU * 2 * MB;       // per buffer
   constexpr int WINS = NPL * TU * 2 * 2;           // DMA instructions per weight stage
+  constexpr int LOOK = BF2_LOOK(NPL);              // DMA look-ahead in stages (NBUF weight buffers)
+  constexpr int NBUF = LOOK + 1;
+  static_assert(U / TU >= LOOK, "an activation tile must outlive the look-ahead");
   static_assert(WINS % 4 == 0, "weight instructions divide among the 4 waves");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int RLs = a.RLs;                 // padded to a multiple of 64
-  u32x4* Wl0 = reinterpret_cast<u32x4*>(smem_raw);       // [2][NPL][TU][2][MB]
-  u32x4* Il0 = Wl0 + 2 * WPIECES;                          // [2][NPL][2][RLs]
+  u32x4* Wl0 = reinterpret_cast<u32x4*>(smem_raw);       // [NBUF][NPL][TU][2][MB]
+  u32x4* Il0 = Wl0 + NBUF * WPIECES;                       // [2][NPL][2][RLs]
   const int IPIECES = NPL * 2 * RLs;
 
   const int tid = threadIdx.x;
@@ -497,21 +524,27 @@ __global__ __launch_bounds__(256, (NPL == 1 && NB == 128) ? 3 : 2) void corr_bf2
     }
   };
 
-  {
-    const int cg0 = c0 / TCH;
-    dma_i(cg0, cg0 & 1);
-    dma_w(c0, 0);
-    __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0)
-    __syncthreads();
-  }
+  // DMA instructions this wave issues per stage: the weights, plus the activation tile when the
+  // stage opens a channel group
+  int cnt_i = 0;
+#pragma unroll
+  for (int k = 0; k < KI; ++k) cnt_i += (ib + 2 * k < x.nld) ? NPL : 0;
+  auto issue = [&](int st) __attribute__((always_inline)) {      // everything stage `st` needs
+    if (st % TCH == 0 || st == c0) dma_i(st / TCH, (st / TCH) & 1);
+    dma_w(st, (st - c0) % NBUF);
+  };
+  auto group = [&](int st) { return WINS / 4 + ((st % TCH == 0) ? cnt_i : 0); };
+  issue(c0);
+  if (LOOK > 1 && c0 + 1 < c1) issue(c0 + 1);
+  // (the epilogue stores of the previous tile may still be in flight and complete out of order
+  // with loads: a full drain here, partial waits only inside the loop)
+  __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0)
+  __syncthreads();
   for (int st = c0; st < c1; ++st) {
-    const int buf = (st - c0) & 1;
+    const int buf = (st - c0) % NBUF;
     const int cg = st / TCH, tc = st - cg * TCH;
-    const bool more = st + 1 < c1;
-    if (more && !(x.dbg & 1)) {
-      dma_w(st + 1, buf ^ 1);
-      if ((st + 1) % TCH == 0) dma_i(cg + 1, (cg + 1) & 1);
-    }
+    const bool ahead = st + LOOK < c1 && !(x.dbg & 1);
+    if (ahead) issue(st + LOOK);
     const u32x4* Wl = Wl0 + buf * WPIECES;
     const u32x4* Il = Il0 + (cg & 1) * IPIECES;
     if (!(x.dbg & 2))
@@ -550,7 +583,8 @@ __global__ __launch_bounds__(256, (NPL == 1 && NB == 128) ? 3 : 2) void corr_bf2
         }
       }
     }
-    __builtin_amdgcn_s_waitcnt(0x0f70);      // the next stage's DMA has landed
+    // the NEXT stage's DMA has landed: only the group issued above may still be outstanding
+    bf2_wait_vm((LOOK > 1 && ahead) ? group(st + LOOK) : 0);
     __syncthreads();
   }
 
@@ -654,7 +688,7 @@ static int launch_bf2(CorrArgs a, Bf2Extra x, hipStream_t st) {
     segan_set_error("corr_bf2: window of %d positions too long", a.RLv);
     return SEGAN_EUNSUPPORTED;
   }
-  const size_t lds = (size_t)(2 * NPL * TU * 2 * MB + 2 * NPL * 2 * a.RLs) * 16;
+  const size_t lds = (size_t)((BF2_LOOK(NPL) + 1) * NPL * TU * 2 * MB + 2 * NPL * 2 * a.RLs) * 16;
   auto kern = corr_bf2_kernel<MB, NB, WM, U, OUT_HI, SHIFTMASK, NPL, TU>;
   static bool attr_done[16];
   static int occ[16];
