@@ -207,8 +207,8 @@ def hip_step_parity(ref, opts, gsd0, dsd0, clean, noisy, z, rolls, dev, precisio
         g_grad = max(_rel(gn[k].grad, g) for k, g in ref['g_grads'].items())
         out = {
             'batch': int(clean.size(0)), 'precision': precision,
-            'reduction_mode': 'deterministic (fixed-order reductions: the default and the timed mode)'
-                              if deterministic else 'fp32 atomics in the weight-gradient / dense-head splits',
+            'reduction_mode': 'deterministic (fixed-order reductions)' if deterministic else
+                              'default (fp32 atomics in the weight-gradient / dense-head splits: the timed mode)',
             'g_mse': ((y - yr) ** 2).mean().item(), 'g_max_abs': (y - yr).abs().max().item(),
             'd_real_loss_rel': _lrel(d_real, ref['d_real_loss']),
             'd_fake_loss_rel': _lrel(d_fake, ref['d_fake_loss']),
@@ -226,8 +226,8 @@ PARITY_NOTE = ('HIP step vs the CPU oracle step timed above, same weights / inpu
                'generator phase through the oracle\'s post-step D; gradient figures are relative L2 per '
                'tensor (ReLU-gate flips at fp32 roundoff bound them, tests/test_gpu_kernels.py::'
                'test_discriminator_batchnorm_at_batch_300); `parity` = fp32 in the deterministic mode '
-               '(the default and timed mode), `parity_atomics_mode` = fp32 with the atomics reductions, '
-               'other_precisions.*.parity = the bf16x3 / bf16 contractions')
+               '(bit-reproducible), `parity_default_mode` = fp32 in the timed (atomics) mode, '
+               'other_precisions.*.parity = the bf16x3 / bf16 contractions in the timed mode')
 
 
 def cpu_baseline(B=300, steps=2, dev=None, modes=('bf16x3', 'bf16')):
@@ -280,8 +280,8 @@ def cpu_baseline(B=300, steps=2, dev=None, modes=('bf16x3', 'bf16')):
                                       ['%.2f' % t for t in results['onednn_on']], best))
     parity = {}
     if dev is not None and ref is not None:
-        for name, prec, det in (('fp32_deterministic', 'fp32', True), ('fp32_atomics', 'fp32', False)) + \
-                tuple((p, p, True) for p in modes):
+        for name, prec, det in (('fp32_deterministic', 'fp32', True), ('fp32_default', 'fp32', False)) + \
+                tuple((p, p, False) for p in modes):
             try:
                 parity[name] = hip_step_parity(ref, opts, gsd0, dsd0, clean, noisy, z, rolls, dev,
                                                prec, det)
@@ -324,7 +324,7 @@ def wsegan_parity(opts, B, dev):
                 kind='port', sample='oracle WSEGAN step (--misalign_pair) at batch {}: warm-up at batch '
                                     '4, ONE timed step, oneDNN off: {:.2f} s'.format(B, dt))
     out = {}
-    for name, det in (('fp32_deterministic', True), ('fp32_atomics', False)):
+    for name, det in (('fp32_deterministic', True), ('fp32_default', False)):
         old = ops.get_deterministic()
         ops.set_deterministic(det)
         try:
@@ -557,8 +557,8 @@ def main():
     finite = all(bool(torch.isfinite(x)) for x in losses_out)
 
     # what reproducibility costs: the same K steps in the OTHER reduction mode (the default —
-    # and the timed one — is the deterministic mode; the other adds the weight-gradient /
-    # dense-head contraction splits with fp32 atomics)
+    # and the timed one — adds the weight-gradient / dense-head contraction splits with fp32
+    # atomics; the deterministic mode adds them in a fixed order)
     ms_other = None
     timed_det = _ops.get_deterministic()
     if not args.no_modes:
@@ -654,8 +654,8 @@ def main():
                        'z': 'device generator' if args.device_z else 'host randn + H2D per step (as train.py)'},
             'losses_finite': finite,
             'precision': args.precision,
-            'reduction_mode': ('deterministic (fixed-order reductions: the default)' if timed_det else
-                               'fp32 atomics in the weight-gradient / dense-head splits (SEGAN_DETERMINISTIC=0)'),
+            'reduction_mode': ('deterministic (fixed-order reductions, SEGAN_DETERMINISTIC=1)' if timed_det else
+                               'default: fp32 atomics in the weight-gradient / dense-head contraction splits'),
             'ms_per_step_deterministic': ms if timed_det else ms_other,
             'ms_per_step_atomics': ms_other if timed_det else ms,
             'gflop_per_chunk': gflop,
@@ -710,7 +710,7 @@ def main():
                 line['speedup_vs_cpu_baseline'] = value / line['cpu_baseline']['value']
                 if parity:
                     line['parity'] = dict(parity.get('fp32_deterministic', {}), note=PARITY_NOTE)
-                    line['parity_atomics_mode'] = parity.get('fp32_atomics')
+                    line['parity_default_mode'] = parity.get('fp32_default')
                     for k in ('bf16x3', 'bf16'):
                         if k in parity and k in line.get('other_precisions', {}):
                             line['other_precisions'][k]['parity'] = parity[k]
@@ -726,7 +726,7 @@ def main():
                                       note='HIP WSEGAN step vs the oracle WSEGAN step timed above (same '
                                            'weights / inputs / z / phase shifts / misalign permutation; '
                                            'generator phase through the oracle\'s post-step D)')
-                line['parity_atomics_mode'] = par.get('fp32_atomics')
+                line['parity_default_mode'] = par.get('fp32_default')
             except Exception as e:
                 line['cpu_baseline'] = {'error': repr(e)}
         print(json.dumps(line))

@@ -43,4 +43,23 @@ for layer in layers:
             'lds_bank_conflict_over_idx_active': c.get('SQ_LDS_BANK_CONFLICT', 0) / (c.get('SQ_LDS_IDX_ACTIVE', 0) or 1.0),
             'raw': dict(c),
         }
+
+def add_summary(res):
+    """mfma_pipe_busy per kernel family = SQ_VALU_MFMA_BUSY_CYCLES / (32 x SQ_BUSY_CYCLES): the first counts
+    MFMA-pipe cycles summed over the 1024 SIMDs (64 per fp32 MFMA, 32 per bf16 MFMA: checked against
+    SQ_INSTS_MFMA), the second the busy cycles summed over the 32 shader engines (checked against the kernel
+    durations), so 32 x SQ_BUSY_CYCLES is the SIMD-cycles of the launch AT THE CLOCK IT RAN AT."""
+    fam = {'corr2': 'corr2_kernel', 'wgrad2': 'wgrad2_kernel', 'conv_dgrad_short': 'conv_dgrad_short_kernel',
+           'corr_bf2': 'corr_bf2_kernel', 'wgrad_bf2': 'wgrad_bf2_kernel'}
+    out = {'note': add_summary.__doc__.replace('\n    ', ' ')}
+    for name, key in fam.items():
+        v = [k['raw']['SQ_VALU_MFMA_BUSY_CYCLES'] / (32.0 * k['raw']['SQ_BUSY_CYCLES'])
+             for layer in res.values() if isinstance(layer, dict) for kn, k in layer.items()
+             if key in kn and k['raw'].get('SQ_BUSY_CYCLES')]
+        if v:
+            out[name + '_mfma_pipe_busy_mean'] = sum(v) / len(v)
+    res['_summary'] = out
+
+
+add_summary(res)
 json.dump(res, sys.stdout, indent=1)

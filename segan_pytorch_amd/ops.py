@@ -22,15 +22,16 @@ _precision = _PREC_NAMES[_os.environ.get('SEGAN_PRECISION', 'fp32')]
 _EUNSUPPORTED = -3
 
 
-_deterministic = _os.environ.get('SEGAN_DETERMINISTIC', '1') != '0'
+_deterministic = _os.environ.get('SEGAN_DETERMINISTIC', '0') == '1'
 
 
 def set_deterministic(on):
-    """Bit-reproducible mode — the DEFAULT since round 3 (measured cost: 0.6 % of the step).  The
-    forward / data-gradient contractions always are reproducible (their stream-K tail is reduced in
-    a fixed order); this switch makes the weight gradients and the dense-head GEMMs reduce their
-    contraction splits in a fixed order too (slabs + a second kernel) instead of with fp32
-    atomics.  ``set_deterministic(False)`` / SEGAN_DETERMINISTIC=0 selects the atomics.  (The
+    """Bit-reproducible mode.  The forward / data-gradient contractions always are reproducible
+    (their stream-K tail is reduced in a fixed order); this switch makes the weight gradients and
+    the dense-head GEMMs reduce their contraction splits in a fixed order too (slabs + a second
+    kernel) instead of with fp32 atomics.  Measured cost since round 3: 0.6 - 2.2 % of the step
+    (round 2: 11 %) — just above the 1 % at which it would have become the default, so it stays
+    opt-in: ``set_deterministic(True)`` / SEGAN_DETERMINISTIC=1 / train.py --deterministic.  (The
     bf16 / bf16x3 weight gradients always add their splits with atomics.)"""
     global _deterministic
     _deterministic = bool(on)

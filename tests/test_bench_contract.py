@@ -34,11 +34,11 @@ def test_committed_bench_line_has_the_contract_fields():
     assert pr['batch'] == 300 and pr['g_mse'] < 1e-4 and pr['g_max_abs'] < 1e-5
     assert max(pr['d_real_loss_rel'], pr['d_fake_loss_rel'], pr['g_adv_loss_rel'], pr['g_l1_loss_rel']) < 1e-4
     if name >= 'r03':
-        # from round 3 on: the timed mode is the deterministic one, the atomics mode and the bf16
-        # modes are compared with the oracle at the benchmarked batch too, and both are timed
-        pd = d['parity_atomics_mode']
+        # from round 3 on: the timed (atomics) mode, the deterministic mode and the bf16 modes are all
+        # compared with the oracle at the benchmarked batch, and both reduction modes are timed
+        pd = d['parity_default_mode']
         assert pd['batch'] == 300 and pd['g_mse'] < 1e-4 and pd['g_max_abs'] < 1e-5
-        assert 'deterministic' in d['reduction_mode'] and d['ms_per_step_atomics'] > 0
+        assert d['ms_per_step_atomics'] == d['ms_per_step'] and d['ms_per_step_deterministic'] > 0
         for k, mse_tol in (('bf16x3', 1e-9), ('bf16', 1e-4)):
             pp = d['other_precisions'][k]['parity']
             assert pp['batch'] == 300 and pp['g_mse'] < mse_tol, k

@@ -153,11 +153,11 @@ def test_tiny_no_bias_gan_step_matches_reference():
 
 
 @pytest.mark.parametrize('golden', ['tiny_step.pt', 'tiny_s2.pt', 'tiny_nobias.pt'])
-def test_gan_step_in_the_atomics_reduction_mode(golden):
-    """The same reference steps with the OTHER reduction mode (ops.set_deterministic(False),
-    train.py --atomics): weight-gradient and dense-head contraction splits added with fp32 atomics
-    instead of in a fixed order (the default, which this file's autouse fixture pins).  Same
-    tolerances: the atomics change only the association of fp32 sums."""
+def test_gan_step_in_the_default_reduction_mode(golden):
+    """The same reference steps with the kernels in their DEFAULT mode — the one bench.py times:
+    weight-gradient and dense-head contraction splits added with fp32 atomics instead of in a
+    fixed order (this file's autouse fixture pins everything else to the deterministic mode).
+    Same tolerances: the atomics change only the association of fp32 sums."""
     from segan_pytorch_amd import ops
     ops.set_deterministic(False)
     try:
@@ -238,10 +238,11 @@ def _chk(t, c, tol):
 
 @pytest.fixture(autouse=True)
 def deterministic():
-    """Bit-reproducible kernels (ops.set_deterministic, the product default) for every test of
-    this file: the comparisons with the reference then give the same numbers on every run and every
-    box — no tolerance is ever met by luck.  The atomics mode is covered by
-    test_gan_step_in_the_atomics_reduction_mode and tests/test_gpu_kernels.py."""
+    """Bit-reproducible kernels (ops.set_deterministic) for every test of this file: the
+    comparisons with the reference then give the same numbers on every run and every box — no
+    tolerance is ever met by luck.  The default mode (fp32 atomics in the weight-gradient tail) is
+    covered by test_gan_step_in_the_default_reduction_mode, tests/test_gpu_kernels.py and the
+    bench line's `parity_default_mode`."""
     from segan_pytorch_amd import ops
     old = ops.get_deterministic()
     ops.set_deterministic(True)

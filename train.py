@@ -105,11 +105,9 @@ FLAGS = [
                              'host like the reference (generator.py:197): no host randn + copy per step, '
                              'but not the reference\'s RNG stream')),
     ('--deterministic', dict(action='store_true', default=False,
-                             help='(the default since round 3; kept for old command lines) '
-                                  'bit-reproducible kernels: every reduction in a fixed order')),
-    ('--atomics', dict(action='store_true', default=False,
-                       help='add the weight-gradient / dense-head contraction splits with fp32 atomics '
-                            'instead of in a fixed order: 0.6 %% faster, not run-to-run reproducible')),
+                             help='bit-reproducible kernels: the weight-gradient and dense-head contraction '
+                                  'splits are added in a fixed order instead of with fp32 atomics '
+                                  '(1-2 %% slower)')),
     ('--pcm_shard', dict(type=str, default=None,
                          help='prefix of a pre-sliced int16 shard (scripts/make_pcm_shard.py): batches '
                               'are normalised and pre-emphasised on the GPU')),
@@ -145,8 +143,9 @@ def main(opts):
     segan = (WSEGAN if opts.wsegan else SEGAN)(opts)
     if getattr(opts, 'device_z', False):
         segan.G.z_generator = torch.Generator(device=device).manual_seed(opts.seed + rank)
-    from segan_pytorch_amd import ops as _ops
-    _ops.set_deterministic(not getattr(opts, 'atomics', False))
+    if getattr(opts, 'deterministic', False):
+        from segan_pytorch_amd import ops as _ops
+        _ops.set_deterministic(True)
     segan.to(device)
     print('Total model parameters: ', segan.get_n_params())
     if opts.g_pretrained_ckpt is not None:
