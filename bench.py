@@ -171,7 +171,8 @@ def _lrel(a, b):
     return abs(float(a) - float(b)) / max(abs(float(b)), 1e-30)
 
 
-def hip_step_parity(ref, opts, gsd0, dsd0, clean, noisy, z, rolls, dev, precision, deterministic):
+def hip_step_parity(ref, opts, gsd0, dsd0, clean, noisy, z, rolls, dev, precision, deterministic,
+                    accumulation='plain'):
     """One HIP GAN step from (gsd0, dsd0) on (clean, noisy, z, rolls) in the given contraction
     precision / reduction mode against the oracle step `ref` from the same state: generator
     output, the four losses, gradients per tensor (relative L2, worst tensor).  The generator
@@ -179,9 +180,10 @@ def hip_step_parity(ref, opts, gsd0, dsd0, clean, noisy, z, rolls, dev, precisio
     ill-conditioned where |g| is at roundoff level: DESIGN.md section 6)."""
     from segan_pytorch_amd import losses, ops
     from segan_pytorch_amd.models import SEGAN
-    old_d, old_p = ops.get_deterministic(), ops.get_precision()
+    old_d, old_p, old_a = ops.get_deterministic(), ops.get_precision(), ops.get_accumulation()
     ops.set_deterministic(deterministic)
     ops.set_precision(precision)
+    ops.set_accumulation(accumulation)
     try:
         mm = SEGAN(SimpleNamespace(**opts))
         mm.G.load_state_dict(gsd0)
@@ -206,7 +208,7 @@ def hip_step_parity(ref, opts, gsd0, dsd0, clean, noisy, z, rolls, dev, precisio
         gn = dict(mm.G.named_parameters())
         g_grad = max(_rel(gn[k].grad, g) for k, g in ref['g_grads'].items())
         out = {
-            'batch': int(clean.size(0)), 'precision': precision,
+            'batch': int(clean.size(0)), 'precision': precision, 'accumulation': accumulation,
             'reduction_mode': 'deterministic (fixed-order reductions)' if deterministic else
                               'default (fp32 atomics in the weight-gradient / dense-head splits: the timed mode)',
             'g_mse': ((y - yr) ** 2).mean().item(), 'g_max_abs': (y - yr).abs().max().item(),
@@ -220,6 +222,7 @@ def hip_step_parity(ref, opts, gsd0, dsd0, clean, noisy, z, rolls, dev, precisio
     finally:
         ops.set_deterministic(old_d)
         ops.set_precision(old_p)
+        ops.set_accumulation(old_a)
 
 
 PARITY_NOTE = ('HIP step vs the CPU oracle step timed above, same weights / inputs / z / phase shifts; '
@@ -227,7 +230,9 @@ PARITY_NOTE = ('HIP step vs the CPU oracle step timed above, same weights / inpu
                'tensor (ReLU-gate flips at fp32 roundoff bound them, tests/test_gpu_kernels.py::'
                'test_discriminator_batchnorm_at_batch_300); `parity` = fp32 in the deterministic mode '
                '(bit-reproducible), `parity_default_mode` = fp32 in the timed (atomics) mode, '
-               'other_precisions.*.parity = the bf16x3 / bf16 contractions in the timed mode')
+               'other_precisions.*.parity = the bf16x3 / bf16 contractions in the timed mode; '
+               '`parity_blocked_accumulation` = fp32 with ops.set_accumulation(\'blocked\') '
+               '(SEGAN_PREC_FP32_BLOCKED, opt-in: timed as ms_per_step_blocked_accumulation)')
 
 
 def cpu_baseline(B=300, steps=2, dev=None, modes=('bf16x3', 'bf16')):
@@ -280,11 +285,13 @@ def cpu_baseline(B=300, steps=2, dev=None, modes=('bf16x3', 'bf16')):
                                       ['%.2f' % t for t in results['onednn_on']], best))
     parity = {}
     if dev is not None and ref is not None:
-        for name, prec, det in (('fp32_deterministic', 'fp32', True), ('fp32_default', 'fp32', False)) + \
-                tuple((p, p, False) for p in modes):
+        for name, prec, det, acc in (('fp32_deterministic', 'fp32', True, 'plain'),
+                                     ('fp32_default', 'fp32', False, 'plain'),
+                                     ('fp32_blocked', 'fp32', False, 'blocked')) + \
+                tuple((p, p, False, 'plain') for p in modes):
             try:
                 parity[name] = hip_step_parity(ref, opts, gsd0, dsd0, clean, noisy, z, rolls, dev,
-                                               prec, det)
+                                               prec, det, acc)
             except Exception as e:      # a parity leg must never cost the bench line
                 parity[name] = {'error': repr(e)}
     return out, parity
@@ -580,6 +587,28 @@ def main():
         finally:
             _ops.set_deterministic(timed_det)
 
+    # the fp32 step with blocked accumulation (ops.set_accumulation: 5x lower forward error for
+    # one resident wave per SIMD), timed beside the headline
+    ms_blocked = None
+    if args.precision == 'fp32' and not args.no_modes:
+        _ops.set_accumulation('blocked')
+        try:
+            for _ in range(2):
+                one_step()
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                one_step()
+            barrier()
+            dd = time.perf_counter() - t1
+            if world > 1:
+                t = torch.tensor([dd], device=dev, dtype=torch.float64)
+                torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+                dd = float(t.item())
+            ms_blocked = 1e3 * dd / args.steps
+        finally:
+            _ops.set_accumulation('plain')
+
     # Same step with the contractions on the bf16 matrix cores, reported BESIDE the fp32
     # headline (never as `value`): 'bf16x3' = exact 3-way split of the fp32 operands,
     # 'bf16' = BASELINE config 5.  Every rank runs the same steps (the collectives match).
@@ -658,6 +687,8 @@ def main():
                                'default: fp32 atomics in the weight-gradient / dense-head contraction splits'),
             'ms_per_step_deterministic': ms if timed_det else ms_other,
             'ms_per_step_atomics': ms_other if timed_det else ms,
+            'ms_per_step_blocked_accumulation': ms_blocked,
+            'accumulation': _ops.get_accumulation(),
             'gflop_per_chunk': gflop,
             'gflop_per_chunk_executed': gflop_exec,
             'step_tflops': gflop * value / 1e3,
@@ -711,6 +742,7 @@ def main():
                 if parity:
                     line['parity'] = dict(parity.get('fp32_deterministic', {}), note=PARITY_NOTE)
                     line['parity_default_mode'] = parity.get('fp32_default')
+                    line['parity_blocked_accumulation'] = parity.get('fp32_blocked')
                     for k in ('bf16x3', 'bf16'):
                         if k in parity and k in line.get('other_precisions', {}):
                             line['other_precisions'][k]['parity'] = parity[k]

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SEGAN_ABI_VERSION 10
+#define SEGAN_ABI_VERSION 11
 
 #define SEGAN_PAD_REFLECT 0
 #define SEGAN_PAD_ZERO 1
@@ -80,6 +80,14 @@ int segan_pack_weights(const float* w, float* wf, float* wt, int M, int N, int K
 #define SEGAN_PREC_FP32 0
 #define SEGAN_PREC_BF16 1
 #define SEGAN_PREC_BF16X3 3
+/* fp32 with BLOCKED accumulation: the contraction runs into the MFMA accumulators for 256 terms
+ * at a time and the block sums are added in a second register set, so the rounding error grows
+ * with sqrt(256) + sqrt(K/256) instead of sqrt(K): forward error against fp64 3e-7 instead of
+ * 1.5-2.2e-6 on the deep layers (tests/diag/diag_accum.py), at two instead of three resident
+ * waves per SIMD (~3 % of the contraction rate).  Same packed weights as SEGAN_PREC_FP32;
+ * built for stride 4, other strides run the plain kernels.  Not a mode of segan_wgrad (its
+ * contractions are split into short pieces already). */
+#define SEGAN_PREC_FP32_BLOCKED 4
 size_t segan_packed_bf_bytes(int M, int N, int S, int tform, int planes);
 int segan_pack_weights_bf(const float* w, void* out, int M, int N, int K, int S, int tform,
                           int pad_t, int planes, void* stream);

@@ -8,13 +8,13 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libsegan_hip.so')
+LIB_PATH = os.environ.get('SEGAN_HIP_LIB') or os.path.join(_HERE, 'libsegan_hip.so')   # override: A/B of two builds
 
 PAD_REFLECT = 0
 PAD_ZERO = 1
 ACT_NONE = 0
 ACT_TANH = 1
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class SeganSrc(Structure):

@@ -26,6 +26,27 @@ int segan_check_launch(const char* what);
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Blocked accumulation of the fp32 contractions.  One MFMA accumulator summed over a whole
+// contraction (up to 63 488 terms: 31 744 sequential roundings) carries a forward error of
+// ~4e-6 against fp64, four times what a blocked CPU sum leaves.  The big kernels therefore
+// run the matrix cores into `acc` for SEGAN_ACC_BLOCK chunks (8 x 32 = 256 terms), add that
+// block to a second register set and restart `acc` from zero: the rounding error grows with
+// sqrt(256/2) + sqrt(K/256) instead of sqrt(K/2).  64 VALU adds + 64 moves per block of 512
+// MFMAs per wave; the second set fits the 256-register budget of 2 waves per SIMD.
+#define SEGAN_ACC_BLOCK 8
+
+template <int NI, int NJ>
+__device__ __forceinline__ void acc_block_flush(f32x16 (&acc)[NI][NJ], f32x16 (&sum)[NI][NJ]) {
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      sum[i][j] += acc[i][j];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+    }
+}
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
 

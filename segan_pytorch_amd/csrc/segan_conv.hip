@@ -574,7 +574,7 @@ __device__ __forceinline__ float buf_load_f32(__amdgpu_buffer_rsrc_t r, int voff
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
 
-template <int MB, int NB, int WM, int U, bool IN_HI, bool OUT_HI, bool SHIFT, bool XF>
+template <int MB, int NB, int WM, int U, bool IN_HI, bool OUT_HI, bool SHIFT, bool XF, bool BLK = false>
 __global__ __launch_bounds__(256, 2) void corr2_kernel(const CorrArgs a) {
   using G = TileGeom<MB, NB, WM, U>;
   constexpr int S = G::S, WN = G::WN, NI = G::NI, NJ = G::NJ, NPT = G::NPT;
@@ -679,6 +679,18 @@ __global__ __launch_bounds__(256, 2) void corr2_kernel(const CorrArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
+  // BLK: blocked accumulation (segan_common.h) — a second register set, so 2 instead of 3
+  // waves per SIMD; without it `accs` is never touched and disappears
+  f32x16 accs[BLK ? NI : 1][BLK ? NJ : 1];
+  if (BLK) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accs[BLK ? i : 0][BLK ? j : 0][e] = 0.0f;
+  }
+
   float ireg[NLD];
   float xsc = 1.0f, xsh = 0.0f, xsl = 1.0f;
 
@@ -730,13 +742,27 @@ __global__ __launch_bounds__(256, 2) void corr2_kernel(const CorrArgs a) {
   load_chunk(c0, 0);
   store_chunk(0);
   __syncthreads();
-  for (int ch = c0; ch < c1; ++ch) {
-    const int buf = (ch - c0) & 1;
-    if (ch + 1 < c1) load_chunk(ch + 1, buf ^ 1);
-    corr_mma_chunk<MB, U, KC, NI, NJ, SHIFT>(Wl0 + buf * (KC * MB), Il0 + buf * (CV * RLs), RLs,
-                                             aoff, boff, rsh, acc);
-    if (ch + 1 < c1) store_chunk(buf ^ 1);
-    __syncthreads();
+  // BLK: blocks of SEGAN_ACC_BLOCK chunks; the inner loop is the plain MFMA pipeline, the block
+  // sum is folded into accs between blocks (nested loops keep the accumulators in place)
+  constexpr int CBLK = BLK ? SEGAN_ACC_BLOCK : (1 << 30);
+  for (int cb = c0; cb < c1; cb += CBLK) {
+    const int ce = BLK ? min(cb + CBLK, c1) : c1;
+    for (int ch = cb; ch < ce; ++ch) {
+      const int buf = (ch - c0) & 1;
+      if (ch + 1 < c1) load_chunk(ch + 1, buf ^ 1);
+      corr_mma_chunk<MB, U, KC, NI, NJ, SHIFT>(Wl0 + buf * (KC * MB), Il0 + buf * (CV * RLs), RLs,
+                                               aoff, boff, rsh, acc);
+      if (ch + 1 < c1) store_chunk(buf ^ 1);
+      __syncthreads();
+    }
+    if constexpr (BLK) acc_block_flush<NI, NJ>(acc, accs);
+    else break;
+  }
+  if constexpr (BLK) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[i][j] = accs[i][j];
   }
 
   if (tw.partial)
@@ -1095,7 +1121,7 @@ static int launch_corr_t(CorrArgs a, hipStream_t st, bool allow_sk) {
   return SEGAN_OK;
 }
 
-template <int MB, int NB, int WM, int U, bool IN_HI, bool OUT_HI, bool SHIFT, bool XF>
+template <int MB, int NB, int WM, int U, bool IN_HI, bool OUT_HI, bool SHIFT, bool XF, bool BLK = false>
 static int launch_corr2_x(CorrArgs a, hipStream_t st, bool allow_sk) {
   constexpr int KC = CORR2_KC;
   constexpr int CV = KC / U;
@@ -1106,7 +1132,7 @@ static int launch_corr2_x(CorrArgs a, hipStream_t st, bool allow_sk) {
   a.RLs = round_up(a.RLs, 64 * SL);
   a.nld = a.RLs / (64 * SL);
   const size_t lds = (size_t)(2 * KC * MB + 2 * CV * a.RLs) * sizeof(float);
-  auto kern = corr2_kernel<MB, NB, WM, U, IN_HI, OUT_HI, SHIFT, XF>;
+  auto kern = corr2_kernel<MB, NB, WM, U, IN_HI, OUT_HI, SHIFT, XF, BLK>;
   static bool attr_done[16];
   static int occ[16];
   static size_t occ_lds[16];
@@ -1129,6 +1155,13 @@ static int launch_corr2_x(CorrArgs a, hipStream_t st, bool allow_sk) {
 
 template <int MB, int NB, int WM, int U, bool IN_HI, bool OUT_HI, bool SHIFT>
 static int launch_corr2_t(CorrArgs& a, hipStream_t st, bool allow_sk) {
+  // blocked accumulation: built for the stride-4 (U = 8) 128-row tiles, the long contractions
+  // of the SEGAN+ nets; elsewhere the plain kernels run (contractions a quarter as long)
+  if constexpr (U == 8 && MB == 128) {
+    if (a.acc_block)
+      return a.xf_mode ? launch_corr2_x<MB, NB, WM, U, IN_HI, OUT_HI, SHIFT, true, true>(a, st, allow_sk)
+                       : launch_corr2_x<MB, NB, WM, U, IN_HI, OUT_HI, SHIFT, false, true>(a, st, allow_sk);
+  }
   return a.xf_mode ? launch_corr2_x<MB, NB, WM, U, IN_HI, OUT_HI, SHIFT, true>(a, st, allow_sk)
                    : launch_corr2_x<MB, NB, WM, U, IN_HI, OUT_HI, SHIFT, false>(a, st, allow_sk);
 }
@@ -1261,7 +1294,9 @@ extern "C" int segan_conv1d_fwd(const segan_src* x, const void* wf, const float*
                                 int B, int N, int M, int L, int K, int S, int padL, int mode,
                                 int roll, int precision, void* scratch, size_t scratch_bytes,
                                 void* stream) {
-  SEGAN_REQUIRE(precision_ok(precision), "conv1d_fwd: precision must be 0, 1 or 3");
+  const int acc_block = precision == SEGAN_PREC_FP32_BLOCKED;
+  if (acc_block) precision = SEGAN_PREC_FP32;
+  SEGAN_REQUIRE(precision_ok(precision), "conv1d_fwd: precision must be 0, 1, 3 or 4");
   SEGAN_REQUIRE(stride_ok(S), "conv1d_fwd: stride %d not in {1,2,4}", S);
   SEGAN_REQUIRE(K >= 1 && K <= 32, "conv1d_fwd: kernel width %d not in [1,32]", K);
   SEGAN_REQUIRE(B > 0 && N > 0 && M > 0 && L > 0, "conv1d_fwd: bad sizes");
@@ -1275,6 +1310,7 @@ extern "C" int segan_conv1d_fwd(const segan_src* x, const void* wf, const float*
   if (int e = check_src(x, N, "conv1d_fwd")) return e;
   const int U = 32 / S;
   CorrArgs a = {};
+  a.acc_block = acc_block;
   a.in = *x;
   a.wp = (const float*)wf;
   a.out0 = out; a.out1 = nullptr; a.bias = bias; a.halo = nullptr;
@@ -1300,7 +1336,9 @@ extern "C" int segan_deconv1d_dgrad(const float* dy, const void* wf, float* dx0,
                                     int M, int M0, int N, int Ls, int K, int S, int pad,
                                     int precision, void* scratch, size_t scratch_bytes,
                                     void* stream) {
-  SEGAN_REQUIRE(precision_ok(precision), "deconv1d_dgrad: precision must be 0, 1 or 3");
+  const int acc_block = precision == SEGAN_PREC_FP32_BLOCKED;
+  if (acc_block) precision = SEGAN_PREC_FP32;
+  SEGAN_REQUIRE(precision_ok(precision), "deconv1d_dgrad: precision must be 0, 1, 3 or 4");
   SEGAN_REQUIRE(stride_ok(S), "deconv1d_dgrad: stride %d not in {1,2,4}", S);
   SEGAN_REQUIRE(K >= 1 && K <= 32, "deconv1d_dgrad: kernel width %d not in [1,32]", K);
   SEGAN_REQUIRE(B > 0 && N > 0 && M > 0 && Ls > 0, "deconv1d_dgrad: bad sizes");
@@ -1309,6 +1347,7 @@ extern "C" int segan_deconv1d_dgrad(const float* dy, const void* wf, float* dx0,
   SEGAN_REQUIRE(dx0 || dx1, "deconv1d_dgrad: both destinations NULL");
   const int U = 32 / S;
   CorrArgs a = {};
+  a.acc_block = acc_block;
   a.in.p0 = dy; a.in.p1 = nullptr; a.in.C0 = N; a.in.C1 = 0;
   a.in.scale = a.in.shift = a.in.slope = nullptr;
   a.wp = (const float*)wf;
@@ -1337,7 +1376,9 @@ extern "C" int segan_deconv1d_fwd(const segan_src* x, const void* wt, const floa
                                   const float* bias, float* y, int B, int M, int N, int Ls, int K,
                                   int S, int pad, int act, int precision, void* scratch,
                                   size_t scratch_bytes, void* stream) {
-  SEGAN_REQUIRE(precision_ok(precision), "deconv1d_fwd: precision must be 0, 1 or 3");
+  const int acc_block = precision == SEGAN_PREC_FP32_BLOCKED;
+  if (acc_block) precision = SEGAN_PREC_FP32;
+  SEGAN_REQUIRE(precision_ok(precision), "deconv1d_fwd: precision must be 0, 1, 3 or 4");
   SEGAN_REQUIRE(stride_ok(S), "deconv1d_fwd: stride %d not in {1,2,4}", S);
   SEGAN_REQUIRE(K >= 1 && K <= 32, "deconv1d_fwd: kernel width %d not in [1,32]", K);
   SEGAN_REQUIRE(B > 0 && N > 0 && M > 0 && Ls > 0, "deconv1d_fwd: bad sizes");
@@ -1348,6 +1389,7 @@ extern "C" int segan_deconv1d_fwd(const segan_src* x, const void* wt, const floa
   if (int e = check_src(x, M, "deconv1d_fwd")) return e;
   const int U = 32 / S;
   CorrArgs a = {};
+  a.acc_block = acc_block;
   a.in = *x;
   a.wp = (const float*)wt;
   a.out0 = y; a.out1 = nullptr; a.bias = bias; a.halo = nullptr;
@@ -1383,7 +1425,9 @@ extern "C" int segan_conv1d_dgrad(const float* da, const void* wt, const float* 
                                   float* halo, int B, int N, int M, int L, int K, int S, int padL,
                                   int roll, int precision, void* scratch, size_t scratch_bytes,
                                   void* stream) {
-  SEGAN_REQUIRE(precision_ok(precision), "conv1d_dgrad: precision must be 0, 1 or 3");
+  const int acc_block = precision == SEGAN_PREC_FP32_BLOCKED;
+  if (acc_block) precision = SEGAN_PREC_FP32;
+  SEGAN_REQUIRE(precision_ok(precision), "conv1d_dgrad: precision must be 0, 1, 3 or 4");
   SEGAN_REQUIRE(stride_ok(S), "conv1d_dgrad: stride %d not in {1,2,4}", S);
   SEGAN_REQUIRE(K >= 1 && K <= 32, "conv1d_dgrad: kernel width %d not in [1,32]", K);
   SEGAN_REQUIRE(B > 0 && N > 0 && M > 0 && L > 0 && L % S == 0, "conv1d_dgrad: bad sizes");
@@ -1398,6 +1442,7 @@ extern "C" int segan_conv1d_dgrad(const float* da, const void* wt, const float* 
   const int Ls = L / S;
   hipStream_t st = (hipStream_t)stream;
   CorrArgs a = {};
+  a.acc_block = acc_block;
   a.in.p0 = da; a.in.p1 = nullptr; a.in.C0 = M; a.in.C1 = 0;
   a.in.scale = a.in.shift = a.in.slope = nullptr;
   a.wp = (const float*)wt;

@@ -79,6 +79,7 @@ struct CorrArgs {
   float* sk_ws;                // fp32 stream-K: accumulator slabs of the cut tiles (caller scratch)
   size_t sk_ws_floats;
   int xf_mode;                 // input transform: 0 identity, 1 scale / slope (a zero stays zero), 2 with a shift
+  int acc_block;               // fp32: blocked accumulation (SEGAN_PREC_FP32_BLOCKED; segan_common.h)
   int RLv, nld;                // corr2: valid window positions (RLs is the padded row), loads per lane
 };
 

@@ -1036,3 +1036,55 @@ def test_conv1d_dgrad_short_rows(B, N, M, L, S, K, roll):
     assert torch.equal(dx, ops.conv1d_dgrad_short(dag, wg, L, S, roll=roll))
     if ops.short_rows_ok(N, M, L, S):
         assert torch.equal(dx, ops.conv1d_dgrad(dag, wg, L, S, roll=roll))   # the routed path
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['enc4', 'dec0'])
+def test_blocked_accumulation_is_more_accurate(name):
+    """ops.set_accumulation('blocked') (SEGAN_PREC_FP32_BLOCKED): forward and data gradient of the
+    longest contractions (K = 15 872 / 16 384 terms) against fp64.  Plain accumulation leaves a
+    relative L2 error of ~2e-6, blocked ~3e-7 (tests/diag/diag_accum.py); both bit-reproducible."""
+    ops = _ops()
+    S, K, B = 4, 31, 24
+
+    def l2(a, b):
+        a, b = a.double().cpu(), b.double()
+        return ((a - b).norm() / b.norm()).item()
+
+    if name == 'enc4':
+        N, M, L = 512, 1024, 64
+        x, w, b = rnd(B, N, L, seed=1), rnd(M, N, K, seed=2, scale=0.05), rnd(M, seed=3)
+        xd = x.double().requires_grad_(True)
+        ref = conv_ref(xd, w.double(), b.double(), S)
+        da = rnd(*ref.shape, seed=4)
+        ref.backward(da.double())
+        xg, wg, bg, dag = x.to(DEV), w.to(DEV), b.to(DEV), da.to(DEV)
+        run = lambda: (ops.conv1d_fwd(ops.Src(xg), wg, bg, S), ops.conv1d_dgrad(dag, wg, L, S))
+        want = (ref.detach(), xd.grad)
+    else:
+        M, N, Ls = 2048, 512, 16
+        x, w, b = rnd(B, M, Ls, seed=5), rnd(M, N, K, seed=6, scale=0.05), rnd(N, seed=7)
+        pad = ops.deconv_pad(K, S)
+        xd = x.double().requires_grad_(True)
+        ref = F.conv_transpose1d(xd, w.double(), b.double(), stride=S, padding=pad)[:, :, :S * Ls]
+        dy = rnd(*ref.shape, seed=8)
+        ref.backward(dy.double())
+        xg, wg, bg, dyg = x.to(DEV), w.to(DEV), b.to(DEV), dy.to(DEV)
+        run = lambda: (ops.deconv1d_fwd(ops.Src(xg), wg, bg, S), ops.deconv1d_dgrad(dyg, wg, S, 0)[1])
+        want = (ref.detach(), xd.grad)
+    errs = {}
+    for mode in ('plain', 'blocked'):
+        ops.set_accumulation(mode)
+        try:
+            got = run()
+            again = run()
+        finally:
+            ops.set_accumulation('plain')
+        assert all(torch.equal(a, b) for a, b in zip(got, again)), mode
+        errs[mode] = [l2(g, r) for g, r in zip(got, want)]
+    # forward (both layers) and the deconv data gradient contract over K >= 15 872 terms; the conv
+    # data gradient of enc4 runs the short-row GEMM path (K = 1024 per tap), which does not block
+    assert errs['blocked'][0] < 6e-7 and errs['blocked'][0] < 0.5 * errs['plain'][0], errs
+    assert errs['blocked'][1] < 8e-7, errs
+    if name == 'dec0':
+        assert errs['blocked'][1] < 0.5 * errs['plain'][1], errs
