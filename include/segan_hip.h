@@ -84,7 +84,7 @@ int segan_pack_weights(const float* w, float* wf, float* wt, int M, int N, int K
  * at a time and the block sums are added in a second register set, so the rounding error grows
  * with sqrt(256) + sqrt(K/256) instead of sqrt(K): forward error against fp64 3e-7 instead of
  * 1.5-2.2e-6 on the deep layers (tests/diag/diag_accum.py), at two instead of three resident
- * waves per SIMD (~3 % of the contraction rate).  Same packed weights as SEGAN_PREC_FP32;
+ * waves per SIMD (~3 % of the contraction rate, 1.5-2.2 % of the training step).  Same packed weights as SEGAN_PREC_FP32;
  * built for stride 4, other strides run the plain kernels.  Not a mode of segan_wgrad (its
  * contractions are split into short pieces already). */
 #define SEGAN_PREC_FP32_BLOCKED 4

@@ -53,12 +53,14 @@ def set_accumulation(mode):
     accumulator over the whole contraction: the default and the benchmarked configuration) or
     'blocked' (SEGAN_PREC_FP32_BLOCKED: 256-term blocks summed in a second register set).
     Blocked accumulation brings the forward error of the deep layers against fp64 from
-    1.5-2.2e-6 down to 3e-7 — below torch's own CPU fp32 result — and with it the number of
-    PReLU gates that flip between the two implementations at initialisation: at batch 300 the
-    worst-tensor gradient distance to the oracle falls from 2.5e-3 / 2.8e-3 (D / G) to 6.5e-4 /
-    1.7e-3.  It costs one of the three resident waves per SIMD (~3 % of the contraction rate,
-    ~2 % of the step), so it is opt-in: ``set_accumulation('blocked')`` /
-    SEGAN_ACCUMULATION=blocked.  No effect on the bf16 modes."""
+    1.5-2.2e-6 down to 3e-7 — below torch's own CPU fp32 result.  It costs one of the three
+    resident waves per SIMD (~3 % of the contraction rate, 1.5-2.2 % of the step), so it is
+    opt-in: ``set_accumulation('blocked')`` / SEGAN_ACCUMULATION=blocked.  What it does NOT
+    buy is a reliably smaller batch-300 gradient distance to the oracle: that figure is set by
+    which individual PReLU gates flip, not by the size of the roundoff.
+    The weight gradients stay plain (their contractions are split across workgroups already;
+    blocking them was measured: no change in any parity figure for 4.4 % of the step).  No
+    effect on the bf16 modes."""
     global _accumulation
     if mode not in _ACC_NAMES:
         raise ValueError('accumulation must be one of {}'.format(_ACC_NAMES))

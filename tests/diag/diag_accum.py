@@ -7,6 +7,9 @@ sys.path.insert(0, ROOT)
 import torch, torch.nn.functional as F
 from segan_pytorch_amd import ops
 DEV = 'cuda'
+torch.backends.mkldnn.enabled = False     # the oracle's setting (oneDNN's transposed conv is off by 0.2 on the GPU box's host)
+if len(sys.argv) > 2:
+    ops.set_accumulation(sys.argv[2])       # 'plain' | 'blocked'
 def rnd(*s, seed=0, scale=1.0):
     return (torch.randn(*s, generator=torch.Generator().manual_seed(seed)) * scale).float()
 def err(a, b):

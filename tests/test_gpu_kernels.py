@@ -1038,7 +1038,6 @@ def test_conv1d_dgrad_short_rows(B, N, M, L, S, K, roll):
         assert torch.equal(dx, ops.conv1d_dgrad(dag, wg, L, S, roll=roll))   # the routed path
 
 
-@pytest.mark.gpu
 @pytest.mark.parametrize('name', ['enc4', 'dec0'])
 def test_blocked_accumulation_is_more_accurate(name):
     """ops.set_accumulation('blocked') (SEGAN_PREC_FP32_BLOCKED): forward and data gradient of the
