@@ -224,3 +224,20 @@ def test_async_checkpoint_snapshot_is_taken_at_save_time(tmp_path):
     ck2 = torch.load(os.path.join(str(tmp_path), 'weights_S-Generator-8.ckpt'), weights_only=False)
     assert list(ck2['state_dict'].keys()) == list(ck['state_dict'].keys())
     assert not [f for f in os.listdir(str(tmp_path)) if f.endswith('.tmp')]
+
+
+def test_accumulation_mode_switch():
+    """ops.set_accumulation: 'plain' (default) / 'blocked' select SEGAN_PREC_FP32 /
+    SEGAN_PREC_FP32_BLOCKED for the fp32 forward / data-gradient entry points."""
+    from segan_pytorch_amd import ops
+    assert ops.get_accumulation() == 'plain' and ops._fp32() == ops.PREC_FP32 == 0
+    ops.set_accumulation('blocked')
+    try:
+        assert ops.get_accumulation() == 'blocked' and ops._fp32() == ops.PREC_FP32_BLOCKED == 4
+        with pytest.raises(ValueError):
+            ops.set_accumulation('kahan')
+        assert ops.get_accumulation() == 'blocked'
+    finally:
+        ops.set_accumulation('plain')
+    hdr = open(os.path.join(ROOT, 'include', 'segan_hip.h')).read()
+    assert '#define SEGAN_PREC_FP32_BLOCKED 4' in hdr

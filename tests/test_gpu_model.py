@@ -254,6 +254,18 @@ def test_default_segan_plus_step_matches_reference(segan_plus_b2, deterministic)
     _default_net_step(segan_plus_b2)
 
 
+def test_default_segan_plus_step_with_blocked_accumulation(segan_plus_b2, deterministic):
+    """The same step with ops.set_accumulation('blocked') (SEGAN_PREC_FP32_BLOCKED: the
+    corr2_kernel<.., BLK> variants in every deep layer of G and D): same protocol, same
+    tolerances against the reference's recorded step."""
+    from segan_pytorch_amd import ops
+    ops.set_accumulation('blocked')
+    try:
+        _default_net_step(segan_plus_b2)
+    finally:
+        ops.set_accumulation('plain')
+
+
 def test_default_segan_plus_no_bias_step_matches_reference(deterministic):
     """--no_bias, the reference's own batch-300 recipe (run_segan+_train.sh:7, train.py:248), on
     the full SEGAN+ net at B=2: G's convs carry no bias (the kernels take a NULL bias pointer),
