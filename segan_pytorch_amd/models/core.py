@@ -206,6 +206,44 @@ class Saver(object):
             self.optimizer.load_state_dict(st['optimizer'])
 
 
+def purge_checkpoints(ckpt_dir, verbose=True):
+    """Keep only the newest checkpoint of every index file in `ckpt_dir` (what the reference's
+    purge_ckpts.py:7-29 does): for each ``*checkpoints`` index, check that every listed
+    ``weights_<name>`` exists, delete all but the last entry of ``latest`` (and never the one
+    named by ``current``), rewrite the index with that single entry.  Half-written ``.tmp``
+    files of an interrupted asynchronous save are removed too.  Returns the removed paths."""
+    import glob
+    removed = []
+    for index in sorted(glob.glob(os.path.join(ckpt_dir, '*checkpoint*'))):
+        if index.endswith('.tmp') or os.path.basename(index).startswith('weights_'):
+            continue
+        with open(index, 'r') as f:
+            log = json.load(f)
+        latest = list(log.get('latest', []))
+        if not latest:
+            continue
+        missing = [n for n in latest if not os.path.exists(os.path.join(ckpt_dir, 'weights_' + n))]
+        if missing:
+            raise FileNotFoundError('{} lists checkpoints that are not on disk: {}'.format(index, missing))
+        for name in latest[:-1]:
+            if name == log.get('current'):
+                continue
+            path = os.path.join(ckpt_dir, 'weights_' + name)
+            os.unlink(path)
+            removed.append(path)
+            if verbose:
+                print('Removed file ', path)
+        if verbose:
+            print('Kept file ', os.path.join(ckpt_dir, 'weights_' + latest[-1]))
+        log['latest'] = [latest[-1]]
+        with open(index, 'w') as f:
+            f.write(json.dumps(log, indent=2))
+    for tmp in glob.glob(os.path.join(ckpt_dir, 'weights_*.tmp')):
+        os.unlink(tmp)
+        removed.append(tmp)
+    return removed
+
+
 class Model(nn.Module):
 
     def __init__(self, name='BaseModel'):

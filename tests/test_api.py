@@ -241,3 +241,29 @@ def test_accumulation_mode_switch():
         ops.set_accumulation('plain')
     hdr = open(os.path.join(ROOT, 'include', 'segan_hip.h')).read()
     assert '#define SEGAN_PREC_FP32_BLOCKED 4' in hdr
+
+
+def test_purge_checkpoints_keeps_the_newest(tmp_path):
+    """purge_ckpts.py (reference purge_ckpts.py:7-29): after four saves only the last checkpoint
+    and a one-entry index remain, the survivor still loads, and an index that lists a missing
+    file is refused before anything is deleted."""
+    from segan_pytorch_amd.models.core import Saver, purge_checkpoints
+    net = torch.nn.Linear(3, 2)
+    sv = Saver(net, str(tmp_path), max_ckpts=5, prefix='EOE_G-')
+    for step in range(4):
+        sv.save('Generator', step)
+    sv.wait()
+    (tmp_path / 'weights_EOE_G-Generator-9.ckpt.tmp').write_bytes(b'partial')
+    removed = purge_checkpoints(str(tmp_path), verbose=False)
+    assert len(removed) == 4
+    left = sorted(n for n in os.listdir(str(tmp_path)) if n.startswith('weights_'))
+    assert left == ['weights_EOE_G-Generator-3.ckpt']
+    idx = json.load(open(str(tmp_path / 'EOE_G-checkpoints')))
+    assert idx['latest'] == ['EOE_G-Generator-3.ckpt'] and idx['current'] == 'EOE_G-Generator-3.ckpt'
+    assert Saver(torch.nn.Linear(3, 2), str(tmp_path), prefix='EOE_G-').load_weights()
+    sv.save('Generator', 4)
+    sv.wait()
+    os.unlink(str(tmp_path / 'weights_EOE_G-Generator-3.ckpt'))
+    with pytest.raises(FileNotFoundError):
+        purge_checkpoints(str(tmp_path), verbose=False)
+    assert os.path.exists(str(tmp_path / 'weights_EOE_G-Generator-4.ckpt'))
