@@ -346,7 +346,6 @@ struct Bf2Extra {
   int ngroups;          // channel groups of 16
   int G, Qp;            // groups of 8 per sample (= 2*ngroups), positions per row
   int nld;              // DMA instructions per half of the activation tile (RLs' / 64)
-  int dbg;              // experiments (SEGAN_BF2_DBG): 1 = no DMA after a tile's first stage, 2 = no MFMA loop
 };
 
 // stages the DMA runs ahead of the MFMAs.  Measured (scripts/bench_layers.py, bf16): 2 stages ahead
@@ -543,11 +542,10 @@ __global__ __launch_bounds__(256, (NPL == 1 && NB == 128) ? 3 : 2) void corr_bf2
   for (int st = c0; st < c1; ++st) {
     const int buf = (st - c0) % NBUF;
     const int cg = st / TCH, tc = st - cg * TCH;
-    const bool ahead = st + LOOK < c1 && !(x.dbg & 1);
+    const bool ahead = st + LOOK < c1;
     if (ahead) issue(st + LOOK);
     const u32x4* Wl = Wl0 + buf * WPIECES;
     const u32x4* Il = Il0 + (cg & 1) * IPIECES;
-    if (!(x.dbg & 2))
 #pragma unroll
     for (int tu = 0; tu < TU; ++tu) {
       const int u = tc * TU + tu;
@@ -745,14 +743,10 @@ static int launch_bf2(CorrArgs a, Bf2Extra x, hipStream_t st) {
 
 // shared front end: geometry, packing pass, extra arguments.  Returns SEGAN_EUNSUPPORTED (the
 // caller then runs round 1's kernel) when the scratch is missing or too small.
-// column-tile width: 256 halves the weight bytes streamed per MFMA (the L2 -> LDS stream is what
-// bounds these kernels), 128 keeps enough tiles in flight on the short layers
-static int bf2_pick_nb(const CorrArgs& a, int MB_rows) {
-  // measured (scripts/bench_layers.py, SEGAN_BF2_NB): 128-column tiles at three workgroups per CU
-  // beat 256-column tiles at two on every SEGAN+ layer; the wide variant stays selectable
-  (void)a; (void)MB_rows;
-  return 128;
-}
+// column-tile width: 128.  256-column tiles (half the weight bytes streamed per MFMA, two instead
+// of three workgroups per CU) were built and measured on every SEGAN+ layer (scripts/bench_layers.py):
+// within +-4 %, slower on most; dropped.
+#define BF2_NB 128
 
 template <bool IN_HI>
 static int bf2_prepare(CorrArgs& a, int U, int planes, void* scratch, size_t scratch_bytes,
@@ -796,27 +790,10 @@ static int bf2_prepare(CorrArgs& a, int U, int planes, void* scratch, size_t scr
   x.G = pa.G;
   x.Qp = pa.Qp;
   x.nld = 0;
-  {
-    static int dbg = -1;
-    if (dbg < 0) {
-      const char* e = getenv("SEGAN_BF2_DBG");
-      dbg = e ? atoi(e) : 0;
-    }
-    x.dbg = dbg;
-  }
   return SEGAN_OK;
 }
 
 static inline int bf_f_pitch2(int M) { return round_up(M, 128); }
-
-static int bf2_force_nb() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("SEGAN_BF2_NB");
-    v = e ? atoi(e) : 0;
-  }
-  return v;
-}
 
 int segan_corr_bf2_f(CorrArgs& a, int U, const void* wp3, int planes, void* scratch,
                      size_t scratch_bytes, hipStream_t st) {
@@ -825,17 +802,11 @@ int segan_corr_bf2_f(CorrArgs& a, int U, const void* wp3, int planes, void* scra
     return SEGAN_EUNSUPPORTED;
   }
   Bf2Extra x;
-  const int NB = bf2_force_nb() ? bf2_force_nb() : bf2_pick_nb(a, a.Rvalid);
+  constexpr int NB = BF2_NB;
   if (int e = bf2_prepare<true>(a, U, planes, scratch, scratch_bytes, x, st, NB)) return e;
   x.wp3 = (const __bf16*)wp3;
   a.RP = bf_f_pitch2(a.Rvalid);
   x.w_plane = (long)x.ngroups * U * 2 * a.RP * 8;
-  if (NB == 256) {
-    if (U == 8) return planes == 3 ? launch_bf2<256, 2, 8, true, false, 0, 3>(a, x, st)
-                                   : launch_bf2<256, 2, 8, true, false, 0, 1>(a, x, st);
-    return planes == 3 ? launch_bf2<256, 2, 16, true, false, 0, 3>(a, x, st)
-                       : launch_bf2<256, 2, 16, true, false, 0, 1>(a, x, st);
-  }
   if (U == 8) return planes == 3 ? launch_bf2<128, 2, 8, true, false, 0, 3>(a, x, st)
                                  : launch_bf2<128, 2, 8, true, false, 0, 1>(a, x, st);
   return planes == 3 ? launch_bf2<128, 2, 16, true, false, 0, 3>(a, x, st)
@@ -852,21 +823,11 @@ int segan_corr_bf2_t(CorrArgs& a, int U, const void* wp3, int planes, void* scra
     return SEGAN_EUNSUPPORTED;
   }
   Bf2Extra x;
-  const int NB = bf2_force_nb() ? bf2_force_nb() : bf2_pick_nb(a, a.Rvalid);
+  constexpr int NB = BF2_NB;
   if (int e = bf2_prepare<false>(a, U, planes, scratch, scratch_bytes, x, st, NB)) return e;
   x.wp3 = (const __bf16*)wp3;
   // a.RP = S*NP already (t_pitch)
   x.w_plane = (long)x.ngroups * U * 2 * a.RP * 8;
-  if (NB == 256) {
-    if (U == 8 && mask == 8)
-      return planes == 3 ? launch_bf2<256, 1, 8, false, true, 8, 3>(a, x, st)
-                         : launch_bf2<256, 1, 8, false, true, 8, 1>(a, x, st);
-    if (U == 8)
-      return planes == 3 ? launch_bf2<256, 1, 8, false, true, 0, 3>(a, x, st)
-                         : launch_bf2<256, 1, 8, false, true, 0, 1>(a, x, st);
-    return planes == 3 ? launch_bf2<256, 1, 16, false, true, 0, 3>(a, x, st)
-                       : launch_bf2<256, 1, 16, false, true, 0, 1>(a, x, st);
-  }
   if (U == 8 && mask == 8)
     return planes == 3 ? launch_bf2<128, 1, 8, false, true, 8, 3>(a, x, st)
                        : launch_bf2<128, 1, 8, false, true, 8, 1>(a, x, st);
