@@ -389,26 +389,26 @@ def _profile(name):
     return c[-1] if c else None
 
 
-def pmc_mfma_busy(family):
+def pmc_mfma_busy(family, suffix=''):
     """MFMA-pipe busy fraction of a kernel family from the newest committed SQ counter passes
     (profiles/rNN_sq_counters.json, scripts/pmc_sq.sh): MFMA instructions x 64 cycles over the
     SIMD-cycles of the launch."""
     try:
-        d = json.load(open(_profile('sq_counters.json')))
+        d = json.load(open(_profile('sq_counters{}.json'.format(suffix))))
         return d['_summary'][family + '_mfma_pipe_busy_mean']
     except Exception:
         return None
 
 
 def pmc_traffic(main=('corr2_kernel', 'corr_kernel<', 'conv_dgrad_short_kernel'),
-                extra=('corr_fixup_kernel',)):
+                extra=('corr_fixup_kernel',), suffix=''):
     """HBM bytes per launch of the dominant kernel family from the newest committed rocprofv3 PMC
     passes (profiles/rNN_pmc_hbm_traffic.json: FETCH_SIZE and WRITE_SIZE in separate passes over
     this same command; FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md): bytes
     of the contraction kernels plus their stream-K fix-up passes, per contraction launch.
     Returns (bytes per launch, provenance dict) — the provenance says which file, which source
     hash it was measured on and whether the sources have changed since (`stale`)."""
-    path = _profile('pmc_hbm_traffic.json')
+    path = _profile('pmc_hbm_traffic{}.json'.format(suffix))
     if path is None:
         return None, None
     try:
@@ -662,6 +662,11 @@ def main():
         chunks = B * world * args.steps
         value = chunks / dt
         ms = 1e3 * dt / args.steps
+        # the matrix-core peak of the mode that was timed: fp32 MFMA, the dense bf16 MFMA, or — bf16x3,
+        # six bf16 MFMAs per product — a sixth of it in fp32-equivalent FLOPs
+        fp32_run = args.precision == 'fp32'
+        peak_tf = (PEAK_F32_MFMA_TF if fp32_run else
+                   PEAK_BF16_MFMA_TF / (6.0 if args.precision == 'bf16x3' else 1.0))
         line = {
             'metric': '16384-sample waveform chunks/sec (GAN step)', 'value': value,
             'unit': 'chunks/s', 'n_gpus': world, 'ranks_seen': ranks_seen, 'devices': devices_seen,
@@ -674,11 +679,13 @@ def main():
                                     if args.wsegan else
                                     'original SEGAN shape: 11+11 layers of stride 2, k31 (train.py:'
                                     '199-205 flags), batch {} x 16384-sample chunks per GPU, full GAN '
-                                    'step, RMSprop, fp32 (side line, not the headline configuration)'
+                                    'step, RMSprop, {} (side line, not the headline configuration)'
                                     if args.shape == 'vanilla11' else
                                     'SEGAN+ default G+D (5+5 layers, k31, stride 4, z 1024x16), '
                                     'batch {} x 16384-sample chunks per GPU, full GAN step '
-                                    '(model.py:292-321), RMSprop, fp32').format(B),
+                                    '(model.py:292-321), RMSprop, {}').format(
+                                        B, 'fp32' if fp32_run else args.precision +
+                                        ' contractions (side configuration, not the headline)'),
                        'global_batch': B * world, 'parallelism': 'dp{}'.format(world),
                        'z': 'device generator' if args.device_z else 'host randn + H2D per step (as train.py)'},
             'losses_finite': finite,
@@ -692,8 +699,11 @@ def main():
             'gflop_per_chunk': gflop,
             'gflop_per_chunk_executed': gflop_exec,
             'step_tflops': gflop * value / 1e3,
-            'step_frac_of_f32_mfma_peak': gflop * value / 1e3 / PEAK_F32_MFMA_TF / world,
-            'step_frac_executed': gflop_exec * value / 1e3 / PEAK_F32_MFMA_TF / world,
+            'step_peak_tflops': peak_tf,
+            'step_frac_of_f32_mfma_peak': (gflop * value / 1e3 / PEAK_F32_MFMA_TF / world
+                                           if args.precision == 'fp32' else None),
+            'step_frac_of_mfma_peak': gflop * value / 1e3 / peak_tf / world,
+            'step_frac_executed': gflop_exec * value / 1e3 / peak_tf / world,
             'step_frac_note': 'step_frac_of_f32_mfma_peak divides the REFERENCE accounting (SURVEY.md 8d: '
                               'it counts the D weight gradients of the generator phase, which the reference '
                               'computes and discards) by the time; step_frac_executed counts only what this '
@@ -704,27 +714,44 @@ def main():
         if timer is not None:
             s = timer.summary()
             c = s.get('corr')
-            traffic, traffic_prov = pmc_traffic()
+            if fp32_run:
+                traffic, traffic_prov = pmc_traffic()
+            else:       # the bf16 profile exists for 'bf16' only
+                traffic, traffic_prov = (pmc_traffic(main=('corr_bf2_kernel', 'corr_bf_kernel'),
+                                                     extra=('bf2_fixup_kernel', 'act_pack_kernel'),
+                                                     suffix='_bf16')
+                                         if args.precision == 'bf16' else (None, None))
             if c:
                 line['roofline'] = {
-                    'bound': 'mfma', 'kernel': 'corr2_kernel + conv_dgrad_short_kernel (conv/deconv forward + data gradient)',
-                    'achieved': c['tflops'], 'peak': PEAK_F32_MFMA_TF, 'unit': 'TFLOP/s',
-                    'frac': c['tflops'] / PEAK_F32_MFMA_TF, 'traffic': traffic,
+                    'bound': 'mfma',
+                    'kernel': ('corr2_kernel + conv_dgrad_short_kernel (conv/deconv forward + data gradient)'
+                               if fp32_run else 'conv/deconv forward + data gradient entry points on '
+                               'v_mfma_f32_32x32x16_bf16 (corr_bf2_kernel + its packing / fix-up passes)'),
+                    'achieved': c['tflops'], 'peak': peak_tf, 'unit': 'TFLOP/s',
+                    'frac': c['tflops'] / peak_tf, 'traffic': traffic,
                     'traffic_unit': 'HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE; a committed '
                                     'profile, not measured in this run: see traffic_source)',
                     'traffic_source': traffic_prov,
                     'avg_launch_us': c['avg_us'], 'launches': c['launches'],
                     'gflop_per_launch': c['flops_per_launch'] / 1e9,
                     'share_of_step_time': c['total_ms'] / (1e3 * dt),
-                    'mfma_pipe_busy_pmc': pmc_mfma_busy('corr2')}
+                    'mfma_pipe_busy_pmc': (pmc_mfma_busy('corr2') if fp32_run else
+                                           pmc_mfma_busy('corr_bf2', '_bf16') if args.precision == 'bf16'
+                                           else None)}
             if 'wgrad' in s:
                 w = s['wgrad']
-                line['roofline_wgrad'] = {'bound': 'mfma', 'kernel': 'wgrad2_kernel',
-                                          'achieved': w['tflops'], 'peak': PEAK_F32_MFMA_TF,
-                                          'unit': 'TFLOP/s', 'frac': w['tflops'] / PEAK_F32_MFMA_TF,
+                line['roofline_wgrad'] = {'bound': 'mfma',
+                                          'kernel': 'wgrad2_kernel' if fp32_run else
+                                                    'weight-gradient entry point on v_mfma_f32_32x32x16_bf16 '
+                                                    '(wgrad_bf2_kernel + its packing passes)',
+                                          'achieved': w['tflops'], 'peak': peak_tf,
+                                          'unit': 'TFLOP/s', 'frac': w['tflops'] / peak_tf,
                                           'avg_launch_us': w['avg_us'], 'launches': w['launches'],
                                           'share_of_step_time': w['total_ms'] / (1e3 * dt),
-                                          'mfma_pipe_busy_pmc': pmc_mfma_busy('wgrad2')}
+                                          'mfma_pipe_busy_pmc': (
+                                              pmc_mfma_busy('wgrad2') if fp32_run else
+                                              pmc_mfma_busy('wgrad_bf2', '_bf16') if args.precision == 'bf16'
+                                              else None)}
         if modes:
             modes['note'] = ('same workload, contractions on the bf16 MFMA: bf16x3 = fp32 operands '
                              'split exactly into 3 bf16 planes, 6 partial products, fp32 accumulate '

@@ -3,6 +3,9 @@ bench.py` on an MI355X) carries every field of the driver's contract."""
 import glob
 import json
 import os
+import sys
+
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -57,3 +60,41 @@ def test_flop_accounting():
     assert abs(bench.gflop_per_chunk(o) - 37.96) < 0.01
     assert abs(bench.gflop_per_chunk(o, executed=True) - 35.84) < 0.01
     assert abs(bench.gflop_per_chunk(o, wsegan=True) - 44.33) < 0.01
+
+
+@pytest.mark.parametrize('prec', ['fp32', 'bf16', 'bf16x3'])
+@pytest.mark.parametrize('wsegan,shape', [(False, 'segan_plus'), (True, 'segan_plus'), (False, 'vanilla11')])
+def test_bench_line_assembly_runs_without_a_gpu(prec, wsegan, shape):
+    """bench.py's rank-0 line assembly (from the timed numbers to the `roofline` blocks) executed on
+    fakes: every precision prices its kernels against the peak of the matrix-core mode that ran
+    (fp32 MFMA, dense bf16 MFMA, a sixth of it for bf16x3), so no frac can exceed 1 because of the
+    wrong denominator, and the line stays JSON-serialisable."""
+    import textwrap
+    import types
+    sys.path.insert(0, ROOT)
+    import bench
+    src = open(os.path.join(ROOT, 'bench.py')).read()
+    seg = textwrap.dedent(src[src.index("        chunks = B * world * args.steps\n"):
+                              src.index("        if modes:\n            modes['note']")])
+
+    class Timer(object):
+        def summary(self):
+            return {'corr': dict(tflops=100.0, avg_us=100.0, launches=10, flops_per_launch=1e12, total_ms=10.0),
+                    'wgrad': dict(tflops=90.0, avg_us=100.0, launches=5, total_ms=5.0)}
+
+    ns = dict(vars(bench))
+    ns.update(B=300, world=1, dt=0.9, ranks_seen=[0], devices_seen=[0], backend=None, finite=True,
+              timed_det=False, ms_other=90.0, ms_blocked=91.0, gflop=37.96, gflop_exec=35.84, timer=Timer(),
+              _ops=types.SimpleNamespace(get_accumulation=lambda: 'plain'),
+              args=types.SimpleNamespace(steps=10, warmup=3, precision=prec, wsegan=wsegan, shape=shape,
+                                         device_z=False))
+    exec(seg, ns)
+    line = ns['line']
+    json.dumps(line)
+    peak = {'fp32': 157.3, 'bf16': 2500.0, 'bf16x3': 2500.0 / 6}[prec]
+    for key in ('roofline', 'roofline_wgrad'):
+        assert abs(line[key]['peak'] - peak) < 1e-6 * peak
+        assert abs(line[key]['frac'] - line[key]['achieved'] / peak) < 1e-12
+    assert (line['step_frac_of_f32_mfma_peak'] is None) == (prec != 'fp32')
+    assert abs(line['step_frac_of_mfma_peak'] - 37.96 * line['value'] / 1e3 / peak) < 1e-12
+    assert prec in line['config']['workload'] or wsegan
