@@ -47,7 +47,21 @@ def roll(h, r):
     return torch.cat((h[:, :, s:], h[:, :, :s]), dim=2)
 
 
-def gconv_block(x, w, b, slope, stride, bn=None, training=True):
+def _prelu(a, slope, gate=None):
+    """F.prelu(a, slope); with `gate` (a bool tensor of a's shape) the SIDE of every element is
+    imposed instead of read off the sign of a: where(gate, a, slope * a).  Test hook for the
+    gate-aligned gradient comparisons (tests/test_gpu_kernels.py::
+    test_discriminator_gradients_with_aligned_gates): a pre-activation within roundoff of zero may
+    fall on either side in two correct fp32 implementations, and the derivative of PReLU is
+    discontinuous there; imposing one implementation's sides on the other removes exactly that
+    and nothing else (the forward value changes by at most |slope - 1| * |a|, a roundoff)."""
+    if gate is None:
+        return F.prelu(a, slope)
+    sl = slope.view(*([1, -1] + [1] * (a.dim() - 2))) if slope.numel() > 1 else slope
+    return torch.where(gate, a, sl * a)
+
+
+def gconv_block(x, w, b, slope, stride, bn=None, training=True, gate=None):
     """modules.py:91-105.  Returns (h, a, bn_batch_stats)."""
     K = w.shape[2]
     P = (K // 2 - 1, K // 2) if stride > 1 else (K // 2, K // 2)
@@ -55,11 +69,11 @@ def gconv_block(x, w, b, slope, stride, bn=None, training=True):
     if bn is not None:
         a = F.batch_norm(a, bn['running_mean'], bn['running_var'], bn['weight'], bn['bias'],
                          training, 0.1, 1e-5)
-    h = F.prelu(a, slope)
+    h = _prelu(a, slope, gate)
     return h, a
 
 
-def gdeconv_block(x, w, b, slope, stride, tanh=False, bn=None, training=True):
+def gdeconv_block(x, w, b, slope, stride, tanh=False, bn=None, training=True, gate=None):
     """modules.py:135-141 (pad from modules.py:115)."""
     K = w.shape[2]
     pad = max(0, (stride - K) // -2)
@@ -69,7 +83,7 @@ def gdeconv_block(x, w, b, slope, stride, tanh=False, bn=None, training=True):
     if bn is not None:
         h = F.batch_norm(h, bn['running_mean'], bn['running_var'], bn['weight'], bn['bias'],
                          training, 0.1, 1e-5)
-    return torch.tanh(h) if tanh else F.prelu(h, slope)
+    return torch.tanh(h) if tanh else _prelu(h, slope, gate)
 
 
 def _bn_of(sd, p):
@@ -120,14 +134,16 @@ def _count(sd, prefix):
 
 
 def generator_forward(sd, x, z, strides, dec_strides=None, ret_hid=False, training=True,
-                      skip_merge='concat', skip_dropout=0.0):
+                      skip_merge='concat', skip_dropout=0.0, gates=None):
     """generator.py:180-230.  The architecture is read off the state_dict: a level has a skip
     when ``alpha_<l>.skip_k`` (alpha / constant) or ``alpha_<l>.skip_k.weight`` (conv skip,
     generator.py:42-49) exists; a decoder block is a transposed conv (``deconv``) or, for a
     pooling of 1, a GConv1DBlock (``conv``, generator.py:171-176); a block has a BatchNorm1d
     when ``norm.weight`` exists (norm_type='bnorm'; the running buffers in `sd` are updated in
     place in training mode).  `skip_dropout` > 0: nn.Dropout on the skip path
-    (generator.py:53-54,70-71), drawing its masks from torch's global RNG like the reference."""
+    (generator.py:53-54,70-71), drawing its masks from torch's global RNG like the reference.
+    `gates`: {'enc_<l>' / 'dec_<l>': bool tensor} imposes PReLU sides (test hook, see _prelu)."""
+    gates = gates or {}
     n_enc = _count(sd, 'enc_blocks')
     n_dec = _count(sd, 'dec_blocks')
     dec_strides = dec_strides or list(strides)
@@ -137,7 +153,8 @@ def generator_forward(sd, x, z, strides, dec_strides=None, ret_hid=False, traini
     for l in range(n_enc):
         p = 'enc_blocks.{}.'.format(l)
         hi, lin = gconv_block(hi, _weight(sd, p + 'conv.', 0, training), sd.get(p + 'conv.bias'),
-                              sd[p + 'act.weight'], strides[l], bn=_bn_of(sd, p), training=training)
+                              sd[p + 'act.weight'], strides[l], bn=_bn_of(sd, p), training=training,
+                              gate=gates.get('enc_{}'.format(l)))
         if l < n_enc - 1 and ('alpha_{}.skip_k'.format(l) in sd or
                               'alpha_{}.skip_k.weight'.format(l) in sd):
             skips[l] = lin                       # the PRE-activation (generator.py:185,191)
@@ -165,21 +182,25 @@ def generator_forward(sd, x, z, strides, dec_strides=None, ret_hid=False, traini
         if p + 'conv.weight' in sd or p + 'conv.weight_orig' in sd:
             hi, _ = gconv_block(hi, _weight(sd, p + 'conv.', 0, training), sd.get(p + 'conv.bias'),
                                 sd[p + 'act.weight'], dec_strides[l], bn=_bn_of(sd, p),
-                                training=training)
+                                training=training, gate=gates.get('dec_{}'.format(l)))
         else:
             last = (p + 'act.weight') not in sd
             hi = gdeconv_block(hi, _weight(sd, p + 'deconv.', 1, training), sd[p + 'deconv.bias'],
                                sd.get(p + 'act.weight'), dec_strides[l], tanh=last,
-                               bn=_bn_of(sd, p), training=training)
+                               bn=_bn_of(sd, p), training=training,
+                               gate=gates.get('dec_{}'.format(l)))
         enc_idx -= 1
         hall['dec_{}'.format(l)] = hi
     return (hi, hall) if ret_hid else hi
 
 
-def discriminator_forward(sd, x, rolls, strides, training=True, ret_act=False, pool_type='none'):
+def discriminator_forward(sd, x, rolls, strides, training=True, ret_act=False, pool_type='none',
+                          gates=None):
     """discriminator.py:150-194 (norm 'bnorm', 'snorm' or none; heads 'none', 'conv', 'gmax',
     'gavg').  `sd` must hold the BN running buffers when bnorm; they are updated in place like
-    nn.BatchNorm1d."""
+    nn.BatchNorm1d.  `gates`: {'h_<l>', 'fc_1', 'fc_3': bool tensor} imposes PReLU sides (test
+    hook, see _prelu); `acts` then also carries the pre-activations 'a_<l>', 'fc_a1', 'fc_a3'."""
+    gates = gates or {}
     n = _count(sd, 'enc_blocks')
     h = x
     acts = {}
@@ -187,15 +208,18 @@ def discriminator_forward(sd, x, rolls, strides, training=True, ret_act=False, p
         p = 'enc_blocks.{}.'.format(l)
         h = roll(h, rolls[l])
         bn = _bn_of(sd, p)
-        h, _ = gconv_block(h, _weight(sd, p + 'conv.', 0, training), sd.get(p + 'conv.bias'),
-                           sd[p + 'act.weight'], strides[l], bn=bn, training=training)
+        h, a = gconv_block(h, _weight(sd, p + 'conv.', 0, training), sd.get(p + 'conv.bias'),
+                           sd[p + 'act.weight'], strides[l], bn=bn, training=training,
+                           gate=gates.get('h_{}'.format(l)))
         acts['h_{}'.format(l)] = h
+        acts['a_{}'.format(l)] = a
     if pool_type == 'none':
         h = h.view(h.size(0), -1)
-        h = F.prelu(F.linear(h, _weight(sd, 'fc.0.', 0, training), sd['fc.0.bias']),
-                    _weight(sd, 'fc.1.', 0, training))
-        h = F.prelu(F.linear(h, _weight(sd, 'fc.2.', 0, training), sd['fc.2.bias']),
-                    _weight(sd, 'fc.3.', 0, training))
+        a1 = F.linear(h, _weight(sd, 'fc.0.', 0, training), sd['fc.0.bias'])
+        h = _prelu(a1, _weight(sd, 'fc.1.', 0, training), gates.get('fc_1'))
+        a3 = F.linear(h, _weight(sd, 'fc.2.', 0, training), sd['fc.2.bias'])
+        h = _prelu(a3, _weight(sd, 'fc.3.', 0, training), gates.get('fc_3'))
+        acts['fc_a1'], acts['fc_a3'] = a1, a3
         y = F.linear(h, _weight(sd, 'fc.4.', 0, training), sd['fc.4.bias'])
     else:
         if pool_type == 'conv':                  # discriminator.py:122-127,175-179

@@ -352,6 +352,9 @@ struct Bf2Extra {
 // with three weight buffers (two workgroups per CU) or with half-size stages (four per CU) give the
 // same total as 1 stage ahead at three per CU — the loop is not latency-bound — so the shallow form stays
 #define BF2_LOOK(NPL) 1
+#ifndef BF2_LDR_EU
+#define BF2_LDR_EU 4      // waves per SIMD the loader variant is compiled for (experiment switch)
+#endif
 
 // s_waitcnt vmcnt(n) for a run-time n (the instruction takes an immediate): loads — LDS-DMA
 // included — return in order, so "at most n outstanding" = all but the newest n have landed
@@ -372,8 +375,14 @@ __device__ __forceinline__ void bf2_wait_vm(int n) {
   }
 }
 
-template <int MB, int NB, int WM, int U, bool OUT_HI, int SHIFTMASK, int NPL, int TU>
-__global__ __launch_bounds__(256, (NPL == 1 && NB == 128) ? 3 : 2) void corr_bf2_kernel(const CorrArgs a, const Bf2Extra x) {
+// LDR: a FIFTH wave per workgroup issues every LDS-DMA instruction of the tile and is the only
+// one that waits on vmcnt; the four contraction waves issue nothing but ds_read_b128 and MFMAs.
+// Why: an LDS-DMA instruction holds its wave's issue port for 60-185 cycles (MI355X_MICROARCH.md,
+// "LDS-DMA piece issue cost"), ~5 of them per stage and wave were ~400 cycles beside 16 MFMAs of
+// 32; moved to a wave of their own they overlap with the other waves' MFMAs, and the next tile's
+// first stage is already in flight while the contraction waves store the previous tile.
+template <int MB, int NB, int WM, int U, bool OUT_HI, int SHIFTMASK, int NPL, int TU, bool LDR>
+__global__ __launch_bounds__(LDR ? 320 : 256, (NPL == 1 && NB == 128) ? (LDR ? BF2_LDR_EU : 3) : 2) void corr_bf2_kernel(const CorrArgs a, const Bf2Extra x) {
   constexpr int S = 32 / U;
   constexpr int WN = 4 / WM;
   constexpr int NI = MB / (32 * WM);
@@ -443,6 +452,61 @@ __global__ __launch_bounds__(256, (NPL == 1 && NB == 128) ? 3 : 2) void corr_bf2
   const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<char*>(reinterpret_cast<const char*>(x.act)) + (size_t)ct.b0 * sample_bytes, 0,
       (int)(left + 2 * x.a_plane_bytes < 0x7fffffffL ? left + 2 * x.a_plane_bytes : 0x7fffffffL), 0x00020000);
+  if (LDR && wave == 4) {
+    // ---- the loader wave: all DMA of the tile, one stage ahead of the contraction waves ----
+    int avo6[2 * KI];
+#pragma unroll
+    for (int pb = 0; pb < 2 * KI; ++pb) {
+      const int j = lane + 64 * pb;
+      avo6[pb] = (int)0x80000000u;
+      if (pb < x.nld && j < a.RLv) {
+        int s, tau;
+        lds_pos_decode(ct, j, a.Tcols, a.H, s, tau);
+        if (ct.b0 + s < a.B) avo6[pb] = (int)(((long)s * x.G * x.Qp + tau) * 16);
+      }
+    }
+    int lwvo[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int wr = 64 * i + lane;
+      const int wgrow = OUT_HI ? (wr / NPT) * a.NP + n0 + wr % NPT : m0 + wr;
+      lwvo[i] = wgrow * 16;
+    }
+    auto lissue = [&](int st) __attribute__((always_inline)) {
+      if (st % TCH == 0 || st == c0) {
+        const int cg = st / TCH;
+        u32x4* Il = Il0 + (cg & 1) * IPIECES;
+#pragma unroll
+        for (int p = 0; p < NPL; ++p)
+#pragma unroll
+          for (int g2 = 0; g2 < 2; ++g2) {
+            const long soff = (long)p * x.a_plane_bytes + ((long)(2 * cg + g2) * x.Qp) * 16;
+#pragma unroll
+            for (int pb = 0; pb < 2 * KI; ++pb)
+              if (pb < x.nld)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                    ars, (__attribute__((address_space(3))) void*)(Il + (p * 2 + g2) * RLs + 64 * pb), 16,
+                    avo6[pb], (int)soff, 0, 0);
+          }
+      }
+      u32x4* Wl = Wl0 + ((st - c0) % NBUF) * WPIECES;
+#pragma unroll
+      for (int q = 0; q < WINS; ++q) {
+        const int i = q & 1, g = (q >> 1) & 1, tu = (q >> 2) % TU, p = q / (4 * TU);
+        const long soff = (long)p * x.w_plane * 2 + ((long)((st * TU + tu) * 2 + g) * a.RP) * 16;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            wrs, (__attribute__((address_space(3))) void*)(Wl + ((p * TU + tu) * 2 + g) * MB + 64 * i), 16,
+            lwvo[i], (int)soff, 0, 0);
+      }
+    };
+    lissue(c0);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    for (int st = c0; st < c1; ++st) {
+      if (st + 1 < c1) lissue(st + 1);
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    continue;
+  }
   // this wave stages half g = wave & 1, position blocks (wave >> 1) + 2k (static register indices)
   const int ig = wave & 1, ib = wave >> 1;
   int avo[KI];
@@ -533,17 +597,24 @@ __global__ __launch_bounds__(256, (NPL == 1 && NB == 128) ? 3 : 2) void corr_bf2
     dma_w(st, (st - c0) % NBUF);
   };
   auto group = [&](int st) { return WINS / 4 + ((st % TCH == 0) ? cnt_i : 0); };
-  issue(c0);
-  if (LOOK > 1 && c0 + 1 < c1) issue(c0 + 1);
-  // (the epilogue stores of the previous tile may still be in flight and complete out of order
-  // with loads: a full drain here, partial waits only inside the loop)
-  __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0)
-  __syncthreads();
+  if (LDR) {
+    // the loader's first stage has landed; this wave's own epilogue stores of the previous tile may
+    // stay in flight (a bare barrier: the contraction waves never wait on vmcnt)
+    // (asm with a memory clobber: the compiler must not move LDS reads across it either)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  } else {
+    issue(c0);
+    if (LOOK > 1 && c0 + 1 < c1) issue(c0 + 1);
+    // (the epilogue stores of the previous tile may still be in flight and complete out of order
+    // with loads: a full drain here, partial waits only inside the loop)
+    __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0)
+    __syncthreads();
+  }
   for (int st = c0; st < c1; ++st) {
     const int buf = (st - c0) % NBUF;
     const int cg = st / TCH, tc = st - cg * TCH;
     const bool ahead = st + LOOK < c1;
-    if (ahead) issue(st + LOOK);
+    if (!LDR && ahead) issue(st + LOOK);
     const u32x4* Wl = Wl0 + buf * WPIECES;
     const u32x4* Il = Il0 + (cg & 1) * IPIECES;
 #pragma unroll
@@ -581,9 +652,13 @@ __global__ __launch_bounds__(256, (NPL == 1 && NB == 128) ? 3 : 2) void corr_bf2
         }
       }
     }
-    // the NEXT stage's DMA has landed: only the group issued above may still be outstanding
-    bf2_wait_vm((LOOK > 1 && ahead) ? group(st + LOOK) : 0);
-    __syncthreads();
+    if (LDR) {
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // this stage's LDS reads have returned
+    } else {
+      // the NEXT stage's DMA has landed: only the group issued above may still be outstanding
+      bf2_wait_vm((LOOK > 1 && ahead) ? group(st + LOOK) : 0);
+      __syncthreads();
+    }
   }
 
   if (partial)
@@ -673,8 +748,27 @@ static int launch_pack(const PackArgs& pa, int planes, hipStream_t st) {
   return segan_check_launch("act_pack_kernel");
 }
 
+// SEGAN_BF2_LDR=0 keeps the DMA on the four contraction waves (round 3's form; A/B switch)
+static bool bf2_loader_on() {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("SEGAN_BF2_LDR");
+    on = e ? atoi(e) : 1;
+  }
+  return on != 0;
+}
+
+template <int NB, int WM, int U, bool IN_HI, bool OUT_HI, int SHIFTMASK, int NPL, bool LDR>
+static int launch_bf2_v(CorrArgs a, Bf2Extra x, hipStream_t st);
+
 template <int NB, int WM, int U, bool IN_HI, bool OUT_HI, int SHIFTMASK, int NPL>
 static int launch_bf2(CorrArgs a, Bf2Extra x, hipStream_t st) {
+  return bf2_loader_on() ? launch_bf2_v<NB, WM, U, IN_HI, OUT_HI, SHIFTMASK, NPL, true>(a, x, st)
+                         : launch_bf2_v<NB, WM, U, IN_HI, OUT_HI, SHIFTMASK, NPL, false>(a, x, st);
+}
+
+template <int NB, int WM, int U, bool IN_HI, bool OUT_HI, int SHIFTMASK, int NPL, bool LDR>
+static int launch_bf2_v(CorrArgs a, Bf2Extra x, hipStream_t st) {
   constexpr int MB = 128;
   constexpr int S = 32 / U;
   constexpr int TU = (NPL == 3) ? 1 : (U >= 8 ? 4 : U);   // bf16x3: 3 planes per tap fill the LDS
@@ -687,7 +781,8 @@ static int launch_bf2(CorrArgs a, Bf2Extra x, hipStream_t st) {
     return SEGAN_EUNSUPPORTED;
   }
   const size_t lds = (size_t)((BF2_LOOK(NPL) + 1) * NPL * TU * 2 * MB + 2 * NPL * 2 * a.RLs) * 16;
-  auto kern = corr_bf2_kernel<MB, NB, WM, U, OUT_HI, SHIFTMASK, NPL, TU>;
+  auto kern = corr_bf2_kernel<MB, NB, WM, U, OUT_HI, SHIFTMASK, NPL, TU, LDR>;
+  constexpr int NTHR = LDR ? 320 : 256;
   static bool attr_done[16];
   static int occ[16];
   static size_t occ_lds[16];
@@ -716,7 +811,7 @@ static int launch_bf2(CorrArgs a, Bf2Extra x, hipStream_t st) {
   if (sk_on && a.act == SEGAN_ACT_NONE && ntiles >= 64 && nst >= 8 && classic_eff < 0.97) {
     if (occ[dev] == 0 || occ_lds[dev] != lds) {
       int nb = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), 256,
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), NTHR,
                                                        lds) != hipSuccess || nb < 1)
         nb = 1;
       occ[dev] = nb > 4 ? 4 : nb;
@@ -731,7 +826,7 @@ static int launch_bf2(CorrArgs a, Bf2Extra x, hipStream_t st) {
       grid = (unsigned)G;
     }
   }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a, x);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), lds, st, a, x);
   if (int e = segan_check_launch("corr_bf2_kernel")) return e;
   if (a.sk_total > 0) {
     hipLaunchKernelGGL((bf2_fixup_kernel<MB, NB, WM, U, OUT_HI>), dim3(ntiles - a.sk_nfull), dim3(256),

@@ -144,6 +144,14 @@ __global__ void bn_partial_kernel(const float* __restrict__ x, float* __restrict
   }
 }
 
+// BatchNorm as the per-channel affine map the consumers apply: y = fmaf(x, scale, shift).  One
+// definition for the forward (bn_final_kernel) and the backward (act_bwd_kernel).
+__device__ __forceinline__ void bn_affine(float gamma, float beta, float mean, float rstd,
+                                          float& scale, float& shift) {
+  scale = gamma * rstd;
+  shift = fmaf(-mean, scale, beta);
+}
+
 __global__ void bn_final_kernel(const float* __restrict__ ws, const float* gamma, const float* beta,
                                 float eps, float momentum, float* running_mean, float* running_var,
                                 float* mean_o, float* rstd_o, float* scale_o, float* shift_o, int C,
@@ -166,11 +174,12 @@ __global__ void bn_final_kernel(const float* __restrict__ ws, const float* gamma
   const float rstd = (float)(1.0 / sqrt(var + (double)eps));
   const float g = gamma ? gamma[c] : 1.0f;
   const float bt = beta ? beta[c] : 0.0f;
-  const float sc = g * rstd;
+  float sc, sh;
+  bn_affine(g, bt, (float)mean, rstd, sc, sh);
   if (mean_o) mean_o[c] = (float)mean;
   if (rstd_o) rstd_o[c] = rstd;
   if (scale_o) scale_o[c] = sc;
-  if (shift_o) shift_o[c] = bt - (float)mean * sc;
+  if (shift_o) shift_o[c] = sh;
   if (running_mean) running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
   if (running_var) {
     const double unb = n > 1 ? m2 / (n - 1.0) : var;
@@ -340,12 +349,17 @@ __global__ void act_bwd_kernel(const ActBwdArgs p) {
   const int nb = cr.b_end - cr.b_beg;
   const float sl = p.slope ? p.slope[c] : 1.0f;
   const float al = p.alpha ? p.alpha[c] : 0.0f;
-  float mu = 0.f, rs = 1.f, ga = 1.f, be = 0.f, dbeta_m = 0.f, dgamma_m = 0.f;
+  float mu = 0.f, rs = 1.f, ga = 1.f, be = 0.f, dbeta_m = 0.f, dgamma_m = 0.f, sc = 1.f, sh = 0.f;
   if (PHASE != 0) {
     mu = p.mean[c];
     rs = p.rstd[c];
     ga = p.gamma ? p.gamma[c] : 1.0f;
     be = p.beta ? p.beta[c] : 0.0f;
+    // the forward's per-channel (scale, shift), bit for bit (bn_affine is what bn_final_kernel
+    // stores): the PReLU side of an element is decided by the SAME fmaf(a, scale, shift) the
+    // consuming contraction applied while staging it, so forward and backward agree on every
+    // gate also where the normalised value is within roundoff of zero
+    bn_affine(ga, be, mu, rs, sc, sh);
   }
   if (PHASE == 2) {
     const float* tot = p.ws + (size_t)p.nsplit * p.C * 4 + (size_t)c * 2;
@@ -367,7 +381,7 @@ __global__ void act_bwd_kernel(const ActBwdArgs p) {
       return g;
     }
     const float xh = (av - mu) * rs;
-    const float v = fmaf(ga, xh, be);
+    const float v = fmaf(av, sc, sh);
     const float g = dh * (v > 0.f ? 1.0f : sl);
     if (PHASE == 1) {
       r[0] += dh * (v > 0.f ? 0.0f : v);

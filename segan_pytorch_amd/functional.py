@@ -542,6 +542,7 @@ class DiscriminatorFn(torch.autograd.Function):
         ctx.state = (cs, srcs, bns, head, W)
         disc._last_fwd = (cs, xfs)      # for the lazy int_act dict
         disc._last_extra = extra
+        disc._last_head = head          # linear outputs of the head (gate-aligned parity tests)
         return out
 
     @staticmethod

@@ -329,3 +329,36 @@ def test_wsegan_interf_pair_literal_train_replay(flavour):
         if not torch.is_floating_point(v) or k.endswith(('conv.bias', 'norm.running_mean')):
             continue
         assert (D[k] - v).abs().max().item() < 5e-5, k
+
+
+def test_gate_hook_with_own_gates_is_the_identity(tiny_step):
+    """oracle `gates=` (test hook of the gate-aligned gradient comparisons, segan_oracle._prelu):
+    imposing the sides the oracle takes by itself changes neither outputs nor gradients — the
+    hook alters the PReLU side of an element and nothing else — and imposing a flipped side on
+    one element changes the gradients (the hook is live)."""
+    fx = tiny_step
+    st = fx['opts']['genc_poolings']
+
+    def run(gg=None, gd=None):
+        G = {k: v.clone().requires_grad_(True) for k, v in fx['G0'].items()}
+        D = {k: (v.clone().requires_grad_(True) if k.split('.')[-1] not in O._BUFFERS else v.clone())
+             for k, v in fx['D0'].items()}
+        y, hall = O.generator_forward(G, fx['noisy'], fx['z'], st, ret_hid=True, gates=gg)
+        d, acts = O.discriminator_forward(D, torch.cat((y, fx['noisy']), 1), fx['rolls'][2], st,
+                                          ret_act=True, gates=gd)
+        loss = (d.view(-1) - 1).pow(2).mean() + 100.0 * (y - fx['clean']).abs().mean()
+        ps = [v for v in list(G.values()) + list(D.values()) if v.requires_grad]
+        return y, d, hall, acts, torch.autograd.grad(loss, ps, allow_unused=True)
+
+    y, d, hall, acts, gr = run()
+    gg = {k: v > 0 for k, v in hall.items() if k != 'enc_zc' and k != 'dec_{}'.format(len(st) - 1)}
+    gd = {k: acts['a_' + k[2:]] > 0 for k in acts if k.startswith('h_')}
+    gd['fc_1'], gd['fc_3'] = acts['fc_a1'] > 0, acts['fc_a3'] > 0
+    y2, d2, _, _, gr2 = run(gg, gd)
+    assert torch.equal(y, y2) and torch.equal(d, d2)
+    for a, b in zip(gr, gr2):
+        assert (a is None and b is None) or torch.equal(a, b)
+    gd['h_1'] = gd['h_1'].clone()
+    gd['h_1'][0, 0, 0] = ~gd['h_1'][0, 0, 0]
+    _, _, _, _, gr3 = run(gg, gd)
+    assert any(a is not None and not torch.equal(a, b) for a, b in zip(gr, gr3))
