@@ -557,6 +557,8 @@ def main():
     torch.manual_seed(2000 + rank)
     if args.device_z:
         model.G.z_generator = torch.Generator(device=dev).manual_seed(rank)
+    else:
+        model.G.z_prefetch = not args.wsegan      # as SEGAN.train runs it: next z drawn one step ahead
 
     names = ['utt_additive_{}'.format(i) if i % 2 == 0 else 'utt_{}'.format(i) for i in range(B)]
 
@@ -577,6 +579,8 @@ def main():
     if not args.no_kernel_timer:
         timer = KernelTimer()
         timer.install()
+    if world > 1:
+        sdist.set_profile(True)         # two event records per optimizer step: comm_stats below
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -590,6 +594,43 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     finite = all(bool(torch.isfinite(x)) for x in losses_out)
+
+    # ---- the first multi-GPU run diagnoses itself (round-3 review, item 6): what the gradient
+    # exchange cost in the timed steps, and the same steps with the OTHER transport ----
+    comm = None
+    if world > 1:
+        comm = sdist.comm_stats()
+        sdist.set_profile(False)
+        for a in comm['arenas']:
+            a['wait_device_ms_per_step'] = a.pop('wait_device_ms') / args.steps
+            a['wait_host_ms_per_step'] = a.pop('wait_host_ms') / args.steps
+        # max over ranks of the device time the compute stream waited for collectives per step
+        w = torch.tensor([sum(a['wait_device_ms_per_step'] for a in comm['arenas'])],
+                         device=dev if backend == 'nccl' else 'cpu', dtype=torch.float64)
+        torch.distributed.all_reduce(w, op=torch.distributed.ReduceOp.MAX)
+        comm['comm_wait_ms_per_step'] = float(w.item())
+        comm['ms_per_step'] = {('native' if sdist.native_comm() is not None else 'torch.distributed'):
+                               1e3 * dt / args.steps}
+        if backend == 'nccl' and not args.no_modes:
+            was_native = sdist.native_comm() is not None
+            try:
+                sdist.set_native(not was_native)
+                for _ in range(2):
+                    one_step()
+                barrier()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    one_step()
+                barrier()
+                dd = time.perf_counter() - t1
+                t = torch.tensor([dd], device=dev, dtype=torch.float64)
+                torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+                comm['ms_per_step']['torch.distributed' if was_native else 'native'] = \
+                    1e3 * float(t.item()) / args.steps
+            except Exception as e:      # a side measurement must never cost the headline line
+                comm['other_transport_error'] = repr(e)
+            finally:
+                sdist.set_native(was_native)
 
     # what reproducibility costs: the same K steps in the OTHER reduction mode (the default —
     # and the timed one — adds the weight-gradient / dense-head contraction splits with fp32
@@ -715,8 +756,10 @@ def main():
                                         B, 'fp32' if fp32_run else args.precision +
                                         ' contractions (side configuration, not the headline)'),
                        'global_batch': B * world, 'parallelism': 'dp{}'.format(world),
-                       'z': 'device generator' if args.device_z else 'host randn + H2D per step (as train.py)'},
+                       'z': 'device generator' if args.device_z else 'host randn (one step ahead on a host thread, as SEGAN.train) + H2D per step'},
             'losses_finite': finite,
+            'comm': comm,
+            'comm_wait_ms_per_step': comm['comm_wait_ms_per_step'] if comm else None,
             'precision': args.precision,
             'reduction_mode': ('deterministic (fixed-order reductions, SEGAN_DETERMINISTIC=1)' if timed_det else
                                'default: fp32 atomics in the weight-gradient / dense-head contraction splits'),
@@ -817,6 +860,7 @@ def main():
             except Exception as e:
                 line['cpu_baseline'] = {'error': repr(e)}
         print(json.dumps(line))
+    sdist.destroy_native()
     if world > 1:
         torch.distributed.destroy_process_group()
 

@@ -97,8 +97,9 @@ int segan_pack_weights_bf(const float* w, void* out, int M, int N, int K, int S,
  * both channel segments, padding, roll and polyphase split applied), from where both MFMA operands
  * stream into LDS by LDS-DMA.  op: 0 conv forward, 1 conv data gradient, 2 deconv forward,
  * 3 deconv data gradient; N, M as in that entry point; L = length of the HIGH-rate side; pad =
- * its padL / pad argument.  Pass a buffer of at least this size as `scratch`; without one the
- * round-1 kernels (conversion inside the contraction) run. */
+ * its padL / pad argument.  Pass a buffer of at least this size as `scratch`; without one (or for
+ * a geometry the bf16 kernels do not cover) the entry point returns SEGAN_EUNSUPPORTED and the
+ * caller repeats the call with SEGAN_PREC_FP32 and the fp32 weight packing. */
 size_t segan_bf16_scratch_bytes(int op, int B, int N, int M, int L, int K, int S, int pad, int planes);
 /* Scratch of the four forward / data-gradient contractions below (`scratch`, `scratch_bytes`;
  * may be NULL / 0).  The fp32 kernels run whole rounds of equal tiles one per workgroup and cut

@@ -1020,8 +1020,8 @@ __global__ void pack_g_kernel(const float* __restrict__ w, float* __restrict__ w
 
 // diagnostics: how the last forward / data-gradient contraction of this thread was launched
 static thread_local int g_last_corr[6];
-static void note_launch(int kind, unsigned grid, const CorrArgs& a, int ntiles) {
-  g_last_corr[0] = kind;             // 1 corr_kernel, 2 corr2_kernel
+void segan_note_corr_launch(int kind, unsigned grid, const CorrArgs& a, int ntiles) {
+  g_last_corr[0] = kind;             // 1 corr_kernel, 2 corr2_kernel, 3 corr_bf2_kernel (bf16 / bf16x3)
   g_last_corr[1] = (int)grid;
   g_last_corr[2] = ntiles;
   g_last_corr[3] = a.sk_nfull;       // tiles run whole; the other ntiles - sk_nfull were cut (stream-K)
@@ -1110,7 +1110,7 @@ static int launch_corr_t(CorrArgs a, hipStream_t st, bool allow_sk) {
   const int nch = ceil_div(a.Ktot, KC);
   const unsigned grid = plan_streamk(a, ntiles, nch, resident_per_cu(kern, lds, occ, occ_lds),
                                      (size_t)MB * NB, allow_sk);
-  note_launch(1, grid, a, ntiles);
+  segan_note_corr_launch(1, grid, a, ntiles);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
   if (int e = segan_check_launch("corr_kernel")) return e;
   if (a.sk_total > 0) {
@@ -1142,7 +1142,7 @@ static int launch_corr2_x(CorrArgs a, hipStream_t st, bool allow_sk) {
   const int nch = ceil_div(a.Ktot, KC);
   const unsigned grid = plan_streamk(a, ntiles, nch, resident_per_cu(kern, lds, occ, occ_lds),
                                      (size_t)MB * NB, allow_sk);
-  note_launch(2, grid, a, ntiles);
+  segan_note_corr_launch(2, grid, a, ntiles);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
   if (int e = segan_check_launch("corr2_kernel")) return e;
   if (a.sk_total > 0) {
@@ -1324,8 +1324,7 @@ extern "C" int segan_conv1d_fwd(const segan_src* x, const void* wf, const float*
   if (precision) {
     CorrArgs a2 = a;
     const int e = segan_corr_bf2_f(a2, U, wf, precision, scratch, scratch_bytes, (hipStream_t)stream);
-    if (e != SEGAN_EUNSUPPORTED) return e;
-    return segan_corr_bf_f(a, U, wf, precision, (hipStream_t)stream);
+    return e;      // SEGAN_EUNSUPPORTED: the caller runs the fp32 form of this geometry
   }
   if (N <= 2) return segan_launch_fsmall(a, M, N, S, (hipStream_t)stream);
   set_scratch(a, scratch, scratch_bytes);
@@ -1365,8 +1364,7 @@ extern "C" int segan_deconv1d_dgrad(const float* dy, const void* wf, float* dx0,
   if (precision) {
     CorrArgs a2 = a;
     const int e = segan_corr_bf2_f(a2, U, wf, precision, scratch, scratch_bytes, (hipStream_t)stream);
-    if (e != SEGAN_EUNSUPPORTED) return e;
-    return segan_corr_bf_f(a, U, wf, precision, (hipStream_t)stream);
+    return e;      // SEGAN_EUNSUPPORTED: the caller runs the fp32 form of this geometry
   }
   set_scratch(a, scratch, scratch_bytes);
   return launch_corr<true, false>(a, U, (hipStream_t)stream);
@@ -1413,8 +1411,7 @@ extern "C" int segan_deconv1d_fwd(const segan_src* x, const void* wt, const floa
   if (precision && act == SEGAN_ACT_NONE) {
     CorrArgs a2 = a;
     const int e = segan_corr_bf2_t(a2, U, wt, precision, scratch, scratch_bytes, (hipStream_t)stream);
-    if (e != SEGAN_EUNSUPPORTED) return e;
-    return segan_corr_bf_t(a, U, wt, precision, (hipStream_t)stream);
+    return e;      // SEGAN_EUNSUPPORTED: the caller runs the fp32 form of this geometry
   }
   SEGAN_REQUIRE(precision == 0, "deconv1d_fwd: tanh epilogue only on the fp32 path");
   set_scratch(a, scratch, scratch_bytes);
@@ -1466,8 +1463,7 @@ extern "C" int segan_conv1d_dgrad(const float* da, const void* wt, const float* 
     e = segan_launch_tsmall(a, w, K, M, N, S, 0, st);
   } else if (precision) {
     CorrArgs a2 = a;
-    e = segan_corr_bf2_t(a2, U, wt, precision, scratch, scratch_bytes, st);
-    if (e == SEGAN_EUNSUPPORTED) e = segan_corr_bf_t(a, U, wt, precision, st);
+    e = segan_corr_bf2_t(a2, U, wt, precision, scratch, scratch_bytes, st);      // may decline
   } else {
     e = launch_corr<false, true>(a, U, st);
   }

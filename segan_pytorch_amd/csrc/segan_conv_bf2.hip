@@ -355,6 +355,9 @@ struct Bf2Extra {
 #ifndef BF2_LDR_EU
 #define BF2_LDR_EU 4      // waves per SIMD the loader variant is compiled for (experiment switch)
 #endif
+#ifndef BF2_NLW
+#define BF2_NLW 1         // loader waves per workgroup (experiment switch)
+#endif
 
 // s_waitcnt vmcnt(n) for a run-time n (the instruction takes an immediate): loads — LDS-DMA
 // included — return in order, so "at most n outstanding" = all but the newest n have landed
@@ -382,7 +385,7 @@ __device__ __forceinline__ void bf2_wait_vm(int n) {
 // 32; moved to a wave of their own they overlap with the other waves' MFMAs, and the next tile's
 // first stage is already in flight while the contraction waves store the previous tile.
 template <int MB, int NB, int WM, int U, bool OUT_HI, int SHIFTMASK, int NPL, int TU, bool LDR>
-__global__ __launch_bounds__(LDR ? 320 : 256, (NPL == 1 && NB == 128) ? (LDR ? BF2_LDR_EU : 3) : 2) void corr_bf2_kernel(const CorrArgs a, const Bf2Extra x) {
+__global__ __launch_bounds__(LDR ? 256 + 64 * BF2_NLW : 256, (NPL == 1 && NB == 128) ? (LDR ? BF2_LDR_EU : 3) : 2) void corr_bf2_kernel(const CorrArgs a, const Bf2Extra x) {
   constexpr int S = 32 / U;
   constexpr int WN = 4 / WM;
   constexpr int NI = MB / (32 * WM);
@@ -452,7 +455,8 @@ __global__ __launch_bounds__(LDR ? 320 : 256, (NPL == 1 && NB == 128) ? (LDR ? B
   const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<char*>(reinterpret_cast<const char*>(x.act)) + (size_t)ct.b0 * sample_bytes, 0,
       (int)(left + 2 * x.a_plane_bytes < 0x7fffffffL ? left + 2 * x.a_plane_bytes : 0x7fffffffL), 0x00020000);
-  if (LDR && wave == 4) {
+  if (LDR && wave >= 4) {
+    const int lw = wave - 4;
     // ---- the loader wave: all DMA of the tile, one stage ahead of the contraction waves ----
     int avo6[2 * KI];
 #pragma unroll
@@ -483,7 +487,7 @@ __global__ __launch_bounds__(LDR ? 320 : 256, (NPL == 1 && NB == 128) ? (LDR ? B
             const long soff = (long)p * x.a_plane_bytes + ((long)(2 * cg + g2) * x.Qp) * 16;
 #pragma unroll
             for (int pb = 0; pb < 2 * KI; ++pb)
-              if (pb < x.nld)
+              if (pb < x.nld && (pb % BF2_NLW) == lw)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(
                     ars, (__attribute__((address_space(3))) void*)(Il + (p * 2 + g2) * RLs + 64 * pb), 16,
                     avo6[pb], (int)soff, 0, 0);
@@ -492,6 +496,7 @@ __global__ __launch_bounds__(LDR ? 320 : 256, (NPL == 1 && NB == 128) ? (LDR ? B
       u32x4* Wl = Wl0 + ((st - c0) % NBUF) * WPIECES;
 #pragma unroll
       for (int q = 0; q < WINS; ++q) {
+        if ((q % BF2_NLW) != lw) continue;
         const int i = q & 1, g = (q >> 1) & 1, tu = (q >> 2) % TU, p = q / (4 * TU);
         const long soff = (long)p * x.w_plane * 2 + ((long)((st * TU + tu) * 2 + g) * a.RP) * 16;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(
@@ -731,6 +736,131 @@ __global__ __launch_bounds__(256) void bf2_fixup_kernel(const CorrArgs a, int ns
 }
 
 // ====================================================================================
+// packing: w[m][n][K] fp32 -> NPL bf16 planes in the kernel's tile order
+// ====================================================================================
+// F: piece (cg,u,g,row) holds channels cv = 16cg+8g+e = (n,r): w[row][n][S*u+r]
+// T: piece (cg,u',g,row=(r,nn)) holds channels m = 16cg+8g+e: w[m][nn][S*(U-1-u')+rho(r)]
+//
+// Both are transposes through LDS so that the global reads run along the K taps of consecutive
+// (m, n) rows and the 16-byte piece writes along consecutive rows (round 1's one-thread-per-piece
+// kernel read 8 floats at a stride of N*K per lane: 0.96 ms per step for 1.1 GB of traffic).
+//
+// F form: one block = 64 rows m x one half-group g (8 virtual channels = 8/S real channels),
+// all U taps: reads w[m][n0 .. n0 + 8/S)[0..K) (contiguous per row), writes U x 64 pieces.
+__global__ __launch_bounds__(256) void pack_bf_f_kernel(const float* __restrict__ w,
+                                                        __bf16* __restrict__ out, long plane_stride,
+                                                        int planes, int M, int N, int K, int S, int U,
+                                                        int RP) {
+  extern __shared__ float tf[];                    // [RT rows][W + 1]: (channel in group, tap)
+  const int hg = blockIdx.y;                       // 2*cg + g
+  const int NC = 8 / S;                            // real channels of this half-group
+  const int n0 = hg * NC;
+  const int tid = threadIdx.x;
+  const int W = NC * 32;                           // floats staged per row (taps padded to 32)
+  const int RT = S == 1 ? 32 : 64;                 // rows per block (LDS: RT * (W + 1) floats)
+  const int m0 = blockIdx.x * RT;
+  auto t = [&](int ml, int x) -> float& { return tf[ml * (W + 1) + x]; };
+  for (int e = tid; e < RT * W; e += 256) {
+    const int ml = e / W, x = e - ml * W;
+    const int c = x >> 5, k = x & 31;
+    const int m = m0 + ml, n = n0 + c;
+    t(ml, x) = (m < M && n < N && k < K) ? w[((size_t)m * N + n) * K + k] : 0.0f;
+  }
+  __syncthreads();
+  for (int e = tid; e < U * RT; e += 256) {
+    const int u = e / RT, ml = e - u * RT;
+    if (m0 + ml >= RP) continue;
+    bf16x8 pl[3];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int c = q / S, r = q % S;              // virtual channel q of the half-group = (c, r)
+      __bf16 p1, p2, p3;
+      split3b(t(ml, c * 32 + S * u + r), p1, p2, p3);
+      pl[0][q] = p1; pl[1][q] = p2; pl[2][q] = p3;
+    }
+    const long pc = ((long)((hg >> 1) * U + u) * 2 + (hg & 1)) * RP + m0 + ml;
+    for (int p = 0; p < planes; ++p)
+      *reinterpret_cast<u32x4*>(out + p * plane_stride + pc * 8) = __builtin_bit_cast(u32x4, pl[p]);
+  }
+}
+
+// T form: one block = 8 channels m (one half-group) x 64 output channels nn, all taps: reads
+// w[m][nn0 .. nn0+64)[0..K) (one contiguous run per m), writes (U taps x S phases) x 64 pieces.
+__global__ __launch_bounds__(256) void pack_bf_t_kernel(const float* __restrict__ w,
+                                                        __bf16* __restrict__ out, long plane_stride,
+                                                        int planes, int M, int N, int K, int S, int U,
+                                                        int RP, int NP, int pad) {
+  __shared__ float t[8][32 * 33];                 // [m][nn (pitch 33)][tap]
+  const int hg = blockIdx.y;
+  const int nn0 = blockIdx.x * 32;
+  const int tid = threadIdx.x;
+  for (int e = tid; e < 8 * 32 * 32; e += 256) {
+    const int ml = e >> 10, x = e & 1023;
+    const int nl = x >> 5, k = x & 31;
+    const int m = 8 * hg + ml, nn = nn0 + nl;
+    t[ml][nl * 33 + k] = (m < M && nn < N && k < K) ? w[((size_t)m * N + nn) * K + k] : 0.0f;
+  }
+  __syncthreads();
+  for (int e = tid; e < U * S * 32; e += 256) {
+    const int nl = e & 31;
+    const int ur = e >> 5;                        // u' * S + r
+    const int up = ur / S, r = ur - up * S;
+    const int nn = nn0 + nl;
+    if (nn >= NP) continue;
+    const int rho = (r + pad) % S;
+    const int k = S * (U - 1 - up) + rho;
+    bf16x8 pl[3];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      __bf16 p1, p2, p3;
+      split3b(t[q][nl * 33 + k], p1, p2, p3);
+      pl[0][q] = p1; pl[1][q] = p2; pl[2][q] = p3;
+    }
+    const long pc = ((long)((hg >> 1) * U + up) * 2 + (hg & 1)) * RP + (long)r * NP + nn;
+    for (int p = 0; p < planes; ++p)
+      *reinterpret_cast<u32x4*>(out + p * plane_stride + pc * 8) = __builtin_bit_cast(u32x4, pl[p]);
+  }
+}
+
+static inline int bf_f_pitch(int M) { return round_up(M, 128); }
+
+extern "C" size_t segan_packed_bf_bytes(int M, int N, int S, int tform, int planes) {
+  if (!(S == 1 || S == 2 || S == 4) || M <= 0 || N <= 0 || planes < 1 || planes > 3) return 0;
+  const int U = 32 / S;
+  if (!tform) {
+    const int ng = ceil_div(N * S, 16);
+    return (size_t)planes * ng * U * 2 * bf_f_pitch(M) * 8 * sizeof(__bf16);
+  }
+  const int ng = ceil_div(M, 16);
+  return (size_t)planes * ng * U * 2 * (S * t_np(N, S)) * 8 * sizeof(__bf16);
+}
+
+extern "C" int segan_pack_weights_bf(const float* w, void* out, int M, int N, int K, int S,
+                                     int tform, int pad_t, int planes, void* stream) {
+  SEGAN_REQUIRE(w && out, "pack_weights_bf: NULL pointer");
+  SEGAN_REQUIRE(S == 1 || S == 2 || S == 4, "pack_weights_bf: stride %d not in {1,2,4}", S);
+  SEGAN_REQUIRE(K >= 1 && K <= 32 && M > 0 && N > 0, "pack_weights_bf: bad sizes");
+  SEGAN_REQUIRE(planes == 1 || planes == 3, "pack_weights_bf: planes must be 1 or 3");
+  const int U = 32 / S;
+  const int NP = t_np(N, S);
+  const int RP = tform ? S * NP : bf_f_pitch(M);
+  const int ng = tform ? ceil_div(M, 16) : ceil_div(N * S, 16);
+  const long npieces = (long)ng * U * 2 * RP;
+  const long plane_stride = npieces * 8;
+  hipStream_t st = (hipStream_t)stream;
+  if (!tform) {
+    const int RT = S == 1 ? 32 : 64;
+    const size_t lds = (size_t)RT * ((8 / S) * 32 + 1) * sizeof(float);
+    hipLaunchKernelGGL(pack_bf_f_kernel, dim3(RP / RT, 2 * ng), dim3(256), lds, st, w, (__bf16*)out,
+                       plane_stride, planes, M, N, K, S, U, RP);
+  } else {
+    hipLaunchKernelGGL(pack_bf_t_kernel, dim3(ceil_div(NP, 32), 2 * ng), dim3(256), 0, st, w,
+                       (__bf16*)out, plane_stride, planes, M, N, K, S, U, RP, NP, pad_t);
+  }
+  return segan_check_launch("pack_weights_bf");
+}
+
+// ====================================================================================
 // launchers
 // ====================================================================================
 static inline int bf2_groups16(int Cv) { return ceil_div(Cv, 16); }
@@ -782,7 +912,7 @@ static int launch_bf2_v(CorrArgs a, Bf2Extra x, hipStream_t st) {
   }
   const size_t lds = (size_t)((BF2_LOOK(NPL) + 1) * NPL * TU * 2 * MB + 2 * NPL * 2 * a.RLs) * 16;
   auto kern = corr_bf2_kernel<MB, NB, WM, U, OUT_HI, SHIFTMASK, NPL, TU, LDR>;
-  constexpr int NTHR = LDR ? 320 : 256;
+  constexpr int NTHR = LDR ? 256 + 64 * BF2_NLW : 256;
   static bool attr_done[16];
   static int occ[16];
   static size_t occ_lds[16];
@@ -827,6 +957,7 @@ static int launch_bf2_v(CorrArgs a, Bf2Extra x, hipStream_t st) {
     }
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), lds, st, a, x);
+  segan_note_corr_launch(3, grid, a, ntiles);
   if (int e = segan_check_launch("corr_bf2_kernel")) return e;
   if (a.sk_total > 0) {
     hipLaunchKernelGGL((bf2_fixup_kernel<MB, NB, WM, U, OUT_HI>), dim3(ntiles - a.sk_nfull), dim3(256),
@@ -837,7 +968,7 @@ static int launch_bf2_v(CorrArgs a, Bf2Extra x, hipStream_t st) {
 }
 
 // shared front end: geometry, packing pass, extra arguments.  Returns SEGAN_EUNSUPPORTED (the
-// caller then runs round 1's kernel) when the scratch is missing or too small.
+// caller then runs the fp32 form) when the scratch is missing or too small.
 // column-tile width: 128.  256-column tiles (half the weight bytes streamed per MFMA, two instead
 // of three workgroups per CU) were built and measured on every SEGAN+ layer (scripts/bench_layers.py):
 // within +-4 %, slower on most; dropped.

@@ -1,4 +1,4 @@
-// Declarations shared by the fp32 (segan_conv.hip) and split-bf16 (segan_conv_bf.hip)
+// Declarations shared by the fp32 (segan_conv.hip) and bf16 / bf16x3 (segan_conv_bf2.hip)
 // contraction kernels: column bookkeeping, launch arguments, packed-weight geometry.
 #pragma once
 #include "segan_common.h"
@@ -109,8 +109,6 @@ struct WgradArgs {
   int per_magic;          // ceil(65536 / (Ls + H)): LDS position -> sample when Ls < TK
   int bf_qc;              // bf16 kernel: time chunks per sample group
   int bf_cps;             // bf16 kernel: chunks per workgroup (split of the contraction)
-  void* lo_pk;            // bf16 kernel: scratch for the pre-packed lo operand (or NULL)
-  size_t lo_pk_plane;     // bytes between its planes
   int Mp;                 // its row pitch (M rounded up to 128)
   // wgrad2_kernel
   int w2_cps, w2_nch;     // chunks per contraction split, chunks in total
@@ -143,19 +141,20 @@ static inline int check_src(const segan_src* s, int C, const char* what) {
 int segan_launch_tsmall(CorrArgs& a, const float* w, int K, int M, int N, int S, int pad, hipStream_t st);
 int segan_launch_fsmall(CorrArgs& a, int M, int N, int S, hipStream_t st);
 
-// split-bf16 entry points (segan_conv_bf.hip); `a` is filled exactly as for the fp32 kernels
-int segan_corr_bf_f(CorrArgs& a, int U, const void* wp3, int planes, hipStream_t st);
-int segan_corr_bf_t(CorrArgs& a, int U, const void* wp3, int planes, hipStream_t st);
-// round-3 bf16 forms (segan_conv_bf2.hip): activations pre-packed into `scratch`, both operands by
-// LDS-DMA; SEGAN_EUNSUPPORTED when the scratch is missing / too small or the geometry is not covered
+// diagnostics record of the last forward / data-gradient launch (segan_debug_last_corr)
+void segan_note_corr_launch(int kind, unsigned grid, const CorrArgs& a, int ntiles);
+// bf16 / bf16x3 forms (segan_conv_bf2.hip); `a` is filled exactly as for the fp32 kernels:
+// activations pre-packed into `scratch`, both operands by LDS-DMA; SEGAN_EUNSUPPORTED when the
+// scratch is missing / too small or the geometry is not covered — the caller then runs the fp32
+// form (round 1's bf16 kernels, which used to take those cases, are gone)
 int segan_corr_bf2_f(CorrArgs& a, int U, const void* wp3, int planes, void* scratch,
                      size_t scratch_bytes, hipStream_t st);
 int segan_corr_bf2_t(CorrArgs& a, int U, const void* wp3, int planes, void* scratch,
                      size_t scratch_bytes, hipStream_t st);
 size_t segan_corr_bf2_scratch_bytes(int B, int Cv, int Tcols, int H, int planes);
-// wgrad on the bf16 matrix cores (segan_wgrad_bf.hip); planes = 1 (bf16) or 3 (bf16x3)
-int segan_wgrad_bf(WgradArgs& a, int U, int planes, hipStream_t st);
-size_t segan_wgrad_bf_scratch_bytes(int B, int M, int Ls, int planes);
-// round-3 form (segan_wgrad_bf2.hip): both operands pre-packed into `scratch`, LDS-DMA
+// wgrad on the bf16 matrix cores (segan_wgrad_bf2.hip), planes = 1 (bf16) or 3 (bf16x3): both
+// operands pre-packed into `scratch`, LDS-DMA; SEGAN_EUNSUPPORTED -> the caller runs the fp32 form
 int segan_wgrad_bf2(WgradArgs& a, int U, int planes, void* scratch, size_t scratch_bytes, hipStream_t st);
+// diagnostics record of the last weight-gradient launch (segan_debug_last_wgrad)
+void segan_note_wgrad_launch(int kind, int tiles, int nsplit, int chunks_per_split);
 size_t segan_wgrad_bf2_scratch_bytes(int B, int M, int N, int Ls, int S, int planes);

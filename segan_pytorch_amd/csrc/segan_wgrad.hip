@@ -641,6 +641,11 @@ __global__ void wgrad_lo_materialize_kernel(const segan_src lo, float* out, int 
 
 // diagnostics: how the last fp32 weight gradient of this thread was launched
 static thread_local int g_last_wgrad[6];
+// kind: 1 wgrad_kernel, 2 wgrad2_kernel, 3 wgrad_bf2_kernel (bf16 / bf16x3)
+void segan_note_wgrad_launch(int kind, int tiles, int nsplit, int chunks_per_split) {
+  g_last_wgrad[0] = kind; g_last_wgrad[1] = tiles; g_last_wgrad[2] = nsplit;
+  g_last_wgrad[3] = chunks_per_split; g_last_wgrad[4] = 0; g_last_wgrad[5] = 0;
+}
 extern "C" void segan_debug_last_wgrad(int* out6) {
   for (int i = 0; i < 6; ++i) out6[i] = g_last_wgrad[i];
 }
@@ -894,9 +899,7 @@ extern "C" size_t segan_wgrad_scratch_bytes(int B, int M, int N, int Ls, int S, 
   if (B <= 0 || M <= 0 || N <= 0 || Ls <= 0 || !stride_ok(S)) return 0;
   if (precision != SEGAN_PREC_FP32) {
     const int planes = precision == SEGAN_PREC_BF16 ? 1 : 3;
-    const size_t r1 = segan_wgrad_bf_scratch_bytes(B, M, Ls, planes);
-    const size_t r3 = segan_wgrad_bf2_scratch_bytes(B, M, N, Ls, S, planes);
-    return r1 > r3 ? r1 : r3;
+    return segan_wgrad_bf2_scratch_bytes(B, M, N, Ls, S, planes);
   }
   // room for a materialised lo, plus (deterministic mode) the partial tiles of every split:
   // at most max(tiles, 4 rounds of 1024 resident workgroups) tiles of 128 x 128
@@ -931,10 +934,8 @@ extern "C" int segan_wgrad(const segan_src* lo, const segan_src* hi, float* dw, 
   if (precision != SEGAN_PREC_FP32) {
     const int planes = precision == SEGAN_PREC_BF16 ? 1 : 3;
     WgradArgs a2 = a;
-    const int e = segan_wgrad_bf2(a2, 32 / S, planes, scratch, scratch_bytes, st);
-    if (e != SEGAN_EUNSUPPORTED) return e;
-    a.lo_pk = scratch;
-    return segan_wgrad_bf(a, 32 / S, planes, st);
+    // SEGAN_EUNSUPPORTED (geometry or scratch): the caller runs the fp32 form
+    return segan_wgrad_bf2(a2, 32 / S, planes, scratch, scratch_bytes, st);
   }
   const bool det = (flags & SEGAN_WGRAD_DETERMINISTIC) != 0;
   float* sc = (float*)scratch;

@@ -428,6 +428,7 @@ static int launch_wbf2(WgradArgs& w, void* scratch, size_t scratch_bytes, hipStr
     attr_done[dev] = true;
   }
   hipLaunchKernelGGL((wgrad_bf2_kernel<U, NPL, TQ>), dim3(ncol, nrow, nsplit), dim3(256), lds, st, a);
+  segan_note_wgrad_launch(3, ncol * nrow, nsplit, a.cps);
   return segan_check_launch("wgrad_bf2_kernel");
 }
 
@@ -436,6 +437,6 @@ int segan_wgrad_bf2(WgradArgs& a, int U, int planes, void* scratch, size_t scrat
                                  : launch_wbf2<8, 1>(a, scratch, scratch_bytes, st);
   if (U == 16) return planes == 3 ? launch_wbf2<16, 3>(a, scratch, scratch_bytes, st)
                                   : launch_wbf2<16, 1>(a, scratch, scratch_bytes, st);
-  segan_set_error("wgrad_bf2: stride 1 stays on the round-1 kernel");
+  segan_set_error("wgrad_bf2: stride 1 stays on the fp32 kernel");
   return SEGAN_EUNSUPPORTED;
 }

@@ -189,7 +189,7 @@ class PCMShardDataset(Dataset):
     """Items of a pcm16 shard: (uttname, int16 [2, T+1], first flag, slice_idx).  Use with
     `PCMShardCollate`, which turns a batch into the loader's [uttnames, clean, noisy,
     slice_idx] format with clean/noisy already on the GPU as fp32 — or, for the full-rate
-    training loop, with `pcm_shard_loader`, which gathers whole batches in worker processes."""
+    training loop, with `PCMShardLoader`, which gathers whole batches in worker processes."""
 
     def __init__(self, prefix):
         with open(prefix + '.json') as f:
@@ -273,12 +273,36 @@ class PCMShardLoader(object):
     def __len__(self):
         return len(self.loader)
 
-    def __iter__(self):
+    def _prep(self, item):
         from . import ops
-        for names, pcm, first, idx in self.loader:
-            clean, noisy = ops.pcm16_prep(pcm.to(self.device, non_blocking=True),
-                                          first.to(self.device, non_blocking=True), self.preemph)
-            yield [names, clean, noisy, idx]
+        names, pcm, first, idx = item
+        clean, noisy = ops.pcm16_prep(pcm.to(self.device, non_blocking=True),
+                                      first.to(self.device, non_blocking=True), self.preemph)
+        return [names, clean, noisy, idx]
+
+    def __iter__(self):
+        for item in self.loader:
+            yield self._prep(item)
+
+    def sample(self):
+        """One random batch per call from ONE live iterator, re-created only when the epoch is
+        exhausted — for WSEGAN's `sample_dloader`, which the reference writes as
+        `next(iter(dloader))` every step (model.py:526-535): on this loader that would reset the
+        persistent workers, wait for an un-prefetched first batch (20 MB over IPC + pinning) and
+        throw away up to three prefetched ones, every step (round-3 advice).  Batches then come
+        from a shuffled pass without replacement instead of a fresh shuffle per step."""
+        it = getattr(self, '_live', None)
+        if it is None:
+            it = self._live = iter(self.loader)
+        try:
+            item = next(it)
+        except StopIteration:
+            if hasattr(self.sampler, 'set_epoch'):
+                self._epoch = getattr(self, '_epoch', 0) + 1
+                self.sampler.set_epoch(self._epoch)
+            it = self._live = iter(self.loader)
+            item = next(it)
+        return self._prep(item)
 
 
 class PCMShardCollate(object):

@@ -19,6 +19,7 @@ On CPU tensors (gloo) the same code runs with torch arithmetic, which is what th
 world_size-2 tests exercise.
 """
 import os
+import time
 
 import torch
 import torch.distributed as dist
@@ -77,36 +78,63 @@ def init_from_env(backend=None):
     return rk, ws, lr
 
 
-# ---- the exchange through libsegan_hip's own RCCL communicator (SEGAN_COMM=native) ------------
-_native = None          # ops.Comm
+# ---- the exchange through libsegan_hip's own RCCL communicators (SEGAN_COMM=native) -----------
+_native = None          # ops.Comm of the gradient buckets: used on _native_stream ONLY
+_native_cur = None      # ops.Comm of everything issued on the CURRENT stream (synchronised
+                        # BatchNorm, allreduce_mean_, broadcast_params)
 _native_stream = None   # side stream the bucket all-reduces run on
 
 
 def native_comm():
-    """The library-owned RCCL communicator (C ABI: segan_comm_init / segan_allreduce /
-    segan_comm_destroy) when SEGAN_COMM=native, else None.  torch.distributed then only carries
-    the 128-byte rendezvous id (and the host-side barriers of the launch scripts); gradients,
-    initial weights and synchronised-BatchNorm statistics travel through the C ABI."""
+    """The library-owned RCCL communicator of the gradient buckets (C ABI: segan_comm_init /
+    segan_allreduce / segan_comm_destroy) when SEGAN_COMM=native, else None.  torch.distributed
+    then only carries the 128-byte rendezvous ids (and the host-side barriers of the launch
+    scripts); gradients, initial weights and synchronised-BatchNorm statistics travel through
+    the C ABI.  TWO communicators exist in that mode, one per stream that issues collectives:
+    the bucket all-reduces run on a side stream under the backward pass while the Sync-BN
+    exchanges of that same backward run on the compute stream — one communicator on two streams
+    would leave their relative order to RCCL's internal serialisation, which has to be identical
+    on every rank (round-3 advice); with a communicator per stream each one sees one program
+    order."""
     return _native
 
 
-def _init_native(rk, ws):
-    global _native, _native_stream
-    if _native is not None or os.environ.get('SEGAN_COMM') != 'native' or not torch.cuda.is_available():
+def _init_native(rk, ws, force=False):
+    global _native, _native_cur, _native_stream
+    if _native is not None or not torch.cuda.is_available():
         return
-    ident = [ops.comm_unique_id() if rk == 0 else None]
+    if not force and os.environ.get('SEGAN_COMM') != 'native':
+        return
+    ident = [(ops.comm_unique_id(), ops.comm_unique_id()) if rk == 0 else None]
     if ws > 1:
         dist.broadcast_object_list(ident, src=0)
-    _native = ops.Comm(ws, rk, ident[0])
+    _native = ops.Comm(ws, rk, ident[0][0])
+    _native_cur = ops.Comm(ws, rk, ident[0][1])
     _native_stream = torch.cuda.Stream()
 
 
+def set_native(on):
+    """Switch the data path between the library's own communicators and torch.distributed at
+    run time (bench.py times both in one process); creating them is a collective over all
+    ranks, so every rank must make the same call."""
+    if on:
+        _init_native(rank(), world_size(), force=True)
+    else:
+        destroy_native()
+    _reducers.clear()
+
+
 def destroy_native():
-    global _native, _native_stream
+    global _native, _native_cur, _native_stream
     if _native is not None:
         torch.cuda.synchronize()
         _native.destroy()
-        _native, _native_stream = None, None
+        _native_cur.destroy()
+        _native, _native_cur, _native_stream = None, None, None
+
+
+import atexit
+atexit.register(destroy_native)
 
 
 def allreduce_mean_(flat):
@@ -114,8 +142,8 @@ def allreduce_mean_(flat):
     ws = world_size()
     if ws <= 1:
         return flat
-    if _native is not None and flat.is_cuda:
-        return _native.allreduce(flat, 1.0 / ws)
+    if _native_cur is not None and flat.is_cuda:
+        return _native_cur.allreduce(flat, 1.0 / ws)
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     if flat.is_cuda:
         ops.scale_(flat, 1.0 / ws)
@@ -159,6 +187,7 @@ class GradReducer(object):
                 start = None
         self.armed = False
         self.pending, self.sent, self.works = [], [], []
+        self.wait_events, self.wait_host_s, self.finishes = [], 0.0, 0
 
     def arm(self, passes=1):
         """Call before the LAST backward() that adds to these gradients.  `passes`: how many
@@ -201,28 +230,77 @@ class GradReducer(object):
         """All buckets reduced (those never reported ready are sent now), then the mean."""
         if not self.armed:
             self.arm()
+        flat = self.opt.flat_grad
+        t0 = time.perf_counter()
+        e0 = None
+        if _profile and flat.is_cuda:
+            # how long the COMPUTE stream sits here for the collectives (device time between
+            # these two events): ~0 when the buckets finished under the backward pass
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+        late = 0
         for b in range(len(self.buckets)):
             if not self.sent[b]:
                 self._send(b)
+                late += 1
         for w in self.works:
             w.wait()
         self.armed = False
         self.works = []
-        flat = self.opt.flat_grad
         if getattr(self, 'native', False):
             done = torch.cuda.Event()
             done.record(_native_stream)
             torch.cuda.current_stream().wait_event(done)     # the optimizer step follows
-            self.native = False
-            return                                           # already scaled per bucket
-        if flat.is_cuda:
+            self.native = False                              # already scaled per bucket
+        elif flat.is_cuda:
             ops.scale_(flat, 1.0 / world_size())
         else:
             flat.mul_(1.0 / world_size())
+        if _profile:
+            self.finishes += 1
+            self.late_buckets = getattr(self, 'late_buckets', 0) + late
+            self.wait_host_s += time.perf_counter() - t0
+            if e0 is not None:
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record()
+                self.wait_events.append((e0, e1))
 
 
 _reducers = {}
 _active = None
+_profile = False
+
+
+def set_profile(on):
+    """Collect per-reducer wait statistics (comm_stats); off by default."""
+    global _profile
+    _profile = bool(on)
+    for r in _reducers.values():
+        r.wait_events, r.wait_host_s, r.finishes, r.late_buckets = [], 0.0, 0, 0
+
+
+def comm_stats():
+    """What the gradient exchange cost since set_profile(True), per optimizer arena (in creation
+    order: SEGAN.build_optimizers makes G's first): number of buckets and their sizes, how many
+    all-reduce rounds (`finishes`), how many buckets were only sent at finish() (not overlapped
+    with the backward), the device time the compute stream waited in finish() and the host time
+    spent there.  Synchronises the device."""
+    out = []
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    for r in _reducers.values():
+        out.append({
+            'arena_floats': int(r.opt._total),
+            'buckets': len(r.buckets),
+            'bucket_mb': [round((hi - lo) * 4 / 2 ** 20, 2) for lo, hi in r.buckets],
+            'finishes': r.finishes,
+            'late_buckets': getattr(r, 'late_buckets', 0),
+            'wait_device_ms': sum(a.elapsed_time(b) for a, b in r.wait_events),
+            'wait_host_ms': 1e3 * r.wait_host_s,
+        })
+    return {'backend': 'native (libsegan_hip RCCL communicators)' if _native is not None else
+            'torch.distributed ({})'.format(dist.get_backend() if dist.is_initialized() else 'none'),
+            'sync_bn': sync_bn_enabled(), 'bucket_target_mb': _bucket_bytes / 2 ** 20, 'arenas': out}
 
 
 def _reducer(optimizer):
@@ -274,8 +352,8 @@ def broadcast_params(module, src=0):
         return
     with torch.no_grad():
         for t in list(module.parameters()) + list(module.buffers()):
-            if _native is not None and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous():
-                _native.broadcast(t.data, src)
+            if _native_cur is not None and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous():
+                _native_cur.broadcast(t.data, src)
             else:
                 dist.broadcast(t.data, src)
     ops.bump_weights_epoch()
@@ -318,8 +396,8 @@ def sync_bn_enabled():
 
 def bn_stats_sync(x, gamma, beta, eps, momentum, running_mean, running_var):
     ws = ops.bn_partial(x)                                   # [nsplit, C, 3]
-    if _native is not None:
-        allp = _native.allgather(ws).view(-1, ws.shape[1], 3)
+    if _native_cur is not None:
+        allp = _native_cur.allgather(ws).view(-1, ws.shape[1], 3)
     else:
         parts = [torch.empty_like(ws) for _ in range(world_size())]
         dist.all_gather(parts, ws)
@@ -329,8 +407,8 @@ def bn_stats_sync(x, gamma, beta, eps, momentum, running_mean, running_var):
 
 def act_bwd_bn_sync(a, dh, slope, bn, dslope=None, dgamma=None, dbeta=None, dbias=None):
     totals, ws = ops.act_bwd_bn_reduce(a, dh, slope, bn, dslope, dgamma, dbeta)
-    if _native is not None:
-        _native.allreduce(totals, 1.0)
+    if _native_cur is not None:
+        _native_cur.allreduce(totals, 1.0)
     else:
         dist.all_reduce(totals, op=dist.ReduceOp.SUM)
     count = float(a.shape[0]) * float(a.shape[2]) * world_size()

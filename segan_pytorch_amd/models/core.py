@@ -49,9 +49,11 @@ class Saver(object):
     at ~3 TB/s: a fraction of a millisecond) followed by a device-to-host copy into pinned
     buffers on a side stream — and returns; a writer thread waits for the copy, serialises with
     torch.save into a temporary file and renames it into place.  The training loop goes on while
-    the reference's synchronous 0.7 GB torch.save (core.py:61-70) would block it; the file is
-    byte-for-byte what the synchronous path writes.  `wait()` joins the writer (called before
-    the next save, before loading, and at interpreter exit)."""
+    the reference's synchronous 0.7 GB torch.save (core.py:61-70) would block it; the file
+    holds what the synchronous path writes (same keys, tensors, `state_dict._metadata`).  The index
+    file is rewritten — and the rotated-out checkpoint deleted — only after the weights file is in
+    place.  `wait()` joins the writer (called before the next save, before loading, and at
+    interpreter exit)."""
 
     def __init__(self, model, save_path, max_ckpts=5, optimizer=None, prefix='', async_save=True):
         self.model = model
@@ -100,12 +102,15 @@ class Saver(object):
             events.append(ev)
             return buf
         if isinstance(obj, dict):
-            return type(obj)((k, self._snapshot(v, path + (k,), events)) for k, v in obj.items())
+            out = type(obj)((k, self._snapshot(v, path + (k,), events)) for k, v in obj.items())
+            if hasattr(obj, '_metadata'):      # nn.Module.state_dict()'s per-module versions
+                out._metadata = obj._metadata
+            return out
         if isinstance(obj, (list, tuple)):
             return type(obj)(self._snapshot(v, path + (i,), events) for i, v in enumerate(obj))
         return obj
 
-    def _write(self, payload, events, final):
+    def _write(self, payload, events, final, index, victim):
         try:
             for ev in events:
                 ev.synchronize()
@@ -115,8 +120,24 @@ class Saver(object):
             tmp = final + '.tmp'
             torch.save(payload, tmp)
             os.replace(tmp, final)
+            self._commit(index, victim)
         except BaseException as e:      # surfaced by the next wait()
             self._error = e
+
+    def _commit(self, index, victim):
+        """Publish a checkpoint whose weights file is complete: rewrite the index (atomically) so
+        that `current` never names a file that is not on disk — a crash mid-write leaves the
+        previous index and the previous checkpoint — and only then drop the rotated-out file."""
+        tmp = self.ckpt_path + '.tmp'
+        with open(tmp, 'w') as f:
+            f.write(json.dumps(index, indent=2))
+        os.replace(tmp, self.ckpt_path)
+        if victim is not None:
+            try:
+                print('Removing old ckpt {}'.format(victim))
+                os.remove(victim)
+            except FileNotFoundError:
+                print('ERROR: ckpt is not there?')
 
     def _read_index(self):
         if os.path.exists(self.ckpt_path):
@@ -133,30 +154,33 @@ class Saver(object):
             fname = 'best_' + fname
         fname = '{}{}'.format(self.prefix, fname)
         latest = index['latest']
-        # rotate: drop the oldest once more than max_ckpts are listed (core.py:40-51)
+        # rotate: drop the oldest once more than max_ckpts are listed (core.py:40-51) — after the
+        # new file is complete (the reference rewrites the index and deletes first, core.py:40-60;
+        # with training going on during the write, that order would leave `current` dangling on a
+        # crash)
+        victim = None
         if latest and self.max_ckpts is not None and len(latest) > self.max_ckpts:
             victim = os.path.join(self.save_path, 'weights_' + latest[0])
-            try:
-                print('Removing old ckpt {}'.format(victim))
-                os.remove(victim)
+            if os.path.exists(victim):
                 latest = latest[1:]
-            except FileNotFoundError:
+            else:
                 print('ERROR: ckpt is not there?')
+                victim = None
         latest = latest + [fname]
         index['latest'] = latest
         index['current'] = fname
-        with open(self.ckpt_path, 'w') as f:
-            f.write(json.dumps(index, indent=2))
         payload = {'step': step, 'state_dict': self.model.state_dict()}
         if self.optimizer is not None:
             payload['optimizer'] = self.optimizer.state_dict()
         final = os.path.join(self.save_path, 'weights_' + fname)
         if not self.async_save:
             torch.save(payload, final)
+            self._commit(index, victim)
             return
         events = []
         snap = self._snapshot(payload, (), events)
-        self._writer = threading.Thread(target=self._write, args=(snap, events, final), daemon=True)
+        self._writer = threading.Thread(target=self._write, args=(snap, events, final, index, victim),
+                                        daemon=True)
         _pending.add(self)
         self._writer.start()
 
@@ -173,7 +197,16 @@ class Saver(object):
         if curr is False:
             print('[!] No weights to be loaded')
             return False
-        st = torch.load(os.path.join(self.save_path, 'weights_' + curr), map_location='cpu')
+        path = os.path.join(self.save_path, 'weights_' + curr)
+        if not os.path.exists(path):
+            # an index written by the reference (or an older build) before its weights file was
+            # complete: fall back to the newest listed checkpoint that exists
+            for cand in reversed(self._read_index().get('latest', [])):
+                if os.path.exists(os.path.join(self.save_path, 'weights_' + cand)):
+                    print('[!] {} is missing, loading {} instead'.format(curr, cand))
+                    path = os.path.join(self.save_path, 'weights_' + cand)
+                    break
+        st = torch.load(path, map_location='cpu')
         if 'state_dict' in st:
             self.model.load_state_dict(st['state_dict'])
             if self.optimizer is not None and 'optimizer' in st:

@@ -7,6 +7,8 @@ sub-module names (``enc_blocks``, ``dec_blocks``, ``alpha_<i>``, ``skips``, ``z`
 ``forward(x, z=None, ret_hid=False)`` contract.  The forward is ONE autograd node
 (``functional.GeneratorFn``) that chains the HIP kernels.
 """
+import threading
+
 import torch
 import torch.nn as nn
 
@@ -132,6 +134,9 @@ class Generator(Model):
                 blk = GConv1DBlock(ninp, fmap, kw, stride=1, bias=bias, norm_type=norm_type)
             self.dec_blocks.append(blk)
             ninp = fmap
+        # look-ahead draw of the next step's z on a host thread (_host_z); the training loops set it
+        self.z_prefetch = False
+        self._skip_dropout = skip_dropout
         self._total_pool = 1
         for p in poolings:
             self._total_pool *= p
@@ -152,9 +157,21 @@ class Generator(Model):
             self.__dict__['_zstage'] = st
         i = st['i']
         st['i'] ^= 1
-        if st['copied'][i] is not None:
-            st['copied'][i].synchronize()          # the pinned buffer is free again (long done)
-        torch.randn(shape, out=st['pin'][i])
+        job = st.pop('job', None)
+        if job is not None:
+            # the draw for THIS call was started by the previous one (z_prefetch) into pin[i]
+            job['thread'].join()
+            if job['error'] is not None:
+                raise job['error']
+            if job['shape'] != shape or job['i'] != i:
+                # not what this call needs (a shorter last batch): put the generator back where
+                # the reference's would be and draw again
+                torch.set_rng_state(job['state'])
+                job = None
+        if job is None:
+            if st['copied'][i] is not None:
+                st['copied'][i].synchronize()      # the pinned buffer is free again (long done)
+            torch.randn(shape, out=st['pin'][i])
         main = torch.cuda.current_stream(device)
         if st['main'] is not None:
             st['stream'].wait_event(st['main'])    # readers of dev[i] (two calls ago) are done
@@ -167,9 +184,37 @@ class Generator(Model):
         me = torch.cuda.Event()
         me.record(main)
         st['main'] = me
+        if self.z_prefetch:
+            # the NEXT call's z, drawn by a host thread while this step's launches go out (randn
+            # releases the GIL): same numbers as the reference's draw as long as nothing else
+            # takes from torch's global CPU generator before the next call — the training loop
+            # switches z_prefetch off around the draws it knows of (epoch ends; see SEGAN.train)
+            j = i ^ 1
+            nxt = {'shape': shape, 'i': j, 'state': None, 'error': None}
+
+            def draw():
+                try:
+                    if st['copied'][j] is not None:
+                        st['copied'][j].synchronize()
+                    nxt['state'] = torch.get_rng_state()
+                    torch.randn(shape, out=st['pin'][j])
+                except BaseException as e:      # surfaced by the next call
+                    nxt['error'] = e
+            nxt['thread'] = threading.Thread(target=draw, daemon=True)
+            nxt['thread'].start()
+            st['job'] = nxt
         z = st['dev'][i]
         z._segan_staged = True
         return z
+
+    def cancel_z_prefetch(self):
+        """Undo a pending look-ahead draw (the generator goes back to where it was)."""
+        st = self.__dict__.get('_zstage')
+        job = st.pop('job', None) if st else None
+        if job is not None:
+            job['thread'].join()
+            if job['state'] is not None:
+                torch.set_rng_state(job['state'])
 
     def _fn_params(self):
         return [p for p in nn.Module.parameters(self)]

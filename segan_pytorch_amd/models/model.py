@@ -324,6 +324,13 @@ class SEGAN(Model):
                 if train_gen and noisy_samples is None:      # model.py:288-290
                     noisy_samples = noisy[:20, :, :].contiguous()
                     clean_samples = clean[:20, :, :].contiguous()
+                # z of the NEXT batch is drawn by a host thread while this step's kernels are
+                # launched (Generator._host_z) — within an epoch the z draws are the only takers
+                # of torch's global CPU generator, so the stream stays the reference's
+                # (generator.py:197); not across an epoch end (the samplers reseed from it), not
+                # with skip dropout (its masks come from the same generator inside the forward)
+                self.G.z_prefetch = (getattr(opts, 'prefetch_z', True) and bidx < len(dloader) and
+                                     not getattr(self.G, '_skip_dropout', 0))
                 d_real_loss, d_fake_loss, g_adv_loss, g_l1_loss = self.gan_step(
                     clean, noisy, Gopt, Dopt, criterion, l1_weight)
                 end_t = timeit.default_timer()
@@ -375,6 +382,8 @@ class SEGAN(Model):
                 # asynchronous (core.Saver): the next epoch starts while the files are written
                 self.G.save(self.save_path, iteration, saver=eoe_g_saver)
                 self.D.save(self.save_path, iteration, saver=eoe_d_saver)
+        self.G.z_prefetch = False
+        self.G.cancel_z_prefetch()
         for sv in (eoe_g_saver, eoe_d_saver):
             sv.wait()
         self.G.wait_for_checkpoints()
@@ -437,6 +446,10 @@ class WSEGAN(SEGAN):
         """A fresh iterator every step, first batch only (model.py:526-535).  The reference's
         RandomSampler reshuffles on every iter(); a DistributedSampler only does when its epoch
         changes, so it is bumped per call (otherwise every step would see the same batch)."""
+        if hasattr(dloader, 'sample'):      # PCMShardLoader: one live iterator (datasets.py)
+            uttname, clean, noisy, slice_idx = dloader.sample()
+            return (uttname, clean.unsqueeze(1).to(device), noisy.unsqueeze(1).to(device),
+                    slice_idx.to(device))
         sampler = getattr(dloader, 'sampler', None)
         if hasattr(sampler, 'set_epoch'):
             self._sample_calls = getattr(self, '_sample_calls', 0) + 1

@@ -193,15 +193,34 @@ def last_wgrad_launch():
                     list(arr)))
 
 
+_call_scratch = {}
+
+
+def _stream_scratch(nbytes, device):
+    """A per-call scratch buffer of at least `nbytes` on this device + stream: ONE grow-only
+    buffer per (device, stream), re-used by every call — the calls of a stream execute in order
+    and none keeps its scratch past its last kernel (round-3 advice: a fresh torch.empty of
+    134+ MB per bf16 contraction call went through the caching allocator thousands of times per
+    step)."""
+    st = torch.cuda.current_stream(device)
+    key = (st.device.index, st.cuda_stream)
+    buf = _call_scratch.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = None
+        _call_scratch.pop(key, None)          # release before growing
+        buf = torch.empty(int(nbytes), device=st.device, dtype=torch.uint8)
+        _call_scratch[key] = buf
+    return buf
+
+
 def _bf_scratch(op, B, N, M, L, K, S, pad, device):
-    """(pointer, bytes) of the packed-activation scratch of a bf16 / bf16x3 contraction call
-    (segan_bf16_scratch_bytes); the buffer must stay alive until the call is enqueued — the
-    caching allocator keeps it stream-ordered after that."""
+    """(buffer, pointer, bytes) of the packed-activation scratch of a bf16 / bf16x3 contraction
+    call (segan_bf16_scratch_bytes), from the stream's call scratch."""
     planes = 3 if _precision == PREC_BF16X3 else 1
     nbytes = _lib.load().segan_bf16_scratch_bytes(op, B, N, M, L, K, S, pad, planes)
     if nbytes == 0:
         return None, None, 0
-    buf = torch.empty(nbytes, device=device, dtype=torch.uint8)
+    buf = _stream_scratch(nbytes, device)
     return buf, ctypes.c_void_p(buf.data_ptr()), nbytes
 
 
@@ -422,7 +441,7 @@ def wgrad(lo, hi, dw, K, S, padL, pad_mode, roll=0):
     lib = _lib.load()
     if _precision != PREC_FP32:
         nbytes = lib.segan_wgrad_scratch_bytes(lo.B, M, N, lo.L, S, _precision, 0)
-        scratch = torch.empty(nbytes, device=dw.device, dtype=torch.uint8)
+        scratch = _stream_scratch(nbytes, dw.device)
         rc = lib.segan_wgrad(ctypes.byref(cl), ctypes.byref(ch), _ptr(dw), lo.B, M, N, lo.L, K, S,
                              padL, pad_mode, roll, _precision, 0,
                              ctypes.c_void_p(scratch.data_ptr()) if scratch is not None else None,
@@ -435,7 +454,7 @@ def wgrad(lo, hi, dw, K, S, padL, pad_mode, roll=0):
     scratch, nbytes = None, 0
     if flags or not lo_plain:
         nbytes = lib.segan_wgrad_scratch_bytes(lo.B, M, N, lo.L, S, PREC_FP32, flags)
-        scratch = torch.empty(nbytes, device=dw.device, dtype=torch.uint8)
+        scratch = _stream_scratch(nbytes, dw.device)
     check(lib.segan_wgrad(ctypes.byref(cl), ctypes.byref(ch), _ptr(dw), lo.B, M, N, lo.L, K, S, padL,
                           pad_mode, roll, PREC_FP32, flags,
                           ctypes.c_void_p(scratch.data_ptr()) if scratch is not None else None, nbytes,

@@ -223,7 +223,41 @@ def test_async_checkpoint_snapshot_is_taken_at_save_time(tmp_path):
     sync.save('Generator', 8)
     ck2 = torch.load(os.path.join(str(tmp_path), 'weights_S-Generator-8.ckpt'), weights_only=False)
     assert list(ck2['state_dict'].keys()) == list(ck['state_dict'].keys())
+    # nn.Module.state_dict()'s per-module version record survives the snapshot (round-3 advice)
+    assert ck2['state_dict']._metadata and ck['state_dict']._metadata == ck2['state_dict']._metadata
     assert not [f for f in os.listdir(str(tmp_path)) if f.endswith('.tmp')]
+
+
+def test_checkpoint_index_follows_the_weights_file(tmp_path, monkeypatch):
+    """The index names a checkpoint only once its weights file is complete, and the rotated-out
+    file goes after that: a write that dies leaves the previous index and every listed file
+    (round-3 advice); load_weights falls back to the newest listed file that exists."""
+    import torch
+    from segan_pytorch_amd.models.core import Saver
+    net = torch.nn.Linear(3, 2)
+    sv = Saver(net, str(tmp_path), max_ckpts=1, prefix='X-')
+    for step in range(3):
+        sv.save('Net', step)
+    sv.wait()
+    idx0 = json.load(open(str(tmp_path / 'X-checkpoints')))
+    files0 = sorted(os.listdir(str(tmp_path)))
+    real_save = torch.save
+
+    def dying_save(obj, path, *a, **k):
+        raise OSError('disk full')
+    monkeypatch.setattr(torch, 'save', dying_save)
+    sv.save('Net', 3)
+    with pytest.raises(OSError):
+        sv.wait()
+    monkeypatch.setattr(torch, 'save', real_save)
+    assert json.load(open(str(tmp_path / 'X-checkpoints'))) == idx0
+    assert sorted(os.listdir(str(tmp_path))) == files0          # nothing deleted, nothing half-written
+    assert Saver(torch.nn.Linear(3, 2), str(tmp_path), prefix='X-').load_weights()
+    # an index whose `current` is missing (written by the reference's order of operations)
+    idx = dict(idx0, current='X-Net-99.ckpt', latest=idx0['latest'] + ['X-Net-99.ckpt'])
+    with open(str(tmp_path / 'X-checkpoints'), 'w') as f:
+        json.dump(idx, f)
+    assert Saver(torch.nn.Linear(3, 2), str(tmp_path), prefix='X-').load_weights()
 
 
 def test_accumulation_mode_switch():

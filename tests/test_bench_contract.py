@@ -83,7 +83,7 @@ def test_bench_line_assembly_runs_without_a_gpu(prec, wsegan, shape):
                     'wgrad': dict(tflops=90.0, avg_us=100.0, launches=5, total_ms=5.0)}
 
     ns = dict(vars(bench))
-    ns.update(B=300, world=1, dt=0.9, ranks_seen=[0], devices_seen=[0], backend=None, finite=True,
+    ns.update(B=300, world=1, dt=0.9, ranks_seen=[0], devices_seen=[0], backend=None, finite=True, comm=None,
               timed_det=False, ms_other=90.0, ms_blocked=91.0, gflop=37.96, gflop_exec=35.84, timer=Timer(),
               _ops=types.SimpleNamespace(get_accumulation=lambda: 'plain'),
               args=types.SimpleNamespace(steps=10, warmup=3, precision=prec, wsegan=wsegan, shape=shape,

@@ -123,9 +123,19 @@ def _dp_worker(rank, world, port, q):
     noisy = (clean + 0.1 * torch.randn(4, 1, 1024, generator=g)).clamp(-1, 1)
     z = torch.randn(4, 32, 16, generator=g)
     sl = slice(2 * rank, 2 * rank + 2)
+    sdist.set_profile(True)
     out = _dp_step(o, fx, clean[sl].contiguous(), noisy[sl].contiguous(), z[sl].contiguous(), 11)
     nb = [len(r.buckets) for r in sdist._reducers.values()]
     assert len(nb) == 2 and min(nb) >= 3, nb
+    # the self-diagnosis block bench.py prints for world > 1 (distributed.comm_stats)
+    st = sdist.comm_stats()
+    assert st['backend'] == 'torch.distributed (gloo)' and st['sync_bn'] is False
+    assert [a['buckets'] for a in st['arenas']] == nb
+    for a in st['arenas']:
+        assert a['finishes'] == 1 and a['wait_host_ms'] > 0.0
+        # overlapped: most buckets left from inside the backward pass, not at the optimizer step
+        assert a['late_buckets'] < a['buckets']
+    sdist.set_profile(False)
     q.put((rank, {k: v.numpy() for k, v in out.items()}))
     dist.destroy_process_group()
 

@@ -114,3 +114,16 @@ def test_bench_launches_its_own_ranks():
     assert d['losses_finite'] is True and d['scaling'] == 'weak'
     assert d['config']['global_batch'] == 24 and d['config']['parallelism'] == 'dp2'
     assert abs(d['value'] - 24 * 1e3 / d['ms_per_step']) < 1e-6 * d['value']
+    # the multi-GPU line diagnoses itself: transport, SyncBN switch, bucket layout of the two
+    # gradient arenas (G 64.8 M floats, D 25.8 M), how long the compute stream waited for the
+    # collectives per step and how many buckets only left at the optimizer step
+    c = d['comm']
+    assert c['backend'].startswith('torch.distributed (gloo') and c['sync_bn'] is False
+    assert sorted(a['arena_floats'] // 1000000 for a in c['arenas']) == [25, 64]
+    for a in c['arenas']:
+        assert a['buckets'] == len(a['bucket_mb']) >= 2 and a['finishes'] == 2
+        assert abs(sum(a['bucket_mb']) - a['arena_floats'] * 4 / 2 ** 20) < 0.01
+        assert a['late_buckets'] <= a['buckets'] * a['finishes']
+        assert a['wait_device_ms_per_step'] >= 0.0 and a['wait_host_ms_per_step'] > 0.0
+    assert d['comm_wait_ms_per_step'] == c['comm_wait_ms_per_step'] >= 0.0
+    assert list(c['ms_per_step']) == ['torch.distributed']

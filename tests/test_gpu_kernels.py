@@ -500,8 +500,11 @@ def test_conv_bf16_modes(prec, B, N, M, L, S, roll):
         dx = ops.conv1d_dgrad(da.to(DEV), w.to(DEV), L, S, roll=roll)
         ops.wgrad(ops.Src(da.to(DEV)), ops.Src(x.to(DEV), slope=sl.to(DEV)), dw, K, S,
                   ops.conv_pad(K, S)[0], ops.PAD_REFLECT, roll=roll)
+        kw = ops.last_wgrad_launch()['kernel']
     finally:
         ops.set_precision('fp32')
+    if B == 300:        # a SEGAN+ layer geometry: the bf16 weight-gradient kernel took it
+        assert kw == 3, kw
     assert max_rel(out, ref) < tol
     assert max_rel(dw, wd.grad) < tol
     # data gradient w.r.t. the transformed input (dgrad does not apply the transform)
@@ -861,11 +864,16 @@ def test_conv_layers_at_batch_scale_bf16(prec, name, N, M, L, roll, B):
     ops.set_precision(prec)
     try:
         out = ops.conv1d_fwd(src, wg, bg, S, roll=roll)
+        kf = ops.last_corr_launch()['kernel']
         out2 = ops.conv1d_fwd(src, wg, bg, S, roll=roll)
         dx = ops.conv1d_dgrad(dag, wg, L, S, roll=roll)
+        kd = ops.last_corr_launch()['kernel']
         dx2 = ops.conv1d_dgrad(dag, wg, L, S, roll=roll)
     finally:
         ops.set_precision('fp32')
+    # the bf16 matrix-core kernel (3 = corr_bf2_kernel) took every SEGAN+ layer geometry: an
+    # entry point that declines (SEGAN_EUNSUPPORTED) silently runs the fp32 form instead
+    assert kf == 3 and kd == 3, (kf, kd)
     tol = PREC_TOL[prec]
     assert max_rel(out, ref) < tol and max_rel(dx, hd.grad) < tol
     assert torch.equal(out, out2) and torch.equal(dx, dx2)
@@ -897,11 +905,14 @@ def test_deconv_layers_at_batch_scale_bf16(prec, name, M0, M1, N, Ls, B):
     ops.set_precision(prec)
     try:
         y = ops.deconv1d_fwd(src, wg, bg, S)
+        kf = ops.last_corr_launch()['kernel']
         y2 = ops.deconv1d_fwd(src, wg, bg, S)
         dx0, dx1 = ops.deconv1d_dgrad(dyg, wg, S, M0, need0=need0)
+        kd = ops.last_corr_launch()['kernel']
         dx0b, dx1b = ops.deconv1d_dgrad(dyg, wg, S, M0, need0=need0)
     finally:
         ops.set_precision('fp32')
+    assert kf == 3 and kd == 3, (kf, kd)         # corr_bf2_kernel, not the fp32 fall-back
     tol = PREC_TOL[prec]
     assert max_rel(y, ref) < tol and torch.equal(y, y2)
     assert max_rel(dx1, xin.grad[:, M0:]) < tol and torch.equal(dx1, dx1b)

@@ -432,12 +432,6 @@ def test_vanilla11_step_matches_reference(vanilla11_b8, deterministic):
     ref = O.gan_step(g0, d0, clean, noisy, z, fx['rolls'], st, 100.0, 5e-5)
     m.D.load_state_dict({k: ref['D'][k] if k in ref['D'] else v for k, v in d0.items()})
     ops.bump_weights_epoch()
-    if aligned:     # G's PReLU sides, before g_phase steps G (same bits as the step's forward)
-        with torch.no_grad():
-            _, hall = m.G(ng, z=zg, ret_hid=True)
-        n_dec = len(m.G.dec_blocks)
-        gg = {k: (v > 0).cpu() for k, v in hall.items()
-              if k != 'enc_zc' and k != 'dec_{}'.format(n_dec - 1)}
     g_adv, g_l1 = m.g_phase(Genh, cg, ng, Gopt, crit, 100.0)
     torch.cuda.synchronize()
     assert max_rel(g_adv, ref['g_adv_loss']) < 1e-4
@@ -748,3 +742,44 @@ def test_async_checkpoint_overlaps_training(tiny_step, tmp_path):
     assert moved                                          # the live weights did change meanwhile
     for got, w in zip(ck['optimizer']['state'].values(), want_opt):
         assert torch.equal(got['square_avg'], w)
+
+
+def test_z_prefetch_keeps_the_reference_rng_stream(tiny_step):
+    """Generator.z_prefetch (SEGAN.train's default): z of call n+1 is drawn by a host thread during
+    call n.  The outputs of a run of forwards with z=None — including a shorter last batch, which
+    the look-ahead draw cannot have anticipated — equal the plain run's bit for bit, and after
+    cancel_z_prefetch torch's global CPU generator stands where the reference's would
+    (generator.py:197: one randn per forward)."""
+    fx = tiny_step
+    m = build(fx)
+    m.G.train()
+    x = fx['noisy'].to(DEV)
+    xs = [x, x, x[:2].contiguous(), x, x[:1].contiguous()]
+
+    def run(prefetch):
+        torch.manual_seed(77)
+        outs = []
+        with torch.no_grad():
+            for k, xi in enumerate(xs):
+                m.G.z_prefetch = prefetch and k < len(xs) - 1
+                outs.append(m.G(xi).cpu())
+        m.G.z_prefetch = False
+        m.G.cancel_z_prefetch()
+        return outs, torch.get_rng_state()
+
+    plain, st0 = run(False)
+    ahead, st1 = run(True)
+    for a, b in zip(plain, ahead):
+        assert torch.equal(a, b)
+    assert torch.equal(st0, st1)
+    # a pending draw that is never used is undone: the generator stands after ONE draw
+    torch.manual_seed(5)
+    with torch.no_grad():
+        m.G.z_prefetch = True
+        m.G(x)
+        m.G.z_prefetch = False
+    m.G.cancel_z_prefetch()
+    got = torch.get_rng_state()
+    torch.manual_seed(5)
+    torch.randn(tuple(m.G.z.shape))
+    assert torch.equal(got, torch.get_rng_state())

@@ -308,6 +308,34 @@ def test_legacy_generator_checkpoint_loads(tiny_step, tmp_path):
         assert torch.equal(v.cpu(), fx['G0'][k] + 0.5), k
 
 
+def test_weightG_fmt_converter_cli(tiny_step, tmp_path):
+    """weightG_fmt_converter.py <file> writes <file>.v2 with today's key names and every other
+    top-level entry carried over (weightG_fmt_converter.py:18-44 of the reference); the result
+    loads as a pretrained generator."""
+    import os, subprocess, sys
+    fx = tiny_step
+    legacy = {}
+    for k, v in fx['G0'].items():
+        if k.startswith('enc_blocks'):
+            k = k.replace('enc_blocks', 'gen_enc')
+        elif k.startswith('dec_blocks'):
+            k = k.replace('dec_blocks', 'gen_dec').replace('deconv', 'conv')
+        legacy[k] = v + 0.25
+    path = str(tmp_path / 'old_G.ckpt')
+    torch.save({'state_dict': legacy, 'step': 17}, path)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, 'weightG_fmt_converter.py'), path],
+                         capture_output=True, text=True, cwd=root)
+    assert out.returncode == 0, out.stderr
+    assert 'gen_dec.0.conv.weight -> dec_blocks.0.deconv.weight' in out.stdout
+    ck = torch.load(path + '.v2', weights_only=False)
+    assert ck['step'] == 17 and list(ck['state_dict'].keys()) == list(fx['G0'].keys())
+    m = build(fx)
+    m.G.load_pretrained(path + '.v2', load_last=True)
+    for k, v in m.G.state_dict().items():
+        assert torch.equal(v.cpu(), fx['G0'][k] + 0.25), k
+
+
 def test_gan_step_with_spectral_norm(tiny_snorm):
     """--dnorm_type snorm through the host logic (weights from ops.snorm_fwd per forward call,
     gradients folded back into weight_orig by ops.snorm_bwd), against the reference."""

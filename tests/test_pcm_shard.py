@@ -108,3 +108,35 @@ def test_full_rate_loader_matches_the_reference_pipeline(tmp_path):
                 n += 1
         assert n == len(ds)
     assert seen == set(want)
+
+
+@pytest.mark.gpu
+def test_loader_sample_keeps_one_live_iterator(tmp_path):
+    """PCMShardLoader.sample() (WSEGAN's per-step sample_dloader): 2.5 epochs of calls draw from
+    ONE iterator per epoch — iter() of the underlying DataLoader is entered three times, not once
+    per call — and every epoch yields every item once, bit for bit."""
+    from segan_pytorch_amd.datasets import PCMShardLoader
+    cd, nd = _write_wavs(tmp_path)
+    build_pcm_shard(cd, nd, str(tmp_path / 'sh'), slice_size=16384, stride=0.5)
+    ref = SEDataset(cd, nd, preemph=0.95, slice_size=16384, stride=0.5)
+    want = {(ref[i][0], ref[i][3]): (ref[i][1], ref[i][2]) for i in range(len(ref))}
+    ds = PCMShardDataset(str(tmp_path / 'sh'))
+    loader = PCMShardLoader(ds, 4, 0.95, 'cuda', num_workers=1)
+    entered = []
+    real_iter = type(loader.loader).__iter__
+
+    class Counting(type(loader.loader)):
+        def __iter__(self):
+            entered.append(1)
+            return real_iter(self)
+    loader.loader.__class__ = Counting
+    per_epoch = len(loader)
+    seen = []
+    for _ in range(2 * per_epoch + per_epoch // 2 + 1):
+        names, clean, noisy, idx = loader.sample()
+        for k, name in enumerate(names):
+            rc, rn = want[(name, int(idx[k]))]
+            assert torch.equal(clean[k].cpu(), rc) and torch.equal(noisy[k].cpu(), rn)
+            seen.append((name, int(idx[k])))
+    assert len(entered) == 3, len(entered)
+    assert sorted(seen[:len(ds)]) == sorted(want) and sorted(seen[len(ds):2 * len(ds)]) == sorted(want)

@@ -104,6 +104,9 @@ FLAGS = [
                         help='draw the generator\'s z on the GPU (per-rank generator) instead of on the '
                              'host like the reference (generator.py:197): no host randn + copy per step, '
                              'but not the reference\'s RNG stream')),
+    ('--no_prefetch_z', dict(action='store_true', default=False,
+                             help='draw every z inside its own step instead of one step ahead on a host '
+                                  'thread (same numbers either way: Generator._host_z)')),
     ('--deterministic', dict(action='store_true', default=False,
                              help='bit-reproducible kernels: the weight-gradient and dense-head contraction '
                                   'splits are added in a fixed order instead of with fp32 atomics '
@@ -143,6 +146,7 @@ def main(opts):
     segan = (WSEGAN if opts.wsegan else SEGAN)(opts)
     if getattr(opts, 'device_z', False):
         segan.G.z_generator = torch.Generator(device=device).manual_seed(opts.seed + rank)
+    opts.prefetch_z = not getattr(opts, 'no_prefetch_z', False)
     if getattr(opts, 'deterministic', False):
         from segan_pytorch_amd import ops as _ops
         _ops.set_deterministic(True)
@@ -198,8 +202,11 @@ def main(opts):
     # per-rank host RNG streams for z and the phase shifts
     random.seed(opts.seed + rank)
     torch.manual_seed(opts.seed + rank)
-    segan.train(opts, dloader, losses.MSELoss(), opts.l1_weight, opts.l1_dec_step,
-                opts.l1_dec_epoch, opts.save_freq, va_dloader=va_dloader, device=device)
+    try:
+        segan.train(opts, dloader, losses.MSELoss(), opts.l1_weight, opts.l1_dec_step,
+                    opts.l1_dec_epoch, opts.save_freq, va_dloader=va_dloader, device=device)
+    finally:
+        sdist.destroy_native()      # the library-owned RCCL communicators (SEGAN_COMM=native)
 
 
 if __name__ == '__main__':
