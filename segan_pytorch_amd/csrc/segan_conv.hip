@@ -241,16 +241,62 @@ __device__ __forceinline__ void corr_store_tile(
                             __builtin_bit_cast(unsigned, acc[1 % NI][j][e] + bs),
                             __builtin_bit_cast(unsigned, acc[2 % NI][j][e] + bs),
                             __builtin_bit_cast(unsigned, acc[3 % NI][j][e] + bs)};
-          __builtin_amdgcn_raw_buffer_store_b128(o, qrs, ovo[j], nl * rowstep, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(o, qrs, ovo[j] + nl * rowstep, 0, 0);   // (*)
         }
       }
       return;
+    }
+    int cb[NJ];          // columns still to be stored by the generic form below (-1: done / masked)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) cb[j] = col_b[j];
+    if (QUAD && qfast && a.act == SEGAN_ACT_NONE && n0 + NPT <= a.Nout) {
+      // conv data gradient (HI store with a left pad, a halo and possibly a roll): everything that
+      // depends on the COLUMN only — sample, the first of the lane's four output positions, the
+      // roll's wrap — is worked out once per column instead of once per stored vector; interior
+      // columns (all but the ~8 at a row's ends and the one on the wrap point) then store one
+      // 16-byte vector per channel row (the row offset added to the vector offset: (*) in segan_conv_shared.h).  The generic form below
+      // (~30 VALU per stored vector) costs a bf16 tile 40 % of its time and an fp32 tile 5-10 %.
+      int ovo[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        ovo[j] = (int)0x80000000u;
+        if (col_b[j] >= 0) {
+          const int i0 = 4 * col_t[j] - a.o_padL;
+          int ib = i0 - a.o_roll;
+          if (ib < 0) ib += a.Lout;
+          if (ib >= a.Lout) ib -= a.Lout;
+          if (i0 >= 0 && i0 + 3 < a.Lout && ib + 3 < a.Lout) {
+            ovo[j] = ((col_b[j] * a.Nout + n0 + 4 * h) * a.Lout + ib) * 4;
+            cb[j] = -1;
+          }
+        }
+      }
+      const int rowstep = a.Lout * 4;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int nl = (e & 3) + 8 * (e >> 2);
+        float bs = 0.0f;
+        if (a.bias) bs = a.bias[n0 + 4 * h + nl];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+          const u32x4s o = {__builtin_bit_cast(unsigned, acc[0 % NI][j][e] + bs),
+                            __builtin_bit_cast(unsigned, acc[1 % NI][j][e] + bs),
+                            __builtin_bit_cast(unsigned, acc[2 % NI][j][e] + bs),
+                            __builtin_bit_cast(unsigned, acc[3 % NI][j][e] + bs)};
+          __builtin_amdgcn_raw_buffer_store_b128(o, qrs, ovo[j] + nl * rowstep, 0, 0);   // (*)
+        }
+      }
+      bool left = false;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) left = left || cb[j] >= 0;
+      if (!left) return;
     }
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
-        if (col_b[j] < 0) continue;
+        if (cb[j] < 0) continue;
         const int q = col_t[j];
         if (QUAD) {
           const int n = n0 + (e & 3) + 8 * (e >> 2) + 4 * h;

@@ -223,7 +223,7 @@ __device__ __forceinline__ void bf2_store_tile(const CorrArgs& a,
                            __builtin_bit_cast(unsigned, acc[1][j][e] + bs),
                            __builtin_bit_cast(unsigned, acc[2][j][e] + bs),
                            __builtin_bit_cast(unsigned, acc[3][j][e] + bs)};
-          __builtin_amdgcn_raw_buffer_store_b128(o, ors, ovo[j], nl * rowstep, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(o, ors, ovo[j] + nl * rowstep, 0, 0);   // (*)
         }
       }
       return;
@@ -231,11 +231,56 @@ __device__ __forceinline__ void bf2_store_tile(const CorrArgs& a,
     const bool qfast = obytes < 0x7fffffffL;     // 32-bit byte offsets reach every output element
     const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(
         a.out0, 0, (int)(qfast ? obytes : 0), 0x00020000);
+    int cb[NJ];          // columns still to be stored by the generic form below (-1: done / masked)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) cb[j] = col_b[j];
+    if (QUAD && qfast && a.act == SEGAN_ACT_NONE && n0 + NPT <= a.Nout) {
+      // conv data gradient (HI store with a left pad, a halo and possibly a roll): what depends on
+      // the COLUMN only — sample, first of the lane's four output positions, the roll's wrap — is
+      // worked out once per column; interior columns store one 16-byte vector per channel row (row
+      // offset in the vector offset: (*) in segan_conv_shared.h), the few columns at a row's ends and on the wrap point go
+      // through the generic form below.  Measured with the stores compiled out (round 4): the
+      // generic form alone was 40 % of this kernel's time on enc1 / enc2's data gradients.
+      int ovo[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        ovo[j] = (int)0x80000000u;
+        if (col_b[j] >= 0) {
+          const int i0 = 4 * col_t[j] - a.o_padL;
+          int ib = i0 - a.o_roll;
+          if (ib < 0) ib += a.Lout;
+          if (ib >= a.Lout) ib -= a.Lout;
+          if (i0 >= 0 && i0 + 3 < a.Lout && ib + 3 < a.Lout) {
+            ovo[j] = ((col_b[j] * a.Nout + n0 + 4 * h) * a.Lout + ib) * 4;
+            cb[j] = -1;
+          }
+        }
+      }
+      const int rowstep = a.Lout * 4;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int nl = (e & 3) + 8 * (e >> 2);
+        float bs = 0.0f;
+        if (a.bias && add_bias) bs = a.bias[n0 + 4 * h + nl];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const u32x4 o = {__builtin_bit_cast(unsigned, acc[0 % NI][j][e] + bs),
+                           __builtin_bit_cast(unsigned, acc[1 % NI][j][e] + bs),
+                           __builtin_bit_cast(unsigned, acc[2 % NI][j][e] + bs),
+                           __builtin_bit_cast(unsigned, acc[3 % NI][j][e] + bs)};
+          __builtin_amdgcn_raw_buffer_store_b128(o, qrs, ovo[j] + nl * rowstep, 0, 0);   // (*)
+        }
+      }
+      bool left = false;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) left = left || cb[j] >= 0;
+      if (!left) return;
+    }
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
-        if (col_b[j] < 0) continue;
+        if (cb[j] < 0) continue;
         const int q = col_t[j];
         if (QUAD) {
           const int n = n0 + (e & 3) + 8 * (e >> 2) + 4 * h;
@@ -352,12 +397,6 @@ struct Bf2Extra {
 // with three weight buffers (two workgroups per CU) or with half-size stages (four per CU) give the
 // same total as 1 stage ahead at three per CU — the loop is not latency-bound — so the shallow form stays
 #define BF2_LOOK(NPL) 1
-#ifndef BF2_LDR_EU
-#define BF2_LDR_EU 4      // waves per SIMD the loader variant is compiled for (experiment switch)
-#endif
-#ifndef BF2_NLW
-#define BF2_NLW 1         // loader waves per workgroup (experiment switch)
-#endif
 
 // s_waitcnt vmcnt(n) for a run-time n (the instruction takes an immediate): loads — LDS-DMA
 // included — return in order, so "at most n outstanding" = all but the newest n have landed
@@ -378,14 +417,8 @@ __device__ __forceinline__ void bf2_wait_vm(int n) {
   }
 }
 
-// LDR: a FIFTH wave per workgroup issues every LDS-DMA instruction of the tile and is the only
-// one that waits on vmcnt; the four contraction waves issue nothing but ds_read_b128 and MFMAs.
-// Why: an LDS-DMA instruction holds its wave's issue port for 60-185 cycles (MI355X_MICROARCH.md,
-// "LDS-DMA piece issue cost"), ~5 of them per stage and wave were ~400 cycles beside 16 MFMAs of
-// 32; moved to a wave of their own they overlap with the other waves' MFMAs, and the next tile's
-// first stage is already in flight while the contraction waves store the previous tile.
-template <int MB, int NB, int WM, int U, bool OUT_HI, int SHIFTMASK, int NPL, int TU, bool LDR>
-__global__ __launch_bounds__(LDR ? 256 + 64 * BF2_NLW : 256, (NPL == 1 && NB == 128) ? (LDR ? BF2_LDR_EU : 3) : 2) void corr_bf2_kernel(const CorrArgs a, const Bf2Extra x) {
+template <int MB, int NB, int WM, int U, bool OUT_HI, int SHIFTMASK, int NPL, int TU>
+__global__ __launch_bounds__(256, (NPL == 1 && NB == 128) ? 3 : 2) void corr_bf2_kernel(const CorrArgs a, const Bf2Extra x) {
   constexpr int S = 32 / U;
   constexpr int WN = 4 / WM;
   constexpr int NI = MB / (32 * WM);
@@ -455,63 +488,6 @@ __global__ __launch_bounds__(LDR ? 256 + 64 * BF2_NLW : 256, (NPL == 1 && NB == 
   const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<char*>(reinterpret_cast<const char*>(x.act)) + (size_t)ct.b0 * sample_bytes, 0,
       (int)(left + 2 * x.a_plane_bytes < 0x7fffffffL ? left + 2 * x.a_plane_bytes : 0x7fffffffL), 0x00020000);
-  if (LDR && wave >= 4) {
-    const int lw = wave - 4;
-    // ---- the loader wave: all DMA of the tile, one stage ahead of the contraction waves ----
-    int avo6[2 * KI];
-#pragma unroll
-    for (int pb = 0; pb < 2 * KI; ++pb) {
-      const int j = lane + 64 * pb;
-      avo6[pb] = (int)0x80000000u;
-      if (pb < x.nld && j < a.RLv) {
-        int s, tau;
-        lds_pos_decode(ct, j, a.Tcols, a.H, s, tau);
-        if (ct.b0 + s < a.B) avo6[pb] = (int)(((long)s * x.G * x.Qp + tau) * 16);
-      }
-    }
-    int lwvo[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int wr = 64 * i + lane;
-      const int wgrow = OUT_HI ? (wr / NPT) * a.NP + n0 + wr % NPT : m0 + wr;
-      lwvo[i] = wgrow * 16;
-    }
-    auto lissue = [&](int st) __attribute__((always_inline)) {
-      if (st % TCH == 0 || st == c0) {
-        const int cg = st / TCH;
-        u32x4* Il = Il0 + (cg & 1) * IPIECES;
-#pragma unroll
-        for (int p = 0; p < NPL; ++p)
-#pragma unroll
-          for (int g2 = 0; g2 < 2; ++g2) {
-            const long soff = (long)p * x.a_plane_bytes + ((long)(2 * cg + g2) * x.Qp) * 16;
-#pragma unroll
-            for (int pb = 0; pb < 2 * KI; ++pb)
-              if (pb < x.nld && (pb % BF2_NLW) == lw)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                    ars, (__attribute__((address_space(3))) void*)(Il + (p * 2 + g2) * RLs + 64 * pb), 16,
-                    avo6[pb], (int)soff, 0, 0);
-          }
-      }
-      u32x4* Wl = Wl0 + ((st - c0) % NBUF) * WPIECES;
-#pragma unroll
-      for (int q = 0; q < WINS; ++q) {
-        if ((q % BF2_NLW) != lw) continue;
-        const int i = q & 1, g = (q >> 1) & 1, tu = (q >> 2) % TU, p = q / (4 * TU);
-        const long soff = (long)p * x.w_plane * 2 + ((long)((st * TU + tu) * 2 + g) * a.RP) * 16;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(
-            wrs, (__attribute__((address_space(3))) void*)(Wl + ((p * TU + tu) * 2 + g) * MB + 64 * i), 16,
-            lwvo[i], (int)soff, 0, 0);
-      }
-    };
-    lissue(c0);
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    for (int st = c0; st < c1; ++st) {
-      if (st + 1 < c1) lissue(st + 1);
-      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    }
-    continue;
-  }
   // this wave stages half g = wave & 1, position blocks (wave >> 1) + 2k (static register indices)
   const int ig = wave & 1, ib = wave >> 1;
   int avo[KI];
@@ -602,24 +578,17 @@ __global__ __launch_bounds__(LDR ? 256 + 64 * BF2_NLW : 256, (NPL == 1 && NB == 
     dma_w(st, (st - c0) % NBUF);
   };
   auto group = [&](int st) { return WINS / 4 + ((st % TCH == 0) ? cnt_i : 0); };
-  if (LDR) {
-    // the loader's first stage has landed; this wave's own epilogue stores of the previous tile may
-    // stay in flight (a bare barrier: the contraction waves never wait on vmcnt)
-    // (asm with a memory clobber: the compiler must not move LDS reads across it either)
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  } else {
-    issue(c0);
-    if (LOOK > 1 && c0 + 1 < c1) issue(c0 + 1);
-    // (the epilogue stores of the previous tile may still be in flight and complete out of order
-    // with loads: a full drain here, partial waits only inside the loop)
-    __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0)
-    __syncthreads();
-  }
+  issue(c0);
+  if (LOOK > 1 && c0 + 1 < c1) issue(c0 + 1);
+  // (the epilogue stores of the previous tile may still be in flight and complete out of order
+  // with loads: a full drain here, partial waits only inside the loop)
+  __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0)
+  __syncthreads();
   for (int st = c0; st < c1; ++st) {
     const int buf = (st - c0) % NBUF;
     const int cg = st / TCH, tc = st - cg * TCH;
     const bool ahead = st + LOOK < c1;
-    if (!LDR && ahead) issue(st + LOOK);
+    if (ahead) issue(st + LOOK);
     const u32x4* Wl = Wl0 + buf * WPIECES;
     const u32x4* Il = Il0 + (cg & 1) * IPIECES;
 #pragma unroll
@@ -657,13 +626,9 @@ __global__ __launch_bounds__(LDR ? 256 + 64 * BF2_NLW : 256, (NPL == 1 && NB == 
         }
       }
     }
-    if (LDR) {
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // this stage's LDS reads have returned
-    } else {
-      // the NEXT stage's DMA has landed: only the group issued above may still be outstanding
-      bf2_wait_vm((LOOK > 1 && ahead) ? group(st + LOOK) : 0);
-      __syncthreads();
-    }
+    // the NEXT stage's DMA has landed: only the group issued above may still be outstanding
+    bf2_wait_vm((LOOK > 1 && ahead) ? group(st + LOOK) : 0);
+    __syncthreads();
   }
 
   if (partial)
@@ -878,27 +843,8 @@ static int launch_pack(const PackArgs& pa, int planes, hipStream_t st) {
   return segan_check_launch("act_pack_kernel");
 }
 
-// SEGAN_BF2_LDR=0 keeps the DMA on the four contraction waves (round 3's form; A/B switch)
-static bool bf2_loader_on() {
-  static int on = -1;
-  if (on < 0) {
-    const char* e = getenv("SEGAN_BF2_LDR");
-    on = e ? atoi(e) : 1;
-  }
-  return on != 0;
-}
-
-template <int NB, int WM, int U, bool IN_HI, bool OUT_HI, int SHIFTMASK, int NPL, bool LDR>
-static int launch_bf2_v(CorrArgs a, Bf2Extra x, hipStream_t st);
-
 template <int NB, int WM, int U, bool IN_HI, bool OUT_HI, int SHIFTMASK, int NPL>
 static int launch_bf2(CorrArgs a, Bf2Extra x, hipStream_t st) {
-  return bf2_loader_on() ? launch_bf2_v<NB, WM, U, IN_HI, OUT_HI, SHIFTMASK, NPL, true>(a, x, st)
-                         : launch_bf2_v<NB, WM, U, IN_HI, OUT_HI, SHIFTMASK, NPL, false>(a, x, st);
-}
-
-template <int NB, int WM, int U, bool IN_HI, bool OUT_HI, int SHIFTMASK, int NPL, bool LDR>
-static int launch_bf2_v(CorrArgs a, Bf2Extra x, hipStream_t st) {
   constexpr int MB = 128;
   constexpr int S = 32 / U;
   constexpr int TU = (NPL == 3) ? 1 : (U >= 8 ? 4 : U);   // bf16x3: 3 planes per tap fill the LDS
@@ -911,8 +857,7 @@ static int launch_bf2_v(CorrArgs a, Bf2Extra x, hipStream_t st) {
     return SEGAN_EUNSUPPORTED;
   }
   const size_t lds = (size_t)((BF2_LOOK(NPL) + 1) * NPL * TU * 2 * MB + 2 * NPL * 2 * a.RLs) * 16;
-  auto kern = corr_bf2_kernel<MB, NB, WM, U, OUT_HI, SHIFTMASK, NPL, TU, LDR>;
-  constexpr int NTHR = LDR ? 256 + 64 * BF2_NLW : 256;
+  auto kern = corr_bf2_kernel<MB, NB, WM, U, OUT_HI, SHIFTMASK, NPL, TU>;
   static bool attr_done[16];
   static int occ[16];
   static size_t occ_lds[16];
@@ -941,7 +886,7 @@ static int launch_bf2_v(CorrArgs a, Bf2Extra x, hipStream_t st) {
   if (sk_on && a.act == SEGAN_ACT_NONE && ntiles >= 64 && nst >= 8 && classic_eff < 0.97) {
     if (occ[dev] == 0 || occ_lds[dev] != lds) {
       int nb = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), NTHR,
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), 256,
                                                        lds) != hipSuccess || nb < 1)
         nb = 1;
       occ[dev] = nb > 4 ? 4 : nb;
@@ -956,7 +901,7 @@ static int launch_bf2_v(CorrArgs a, Bf2Extra x, hipStream_t st) {
       grid = (unsigned)G;
     }
   }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), lds, st, a, x);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a, x);
   segan_note_corr_launch(3, grid, a, ntiles);
   if (int e = segan_check_launch("corr_bf2_kernel")) return e;
   if (a.sk_total > 0) {

@@ -83,6 +83,15 @@ struct CorrArgs {
   int RLv, nld;                // corr2: valid window positions (RLs is the padded row), loads per lane
 };
 
+// (*) 16-byte buffer stores take their row offset in the VECTOR offset, never in an SGPR soffset.
+// gfx950 hazard found in round 4: a VALU write to the data registers of a buffer_store_dwordx4 in
+// the slot right after the store can reach the store — LLVM's hazard recogniser pads that case only
+// when the store has NO register soffset ("this hazard only exists if the instruction is not using
+// a register in the soffset field"), which does not hold on this part: with the row in an SGPR and
+// no bias load between two stores, element 0 of every second vector of the conv data gradient was
+// the NEXT row's value (tests/diag/diag_dgrad_epilogue.py).  One v_add per store instead.
+
+
 
 static inline int samples_per_tile(int Tcols, int NB) {
   if (Tcols >= NB) return (Tcols % NB == 0) ? 1 : 2;

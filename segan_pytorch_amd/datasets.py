@@ -264,6 +264,7 @@ class PCMShardLoader(object):
         self.sampler = sampler if sampler is not None else RandomSampler(shard)
         self.preemph = float(preemph)
         self.device = torch.device(device)
+        self._side = None
         self.loader = DataLoader(_BatchIndexDataset(shard), batch_size=None,
                                  sampler=BatchSampler(self.sampler, batch_size, drop_last),
                                  num_workers=num_workers, pin_memory=True,
@@ -280,9 +281,40 @@ class PCMShardLoader(object):
                                       first.to(self.device, non_blocking=True), self.preemph)
         return [names, clean, noisy, idx]
 
+    def _stage(self, item):
+        """H2D copy + prep kernel of one batch on the loader's SIDE stream; (batch, event)."""
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        with torch.cuda.stream(self._side):
+            batch = self._prep(item)
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+        return batch, ev
+
     def __iter__(self):
-        for item in self.loader:
-            yield self._prep(item)
+        """Batch n+1 crosses PCIe (20 MB of int16 at batch 300: ~0.8 ms) and is normalised on a side
+        stream while step n computes; the training stream only waits on the event of a copy that
+        finished long ago."""
+        if self.device.type != 'cuda':
+            for item in self.loader:
+                yield self._prep(item)
+            return
+        it = iter(self.loader)
+        try:
+            nxt = self._stage(next(it))
+        except StopIteration:
+            return
+        while nxt is not None:
+            (names, clean, noisy, idx), ev = nxt
+            try:
+                nxt = self._stage(next(it))
+            except StopIteration:
+                nxt = None
+            main = torch.cuda.current_stream(self.device)
+            main.wait_event(ev)
+            clean.record_stream(main)
+            noisy.record_stream(main)
+            yield [names, clean, noisy, idx]
 
     def sample(self):
         """One random batch per call from ONE live iterator, re-created only when the epoch is

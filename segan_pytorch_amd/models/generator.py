@@ -149,6 +149,8 @@ class Generator(Model):
         buffers alternate; the copy runs on its own stream as soon as the step before the
         previous one (the last reader of that device buffer) has finished."""
         st = self.__dict__.get('_zstage')
+        if st is not None and (st['shape'] != shape or st['device'] != device):
+            self.cancel_z_prefetch()        # a look-ahead draw for the old shape: undone
         if st is None or st['shape'] != shape or st['device'] != device:
             st = {'shape': shape, 'device': device, 'i': 0, 'stream': torch.cuda.Stream(device=device),
                   'pin': [torch.empty(shape, pin_memory=True) for _ in range(2)],
