@@ -473,6 +473,10 @@ def main():
                          'reference (generator.py:197); the default times what train.py runs')
     ap.add_argument('--no-kernel-timer', action='store_true')
     ap.add_argument('--no-modes', action='store_true', help='skip the bf16x3 / bf16 side measurements')
+    ap.add_argument('--comm-ab', action='store_true',
+                    help='world > 1: also time the steps with the OTHER gradient transport (libsegan_hip\'s '
+                         'own RCCL communicators vs torch.distributed); opt-in — the native transport has '
+                         'only ever run at one rank, and a first multi-GPU run should not depend on it')
     ap.add_argument('--wsegan', action='store_true',
                     help='time the WSEGAN step of BASELINE config 4 (--wsegan --misalign_pair) instead '
                          'of the SEGAN+ step; a side measurement, not the headline metric')
@@ -611,7 +615,7 @@ def main():
         comm['comm_wait_ms_per_step'] = float(w.item())
         comm['ms_per_step'] = {('native' if sdist.native_comm() is not None else 'torch.distributed'):
                                1e3 * dt / args.steps}
-        if backend == 'nccl' and not args.no_modes:
+        if backend == 'nccl' and args.comm_ab:
             was_native = sdist.native_comm() is not None
             try:
                 sdist.set_native(not was_native)

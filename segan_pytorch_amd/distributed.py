@@ -70,8 +70,19 @@ def init_from_env(backend=None):
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend == 'nccl':
             torch.cuda.set_device(lr)
+            # RCCL's kernels on a HIGH-PRIORITY stream: the contraction kernels fill every CU (3
+            # workgroups of 4 waves each), so a bucket's all-reduce can only start where a compute
+            # workgroup retires; with priority the hardware dispatcher hands the first freed slots
+            # to RCCL's few workgroups (one per channel) instead of the next compute workgroups
+            opts = None
+            try:
+                opts = dist.ProcessGroupNCCL.Options()
+                opts.is_high_priority_stream = True
+            except Exception:       # pragma: no cover - option absent in this torch build
+                opts = None
+            kw = {'pg_options': opts} if opts is not None else {}
             dist.init_process_group(backend, rank=rk, world_size=ws,
-                                    device_id=torch.device('cuda', lr))
+                                    device_id=torch.device('cuda', lr), **kw)
         else:
             dist.init_process_group(backend, rank=rk, world_size=ws)
     _init_native(rk, ws)
@@ -110,7 +121,7 @@ def _init_native(rk, ws, force=False):
         dist.broadcast_object_list(ident, src=0)
     _native = ops.Comm(ws, rk, ident[0][0])
     _native_cur = ops.Comm(ws, rk, ident[0][1])
-    _native_stream = torch.cuda.Stream()
+    _native_stream = torch.cuda.Stream(priority=-1)     # high priority: see init_from_env
 
 
 def set_native(on):
