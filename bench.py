@@ -227,8 +227,8 @@ def hip_step_parity(ref, opts, gsd0, dsd0, clean, noisy, z, rolls, dev, precisio
 
 PARITY_NOTE = ('HIP step vs the CPU oracle step timed above, same weights / inputs / z / phase shifts; '
                'generator phase through the oracle\'s post-step D; gradient figures are relative L2 per '
-               'tensor (ReLU-gate flips at fp32 roundoff bound them, tests/test_gpu_kernels.py::'
-               'test_discriminator_batchnorm_at_batch_300); `parity` = fp32 in the deterministic mode '
+               'tensor (two dozen ReLU-gate flips at fp32 roundoff bound them: with the gates aligned the distance '
+               'is 5e-6, tests/test_gpu_kernels.py::test_discriminator_gradients_with_aligned_gates); `parity` = fp32 in the deterministic mode '
                '(bit-reproducible), `parity_default_mode` = fp32 in the timed (atomics) mode, '
                'other_precisions.*.parity = the bf16x3 / bf16 contractions in the timed mode; '
                '`parity_blocked_accumulation` = fp32 with ops.set_accumulation(\'blocked\') '
