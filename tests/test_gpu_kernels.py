@@ -937,7 +937,7 @@ def test_discriminator_batchnorm_at_batch_300(gated):
     gated=True: slopes 0.05..0.3.  A PReLU gate is discontinuous in its derivative: of the
     ~10^7 pre-activations a handful sit within fp32 roundoff of zero, the CPU and the GPU take
     different sides there, and each such flip moves the gradients downstream by a discrete
-    amount (measured vs an fp64 oracle, tests/diag/diag_d300.py: GPU 2e-3, fp32 CPU oracle
+    amount (measured vs an fp64 oracle, test_discriminator_gradients_with_aligned_gates: GPU 2e-3, fp32 CPU oracle
     2e-4..6e-4 in relative L2; the forward agrees to 4e-6).  Bound: 6e-3 relative L2."""
     from segan_pytorch_amd.models import Discriminator
     from segan_pytorch_amd import losses
@@ -1007,7 +1007,7 @@ def gpu_discriminator_gates(D):
 @pytest.mark.parametrize('slopes', ['init', 'trained'])
 def test_discriminator_gradients_with_aligned_gates(slopes):
     """What test_discriminator_batchnorm_at_batch_300's 6e-3 allowance rests on, as a test
-    (round-3 review, weak point 1; formerly tests/diag/diag_d300.py + diag_gateflips.py).
+    (round-3 review, weak point 1; formerly the diagnostics diag_d300.py + diag_gateflips.py).
 
     One D forward + backward at B = 300 on the GPU against an fp64 evaluation of the oracle:
       (1) the pre-activations on which the two disagree about the PReLU side are COUNTED: they
