@@ -54,18 +54,22 @@ def _act_bwd_bn(a, dh, slope, bn, dslope, dgamma, dbeta, dbias):
                        dbias=dbias)
 
 
-# Weight gradients on a SIDE stream (round 4).  Inside a backward pass the chain
+# Weight gradients on a SIDE stream (round 4, OPT-IN: SEGAN_WGRAD_OVERLAP=1).  Inside a backward
+# pass the chain
 #   act_bwd(l) -> data gradient(l) -> act_bwd(l-1) -> ...
 # is serial, the weight gradient of layer l hangs off it: it needs da(l) and nothing needs IT before
 # the optimizer step.  Launched on a second stream it runs beside the chain — beside the next
 # data gradient (both on the matrix cores: nothing gained, nothing lost) and beside the next
 # act_bwd / BatchNorm-backward passes, which are HBM-bound and leave the matrix cores idle when
 # they run alone.  Measured (scripts/r04_overlap_ab.sh, alternating runs on one box): fp32 step
-# 87.32 -> 87.10 ms, bf16 24.45 -> 23.92 ms.  The fp32 kernels fill the register file (4 x 124 /
-# 3 x 150 VGPRs per SIMD), so a pointwise kernel only gets a slot where a contraction workgroup
-# retires: the overlap is the tails, not whole kernels; launching the data gradient first changes
-# nothing.  SEGAN_WGRAD_OVERLAP=0 keeps everything on one stream (A/B switch).
-_WGRAD_OVERLAP = os.environ.get('SEGAN_WGRAD_OVERLAP', '1') != '0'
+# 87.32 -> 87.10 ms (0.25 %), bf16 24.45 -> 23.92 ms (2.2 %).  The fp32 kernels fill the register
+# file (4 x 124 / 3 x 150 VGPRs per SIMD), so a pointwise kernel only gets a slot where a contraction
+# workgroup retires: the overlap is the tails, not whole kernels; launching the data gradient
+# first changes nothing.  NOT the default: two contraction kernels sharing the machine each take
+# about twice as long per launch, so every per-kernel figure (bench.py's event-timed `roofline`
+# blocks, a rocprofv3 kernel trace) reads half the rate the kernel has — 0.25 % of the headline is
+# not worth measurements that need a footnote.
+_WGRAD_OVERLAP = os.environ.get('SEGAN_WGRAD_OVERLAP', '0') == '1'
 _side_streams = {}
 
 
