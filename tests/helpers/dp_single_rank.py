@@ -12,6 +12,9 @@ from types import SimpleNamespace
 
 mode, out = sys.argv[1], sys.argv[2]
 os.environ['SEGAN_DETERMINISTIC'] = '1'
+if mode.endswith('overlap'):        # 'overlap' / 'rccl_overlap': weight gradients on the side stream
+    os.environ['SEGAN_WGRAD_OVERLAP'] = '1'
+    mode = 'plain' if mode == 'overlap' else mode[:-len('_overlap')]
 if mode != 'plain':
     with socket.socket() as sk:
         sk.bind(('127.0.0.1', 0))

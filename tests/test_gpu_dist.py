@@ -35,6 +35,21 @@ def test_rccl_single_rank_step_equals_plain_step(tmp_path):
 
 
 @pytest.mark.gpu
+def test_weight_gradients_on_the_side_stream_change_nothing(tmp_path):
+    """SEGAN_WGRAD_OVERLAP=1 (functional._SideStream: the weight gradients of a backward pass are
+    launched on a second stream beside the data-gradient chain, opt-in): the same kernels on the
+    same data in deterministic mode, so the weights after two GAN steps equal the one-stream run's
+    bit for bit — alone and under the RCCL gradient reducer, whose gradient-ready reports then
+    come from the side stream."""
+    plain = _run('plain', str(tmp_path / 'plain.pt'))
+    for mode in ('overlap', 'rccl_overlap'):
+        got = _run(mode, str(tmp_path / (mode + '.pt')))
+        for k, v in plain['sd'].items():
+            assert torch.equal(v, got['sd'][k]), (mode, k)
+        assert plain['info']['losses'] == got['info']['losses']
+
+
+@pytest.mark.gpu
 def test_native_comm_single_rank_step_equals_plain_step(tmp_path):
     """SEGAN_COMM=native: the gradient buckets travel through libsegan_hip's OWN communicator
     (C ABI segan_comm_init / segan_allreduce / segan_comm_destroy; RCCL bound at run time), issued
