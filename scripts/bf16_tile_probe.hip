@@ -14,8 +14,12 @@
 // kernels) and issues NI*NJ MFMAs, the reads one step ahead of the MFMAs.  DMA = 1 adds the LDS
 // WRITE side of the real kernel: per step the workgroup's share of a (2 NI x 2 NJ waves') operand
 // tile arrives by buffer_load ... lds (16 B per lane) from an L2-resident buffer, behind a
-// double buffer and a barrier per STG steps.  Data are random bf16 (DVFS: zeros would give the
-// clock back).  TF/s = MFMAs x 2*32*32*16 / wall time (hipEvents, best of 5); the shader clock is
+// double buffer and a barrier per STG steps.  DMA = 2 (round 4, NOT yet run: the first thing for round
+// 5) feeds the A operand differently: every wave reads its NI "A" fragments of a step STRAIGHT from
+// the L2-resident buffer into registers (buffer_load_dwordx4, one step ahead, no LDS write and no
+// LDS read for A) and only the B fragments travel by LDS-DMA — the question behind DESIGN.md 5.1's
+// last paragraph: is an LDS-DMA instruction's 60-185 cycles of issue port the thing to avoid?
+// Data are random bf16 (DVFS: zeros would give the clock back).  TF/s = MFMAs x 2*32*32*16 / wall time (hipEvents, best of 5); the shader clock is
 // measured inside the kernel (s_memtime over s_memrealtime).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -73,13 +77,14 @@ __global__ __launch_bounds__(256, WPS) void probe(const u32x4* __restrict__ src,
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
   // DMA: the workgroup's fragments of one buffer, instruction q = wave + 4k moves fragment q
-  constexpr int NDMA = (STG * G::FR + 3) / 4;
+  constexpr int NFR = DMA == 2 ? 2 * NJ : G::FR;          // fragments per step that go through LDS-DMA
+  constexpr int NDMA = (STG * NFR + 3) / 4;
   auto issue = [&](int stage, int buf) {
     if (!DMA) return;
 #pragma unroll
     for (int k = 0; k < NDMA; ++k) {
-      const int q = wave + 4 * k;
-      if (q < STG * G::FR)
+      const int q = DMA == 2 ? (wave + 4 * k) / NFR * G::FR + 2 * NI + (wave + 4 * k) % NFR : wave + 4 * k;
+      if (wave + 4 * k < STG * NFR)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(
             rs, (__attribute__((address_space(3))) void*)(lds + buf * G::BUF_U4 + q * 64), 16,
             lane * 16, (int)(((unsigned)(stage * STG * G::FR + q + 7 * blockIdx.x) * 1024u) %
@@ -97,7 +102,15 @@ __global__ __launch_bounds__(256, WPS) void probe(const u32x4* __restrict__ src,
     auto rd = [&](int u, bf16x8 (&a)[NI], bf16x8 (&b)[NJ]) {
       const u32x4* S = L + u * G::STEP_U4 + lane;
 #pragma unroll
-      for (int i = 0; i < NI; ++i) a[i] = __builtin_bit_cast(bf16x8, S[(wm * NI + i) * 64]);
+      for (int i = 0; i < NI; ++i) {
+        if (DMA == 2) {       // this wave's own fragment, 1 KiB straight from L2 into registers
+          const unsigned off = (((unsigned)((st * STG + u) * 2 * NI + wm * NI + i) + 11u * blockIdx.x) * 1024u) %
+                               (unsigned)(src_u4 * 16 - 1024);
+          a[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, (int)(off & ~1023u), 0));
+        } else {
+          a[i] = __builtin_bit_cast(bf16x8, S[(wm * NI + i) * 64]);
+        }
+      }
 #pragma unroll
       for (int j = 0; j < NJ; ++j) b[j] = __builtin_bit_cast(bf16x8, S[(2 * NI + wn * NJ + j) * 64]);
     };
@@ -223,6 +236,11 @@ int main() {
   run<2, 4, 2, 1>(src, src_u4, out, clk, ncu, first);
   run<4, 4, 1, 0>(src, src_u4, out, clk, ncu, first);
   run<4, 4, 1, 1>(src, src_u4, out, clk, ncu, first);
+  // A straight from L2 into registers, B by LDS-DMA
+  run<2, 2, 2, 2>(src, src_u4, out, clk, ncu, first);
+  run<2, 4, 1, 2>(src, src_u4, out, clk, ncu, first);
+  run<4, 2, 1, 2>(src, src_u4, out, clk, ncu, first);
+  run<4, 4, 1, 2>(src, src_u4, out, clk, ncu, first);
   printf("\n]}\n");
   return 0;
 }
