@@ -158,6 +158,11 @@ class Saver(object):
         # new file is complete (the reference rewrites the index and deletes first, core.py:40-60;
         # with training going on during the write, that order would leave `current` dangling on a
         # crash)
+        final = os.path.join(self.save_path, 'weights_' + fname)
+        # a name that is already listed (a re-run in the same save_path restarts at iteration 1, so
+        # the '<name>-<step>' names repeat) is overwritten in place: it moves to the end of the list
+        # and is never its own victim — the deletion happens AFTER the new file is written
+        latest = [n for n in latest if n != fname]
         victim = None
         if latest and self.max_ckpts is not None and len(latest) > self.max_ckpts:
             victim = os.path.join(self.save_path, 'weights_' + latest[0])
@@ -166,13 +171,14 @@ class Saver(object):
             else:
                 print('ERROR: ckpt is not there?')
                 victim = None
+        if victim == final:
+            victim = None
         latest = latest + [fname]
         index['latest'] = latest
         index['current'] = fname
         payload = {'step': step, 'state_dict': self.model.state_dict()}
         if self.optimizer is not None:
             payload['optimizer'] = self.optimizer.state_dict()
-        final = os.path.join(self.save_path, 'weights_' + fname)
         if not self.async_save:
             torch.save(payload, final)
             self._commit(index, victim)

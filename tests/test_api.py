@@ -260,6 +260,37 @@ def test_checkpoint_index_follows_the_weights_file(tmp_path, monkeypatch):
     assert Saver(torch.nn.Linear(3, 2), str(tmp_path), prefix='X-').load_weights()
 
 
+@pytest.mark.parametrize('async_save', [False, True])
+def test_resaving_the_same_step_names_keeps_every_new_file(tmp_path, async_save):
+    """A second run in the same save_path restarts at iteration 1 (model.py:271), so the
+    '<name>-<step>' checkpoint names repeat.  The rotated-out file is deleted AFTER the new one is
+    written (round-3 order), so a checkpoint must never be its own victim (round-4 advice): after
+    the re-run `current` names a file that exists and that holds the NEW weights."""
+    from segan_pytorch_amd.models.core import Saver
+    net = torch.nn.Linear(3, 2)
+    sv = Saver(net, str(tmp_path), max_ckpts=3, prefix='EOE_G-', async_save=async_save)
+    for step in (101, 201, 301, 401, 501):
+        sv.save('Net', step)
+    sv.wait()
+    net2 = torch.nn.Linear(3, 2)
+    sv2 = Saver(net2, str(tmp_path), max_ckpts=3, prefix='EOE_G-', async_save=async_save)
+    for step in (101, 201, 301, 401, 501, 601):
+        with torch.no_grad():
+            net2.weight.fill_(float(step))
+        sv2.save('Net', step)
+        sv2.wait()
+        idx = json.load(open(str(tmp_path / 'EOE_G-checkpoints')))
+        cur = str(tmp_path / ('weights_' + idx['current']))
+        assert idx['current'] == 'EOE_G-Net-{}.ckpt'.format(step) and os.path.exists(cur)
+        assert float(torch.load(cur)['state_dict']['weight'][0, 0]) == float(step)
+        assert len(idx['latest']) == len(set(idx['latest'])) <= 4
+        for n in idx['latest']:
+            assert os.path.exists(str(tmp_path / ('weights_' + n))), n
+    probe = torch.nn.Linear(3, 2)
+    assert Saver(probe, str(tmp_path), prefix='EOE_G-').load_weights()
+    assert float(probe.weight.detach()[0, 0]) == 601.0
+
+
 def test_accumulation_mode_switch():
     """ops.set_accumulation: 'plain' (default) / 'blocked' select SEGAN_PREC_FP32 /
     SEGAN_PREC_FP32_BLOCKED for the fp32 forward / data-gradient entry points."""
