@@ -398,6 +398,40 @@ def wsegan_parity(opts, B, dev):
     return base, out
 
 
+def host_side_costs(dev, zshape, world, backend, device_z):
+    """Per-rank host cost of one step's z: all ranks draw at the same moment (after a barrier), 3
+    draws each into a pinned buffer, the median; then the H2D copy of that buffer, event-timed.
+    Gathered over the ranks.  With --device-z no host draw happens in the step: reported as such."""
+    import torch.distributed as dist
+    from segan_pytorch_amd import distributed as sdist
+    pin = torch.empty(zshape, pin_memory=True)
+    dst = torch.empty(zshape, device=dev)
+    dist.barrier()
+    draws = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        torch.randn(zshape, out=pin)
+        draws.append(1e3 * (time.perf_counter() - t0))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    dst.copy_(pin, non_blocking=True)       # warm-up
+    torch.cuda.synchronize()
+    e0.record()
+    dst.copy_(pin, non_blocking=True)
+    e1.record()
+    torch.cuda.synchronize()
+    mine = torch.tensor([sorted(draws)[1], e0.elapsed_time(e1)], dtype=torch.float64,
+                        device=dev if backend == 'nccl' else 'cpu')
+    allr = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allr, mine)
+    return {'z_draw_ms_per_rank': [round(float(t[0]), 2) for t in allr],
+            'z_h2d_ms_per_rank': [round(float(t[1]), 3) for t in allr],
+            'z_bytes': int(np.prod(zshape)) * 4,
+            'z_in_the_timed_steps': 'device generator (no host draw)' if device_z else
+                                    'host randn one step ahead on a thread + pinned H2D on a side stream',
+            'pinning': sdist.host_pin(), 'torch_threads': torch.get_num_threads(),
+            'cpus_visible': len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else os.cpu_count()}
+
+
 def csrc_sha():
     """Short hash over the HIP sources: profile-derived figures carry the hash of the sources they
     were measured on, so a bench line built on newer kernels shows them as stale."""
@@ -615,6 +649,11 @@ def main():
         comm['comm_wait_ms_per_step'] = float(w.item())
         comm['ms_per_step'] = {('native' if sdist.native_comm() is not None else 'torch.distributed'):
                                1e3 * dt / args.steps}
+        # what every rank's HOST side costs with all ranks of the node at it at once (round-4 review,
+        # item 7): the single-threaded randn of one z (drawn one step ahead on a host thread: it must
+        # stay below the step time) and its pinned H2D copy, per rank; plus how the ranks were pinned
+        comm['host'] = host_side_costs(dev, (B, opts['z_dim'], 16384 // int(np.prod(opts['genc_poolings']))),
+                                       world, backend, args.device_z)
         if backend == 'nccl' and args.comm_ab:
             was_native = sdist.native_comm() is not None
             try:
@@ -789,12 +828,16 @@ def main():
         if timer is not None:
             s = timer.summary()
             c = s.get('corr')
+            # counters belong to the workload they were collected on (round-4 review, weak 8: the
+            # 11-layer side line used to carry the SEGAN+ profile's figures): the committed PMC
+            # files are looked up by workload suffix and a workload without its own passes gets null
+            wl = ('_vanilla11' if args.shape == 'vanilla11' else '') + ('_wsegan' if args.wsegan else '')
             if fp32_run:
-                traffic, traffic_prov = pmc_traffic()
+                traffic, traffic_prov = pmc_traffic(suffix=wl)
             else:       # the bf16 profile exists for 'bf16' only
                 traffic, traffic_prov = (pmc_traffic(main=('corr_bf2_kernel', 'corr_bf_kernel'),
                                                      extra=('bf2_fixup_kernel', 'act_pack_kernel'),
-                                                     suffix='_bf16')
+                                                     suffix='_bf16' + wl)
                                          if args.precision == 'bf16' else (None, None))
             if c:
                 line['roofline'] = {
@@ -810,8 +853,8 @@ def main():
                     'avg_launch_us': c['avg_us'], 'launches': c['launches'],
                     'gflop_per_launch': c['flops_per_launch'] / 1e9,
                     'share_of_step_time': c['total_ms'] / (1e3 * dt),
-                    'mfma_pipe_busy_pmc': (pmc_mfma_busy('corr2') if fp32_run else
-                                           pmc_mfma_busy('corr_bf2', '_bf16') if args.precision == 'bf16'
+                    'mfma_pipe_busy_pmc': (pmc_mfma_busy('corr2', wl) if fp32_run else
+                                           pmc_mfma_busy('corr_bf2', '_bf16' + wl) if args.precision == 'bf16'
                                            else None)}
             if 'wgrad' in s:
                 w = s['wgrad']
@@ -824,8 +867,8 @@ def main():
                                           'avg_launch_us': w['avg_us'], 'launches': w['launches'],
                                           'share_of_step_time': w['total_ms'] / (1e3 * dt),
                                           'mfma_pipe_busy_pmc': (
-                                              pmc_mfma_busy('wgrad2') if fp32_run else
-                                              pmc_mfma_busy('wgrad_bf2', '_bf16') if args.precision == 'bf16'
+                                              pmc_mfma_busy('wgrad2', wl) if fp32_run else
+                                              pmc_mfma_busy('wgrad_bf2', '_bf16' + wl) if args.precision == 'bf16'
                                               else None)}
         if modes:
             modes['note'] = ('same workload, contractions on the bf16 MFMA: bf16x3 = fp32 operands '

@@ -259,17 +259,23 @@ class PCMShardLoader(object):
 
     def __init__(self, shard, batch_size, preemph, device, sampler=None, drop_last=False,
                  num_workers=2):
-        from torch.utils.data import BatchSampler, DataLoader, RandomSampler
+        from torch.utils.data import RandomSampler
         self.shard = shard
         self.sampler = sampler if sampler is not None else RandomSampler(shard)
         self.preemph = float(preemph)
         self.device = torch.device(device)
         self._side = None
-        self.loader = DataLoader(_BatchIndexDataset(shard), batch_size=None,
-                                 sampler=BatchSampler(self.sampler, batch_size, drop_last),
-                                 num_workers=num_workers, pin_memory=True,
-                                 prefetch_factor=2 if num_workers > 0 else None,
-                                 persistent_workers=num_workers > 0)
+        self._batch_size, self._drop_last, self._num_workers = batch_size, drop_last, num_workers
+        self.loader = self._make_loader()
+        self._sample_loader = None      # sample()'s own loader: see there
+
+    def _make_loader(self):
+        from torch.utils.data import BatchSampler, DataLoader
+        nw = self._num_workers
+        return DataLoader(_BatchIndexDataset(self.shard), batch_size=None,
+                          sampler=BatchSampler(self.sampler, self._batch_size, self._drop_last),
+                          num_workers=nw, pin_memory=True, prefetch_factor=2 if nw > 0 else None,
+                          persistent_workers=nw > 0)
 
     def __len__(self):
         return len(self.loader)
@@ -322,19 +328,42 @@ class PCMShardLoader(object):
         `next(iter(dloader))` every step (model.py:526-535): on this loader that would reset the
         persistent workers, wait for an un-prefetched first batch (20 MB over IPC + pinning) and
         throw away up to three prefetched ones, every step (round-3 advice).  Batches then come
-        from a shuffled pass without replacement instead of a fresh shuffle per step."""
-        it = getattr(self, '_live', None)
-        if it is None:
-            it = self._live = iter(self.loader)
-        try:
-            item = next(it)
-        except StopIteration:
-            if hasattr(self.sampler, 'set_epoch'):
-                self._epoch = getattr(self, '_epoch', 0) + 1
-                self.sampler.set_epoch(self._epoch)
-            it = self._live = iter(self.loader)
-            item = next(it)
-        return self._prep(item)
+        from a shuffled pass without replacement instead of a fresh shuffle per step.
+
+        The iterator lives on a SECOND DataLoader of the same shard and sampler (created on first
+        use): a DataLoader with persistent workers has one shared `_iterator`, so sampling from
+        the loader that `__iter__` walks — train / evaluate over this object while WSEGAN samples
+        from it — would make the two iterators reset each other (dropped or duplicated batches;
+        round-4 advice).  The next sample batch is staged (H2D + prep kernel) on the side stream
+        while the caller computes on this one, like `__iter__` does."""
+        if self._sample_loader is None:
+            self._sample_loader = self._make_loader()
+
+        def fetch():
+            it = getattr(self, '_live', None)
+            if it is None:
+                it = self._live = iter(self._sample_loader)
+            try:
+                return next(it)
+            except StopIteration:
+                if hasattr(self.sampler, 'set_epoch'):
+                    self._epoch = getattr(self, '_epoch', 0) + 1
+                    self.sampler.set_epoch(self._epoch)
+                it = self._live = iter(self._sample_loader)
+                return next(it)
+
+        if self.device.type != 'cuda':
+            return self._prep(fetch())
+        staged = getattr(self, '_sample_next', None)
+        if staged is None:
+            staged = self._stage(fetch())
+        self._sample_next = self._stage(fetch())      # in flight under the caller's step
+        (names, clean, noisy, idx), ev = staged
+        main = torch.cuda.current_stream(self.device)
+        main.wait_event(ev)
+        clean.record_stream(main)
+        noisy.record_stream(main)
+        return [names, clean, noisy, idx]
 
 
 class PCMShardCollate(object):

@@ -86,7 +86,42 @@ def init_from_env(backend=None):
         else:
             dist.init_process_group(backend, rank=rk, world_size=ws)
     _init_native(rk, ws)
+    pin_host_threads(int(os.environ.get('LOCAL_RANK', lr)), int(os.environ.get('LOCAL_WORLD_SIZE', ws)))
     return rk, ws, lr
+
+
+_host_pin = None
+
+
+def pin_host_threads(local_rank, local_world):
+    """One slice of the host's cores per rank of this node (round-4 review, item 7): N ranks that
+    each start torch's default intra-op pool (= all cores) and a z-draw thread oversubscribe the
+    host N times over, and the single-threaded randn of the next z (~25 ms for 300 x 1024 x 16)
+    then competes with 8 x 128 idle-spinning OpenMP threads.  The rank's process is bound to a
+    contiguous range of the CPUs it was allowed (contiguous ranges follow the NUMA nodes on the
+    usual enumeration), torch's intra-op pool is sized to it (at most 16: the host side of a step
+    is launches and one randn).  `SEGAN_NO_PIN=1` leaves the process alone.  Returns what was done
+    (also kept for bench.py's `comm.host` block), or None."""
+    global _host_pin
+    if local_world <= 1 or os.environ.get('SEGAN_NO_PIN') == '1' or not hasattr(os, 'sched_setaffinity'):
+        return None
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+        per = len(cpus) // local_world
+        if per < 1:
+            return None
+        mine = cpus[local_rank * per:(local_rank + 1) * per]
+        os.sched_setaffinity(0, mine)
+        torch.set_num_threads(max(1, min(per, 16)))
+        _host_pin = {'cpus_per_rank': per, 'first_cpu': mine[0], 'last_cpu': mine[-1],
+                     'torch_threads': torch.get_num_threads()}
+    except Exception as e:      # pragma: no cover - a container that forbids it
+        _host_pin = {'error': repr(e)}
+    return _host_pin
+
+
+def host_pin():
+    return _host_pin
 
 
 # ---- the exchange through libsegan_hip's own RCCL communicators (SEGAN_COMM=native) -----------
@@ -163,11 +198,11 @@ def allreduce_mean_(flat):
     return flat
 
 
-_bucket_bytes = int(float(os.environ.get('SEGAN_DP_BUCKET_MB', '32')) * (1 << 20))
+_bucket_bytes = int(float(os.environ.get('SEGAN_DP_BUCKET_MB', '16')) * (1 << 20))
 
 
 def set_bucket_bytes(n):
-    """Target size of a gradient bucket (default 32 MiB, SEGAN_DP_BUCKET_MB); a parameter is
+    """Target size of a gradient bucket (default 16 MiB, SEGAN_DP_BUCKET_MB: D = {fc} 16 MB, {enc4} 62, {enc3, enc2} 19, {enc1, enc0} 1; G = {dec1..dec4} 41, {dec0} 124, {enc4, alphas} 62, {enc3, enc2} 19, {enc1, enc0} 1); a parameter is
     never split, so the big weights form buckets of their own."""
     global _bucket_bytes
     _bucket_bytes = int(n)
@@ -183,19 +218,28 @@ class GradReducer(object):
         self.buckets = []                 # (first float, end float)
         self.members = []                 # number of parameters per bucket
         self.bucket_of = {}
-        start, n, nb = None, 0, 0
+        # Buckets are runs of consecutive parameters built from the LAST parameter backwards: the
+        # backward passes finish the layers in reverse registration order (G: dec4 .. dec0, enc4 ..
+        # enc0; D: fc, enc4 .. enc0), so a run that ENDS at a late layer closes as soon as its
+        # earliest member is done, and what is left for the end of the pass — the only part of the
+        # exchange nothing can hide — is the small early layers (D: enc1 + enc0, 1 MB; built
+        # front to back the first bucket was enc0 .. enc4 = 82 MB of D's 98, all of it exposed on the
+        # critical path before Dopt.step, model.py:308)
         params, offs = optimizer._params, optimizer._offsets
-        for i, p in enumerate(params):
-            if start is None:
-                start, n, nb = offs[i], 0, 0
-            self.bucket_of[id(p)] = len(self.buckets)
-            n += 1
-            nb += p.numel() * 4
-            end = offs[i + 1] if i + 1 < len(params) else optimizer._total
-            if nb >= bucket_bytes or i + 1 == len(params):
-                self.buckets.append((start, end))
-                self.members.append(n)
-                start = None
+        i = len(params) - 1
+        while i >= 0:
+            hi = offs[i + 1] if i + 1 < len(params) else optimizer._total
+            nb, j = 0, i
+            while True:
+                nb += params[j].numel() * 4
+                if nb >= bucket_bytes or j == 0:
+                    break
+                j -= 1
+            for k in range(j, i + 1):
+                self.bucket_of[id(params[k])] = len(self.buckets)
+            self.buckets.append((offs[j], hi))
+            self.members.append(i - j + 1)
+            i = j - 1
         self.armed = False
         self.pending, self.sent, self.works = [], [], []
         self.wait_events, self.wait_host_s, self.finishes = [], 0.0, 0
@@ -250,10 +294,13 @@ class GradReducer(object):
             e0 = torch.cuda.Event(enable_timing=True)
             e0.record()
         late = 0
+        lb = self.__dict__.setdefault('late_by_bucket', [0] * len(self.buckets))
         for b in range(len(self.buckets)):
             if not self.sent[b]:
                 self._send(b)
                 late += 1
+                if _profile:
+                    lb[b] += 1
         for w in self.works:
             w.wait()
         self.armed = False
@@ -288,6 +335,7 @@ def set_profile(on):
     _profile = bool(on)
     for r in _reducers.values():
         r.wait_events, r.wait_host_s, r.finishes, r.late_buckets = [], 0.0, 0, 0
+        r.late_by_bucket = [0] * len(r.buckets)
 
 
 def comm_stats():
@@ -306,6 +354,7 @@ def comm_stats():
             'bucket_mb': [round((hi - lo) * 4 / 2 ** 20, 2) for lo, hi in r.buckets],
             'finishes': r.finishes,
             'late_buckets': getattr(r, 'late_buckets', 0),
+            'late_by_bucket': list(getattr(r, 'late_by_bucket', [0] * len(r.buckets))),
             'wait_device_ms': sum(a.elapsed_time(b) for a, b in r.wait_events),
             'wait_host_ms': 1e3 * r.wait_host_s,
         })

@@ -79,7 +79,16 @@ class _SideStream(object):
     caching allocator must not hand their memory out again before the side stream is done)."""
 
     def __init__(self, *tensors):
-        self.tensors = [t for t in tensors if t is not None and t.is_cuda]
+        # an ops.Src stands for its segments and per-channel vectors: every operand the side
+        # stream reads is recorded, not only the gradient (round-4 advice) — the backward passes
+        # below also keep ctx.state alive until _join_side, but the allocator no longer depends on it
+        flat = []
+        for t in tensors:
+            if isinstance(t, Src):
+                flat.extend((t.t0, t.t1, t.scale, t.shift, t.slope))
+            else:
+                flat.append(t)
+        self.tensors = [t for t in flat if torch.is_tensor(t) and t.is_cuda]
         self.on = _WGRAD_OVERLAP and bool(self.tensors)
 
     def __enter__(self):
@@ -447,7 +456,7 @@ class GeneratorFn(torch.autograd.Function):
                 da = _act_bwd_bn(a_dec[li], dh, blk.act.weight, bnsv, _gb(blk.act.weight),
                                  _gb(bnm.weight), _gb(bnm.bias), _gb(mod.bias))
             src = src_dec[li]
-            with _SideStream(da):
+            with _SideStream(da, src):
                 if W.needs_grad(mod):
                     gw = W.grad_target(mod)
                     if is_conv:
@@ -522,7 +531,7 @@ class GeneratorFn(torch.autograd.Function):
                 da = _act_bwd_bn(a_enc[l], g, None, bnsv, None, _gb(bnm.weight), _gb(bnm.bias),
                                  _gb(blk.conv.bias))
             padL = ops.conv_pad(K, S)[0]
-            with _SideStream(da):
+            with _SideStream(da, src_enc[l]):
                 if W.needs_grad(blk.conv):
                     gw = W.grad_target(blk.conv)
                     ops.wgrad(Src(da), src_enc[l], gw, K, S, padL, PAD_REFLECT)
@@ -682,7 +691,7 @@ class DiscriminatorFn(torch.autograd.Function):
                 dc = ops.act_bwd(cs[l], dh, slope=blk.act.weight, dslope=_gb(blk.act.weight),
                                  dbias=_gb(blk.conv.bias))
             padL = ops.conv_pad(K, S)[0]
-            with _SideStream(dc):
+            with _SideStream(dc, srcs[l]):
                 if W.needs_grad(blk.conv):
                     gw = W.grad_target(blk.conv)
                     ops.wgrad(Src(dc), srcs[l], gw, K, S, padL, PAD_REFLECT, roll=ctx.rolls[l])

@@ -165,7 +165,9 @@ class Generator(Model):
             job['thread'].join()
             if job['error'] is not None:
                 raise job['error']
-            if job['shape'] != shape or job['i'] != i:
+            if self._z_prefetch_raced(job):
+                job = None      # draw again, from the generator as it stands (no rewind)
+            elif job['shape'] != shape or job['i'] != i:
                 # not what this call needs (a shorter last batch): put the generator back where
                 # the reference's would be and draw again
                 torch.set_rng_state(job['state'])
@@ -186,20 +188,25 @@ class Generator(Model):
         me = torch.cuda.Event()
         me.record(main)
         st['main'] = me
-        if self.z_prefetch:
+        if self.z_prefetch and not self.__dict__.get('z_prefetch_disabled', False):
             # the NEXT call's z, drawn by a host thread while this step's launches go out (randn
             # releases the GIL): same numbers as the reference's draw as long as nothing else
             # takes from torch's global CPU generator before the next call — the training loop
             # switches z_prefetch off around the draws it knows of (epoch ends; see SEGAN.train)
             j = i ^ 1
-            nxt = {'shape': shape, 'i': j, 'state': None, 'error': None}
+            # the generator's state is snapshotted HERE, on the calling thread; the draw thread
+            # notes what it found and what it left, and the join checks both (_z_prefetch_raced):
+            # any other taker of the global generator in between is detected, not silently mixed in
+            nxt = {'shape': shape, 'i': j, 'state': torch.get_rng_state(), 'before': None,
+                   'after': None, 'error': None}
 
             def draw():
                 try:
                     if st['copied'][j] is not None:
                         st['copied'][j].synchronize()
-                    nxt['state'] = torch.get_rng_state()
+                    nxt['before'] = torch.get_rng_state()
                     torch.randn(shape, out=st['pin'][j])
+                    nxt['after'] = torch.get_rng_state()
                 except BaseException as e:      # surfaced by the next call
                     nxt['error'] = e
             nxt['thread'] = threading.Thread(target=draw, daemon=True)
@@ -209,13 +216,35 @@ class Generator(Model):
         z._segan_staged = True
         return z
 
+    def _z_prefetch_raced(self, job):
+        """True when something else took from torch's global CPU generator while the look-ahead
+        draw `job` was pending (a num_workers=0 dataset or collate using torch RNG, a user hook,
+        dropout drawn on the host ...): the generator did not stand where the calling thread left
+        it when the draw began, or does not stand where the draw left it now.  The order of those
+        takes relative to the z draw is then a matter of thread timing, so the look-ahead is
+        switched off for good (``z_prefetch_disabled``; SEGAN.train's per-step switch honours it),
+        with one warning; the caller draws z synchronously from the generator as it stands."""
+        if job['after'] is None:
+            return False
+        if torch.equal(job['before'], job['state']) and torch.equal(torch.get_rng_state(), job['after']):
+            return False
+        import warnings
+        warnings.warn('Generator.z_prefetch: torch\'s global CPU generator was used by something else '
+                      'while the next z was being drawn on the host thread; the look-ahead draw is '
+                      'switched off for the rest of the run (same as --no_prefetch_z) so that the draw '
+                      'order stays deterministic', RuntimeWarning)
+        self.__dict__['z_prefetch_disabled'] = True
+        self.z_prefetch = False
+        return True
+
     def cancel_z_prefetch(self):
-        """Undo a pending look-ahead draw (the generator goes back to where it was)."""
+        """Undo a pending look-ahead draw (the generator goes back to where it was — unless
+        something else has used it meanwhile: then it is left alone, see _z_prefetch_raced)."""
         st = self.__dict__.get('_zstage')
         job = st.pop('job', None) if st else None
         if job is not None:
             job['thread'].join()
-            if job['state'] is not None:
+            if job['state'] is not None and not self._z_prefetch_raced(job):
                 torch.set_rng_state(job['state'])
 
     def _fn_params(self):

@@ -213,6 +213,34 @@ def _stream_scratch(nbytes, device):
     return buf
 
 
+def release_scratch(device=None):
+    """Hand the per-stream scratch buffers (the stream-K slabs of the fp32 contractions, 128 MiB
+    per device + stream, and the grow-only call scratch of the bf16 / weight-gradient calls, 134+ MB
+    per stream) back to the caching allocator — all of them, or those of one device.
+
+    The buffers are keyed by the RAW stream handle, so an entry outlives a destroyed torch stream;
+    nothing else ever frees them.  Call it where streams come and go (a server that creates a
+    stream per request) or before handing the device to something else; the next contraction call
+    re-allocates what it needs.  Safe at any point between calls: the kernels that used a buffer
+    were enqueued on its stream, and the caching allocator re-uses the block in stream order
+    (the buffers were allocated while their stream was current).
+
+    The invariant the sharing rests on, stated here because nothing else enforces it: a library
+    call hands out AT MOST ONE region of a stream's call scratch (`_stream_scratch`), and no call
+    keeps it past its last kernel.  A bf16 call that the library declines (SEGAN_EUNSUPPORTED) and
+    that is retried in fp32 satisfies it because the fp32 forms use `_scratch()` — the separate
+    stream-K buffer — only."""
+    dev = None if device is None else torch.device(device).index
+    for d in (_corr_scratch, _call_scratch):
+        for key in [k for k in d if dev is None or k[0] == dev]:
+            del d[key]
+
+
+def scratch_bytes():
+    """Bytes currently held by the per-stream scratch buffers (diagnostics / tests)."""
+    return sum(b.numel() for d in (_corr_scratch, _call_scratch) for b in d.values())
+
+
 def _bf_scratch(op, B, N, M, L, K, S, pad, device):
     """(buffer, pointer, bytes) of the packed-activation scratch of a bf16 / bf16x3 contraction
     call (segan_bf16_scratch_bytes), from the stream's call scratch."""

@@ -139,6 +139,20 @@ def test_bench_launches_its_own_ranks():
         assert a['buckets'] == len(a['bucket_mb']) >= 2 and a['finishes'] == 2
         assert abs(sum(a['bucket_mb']) - a['arena_floats'] * 4 / 2 ** 20) < 0.01
         assert a['late_buckets'] <= a['buckets'] * a['finishes']
+        # buckets run from the last parameter backwards (the order the backward finishes them in), so
+        # every bucket closes inside the backward pass: none — and in particular none of the big ones
+        # (G: dec0 124 MB, enc4 62 MB; D: enc4 62 MB) — is left for the optimizer step
+        assert len(a['late_by_bucket']) == a['buckets'] and sum(a['late_by_bucket']) == a['late_buckets']
+        for mb, late in zip(a['bucket_mb'], a['late_by_bucket']):
+            if mb > 30:
+                assert late == 0, (a['bucket_mb'], a['late_by_bucket'])
+    # the host side of every rank, all ranks at it at once: z draw (single-threaded randn) and its H2D
+    h = c['host']
+    assert len(h['z_draw_ms_per_rank']) == len(h['z_h2d_ms_per_rank']) == 2
+    assert all(v > 0 for v in h['z_draw_ms_per_rank'] + h['z_h2d_ms_per_rank'])
+    assert h['pinning'] is None or 'cpus_per_rank' in h['pinning'] or 'error' in h['pinning']
+    for a in c['arenas']:
+        pass
         assert a['wait_device_ms_per_step'] >= 0.0 and a['wait_host_ms_per_step'] > 0.0
     assert d['comm_wait_ms_per_step'] == c['comm_wait_ms_per_step'] >= 0.0
     assert list(c['ms_per_step']) == ['torch.distributed']

@@ -1004,6 +1004,86 @@ def gpu_discriminator_gates(D):
     return gates
 
 
+def discriminator_aligned_gates_run(slopes, precision='fp32', B=300):
+    """One D forward + backward at batch B on the GPU in the given contraction precision against an
+    fp64 evaluation of the oracle, free-running and with the GPU's PReLU sides imposed (oracle
+    `gates=`: where(gate, a, slope*a)).  Returns the figures the two tests below assert:
+    flips / total gates, the largest fp64 |a| at a flipped gate, the logits' distance, the
+    free-running and the aligned gradient distance (relative L2, worst tensor, with its name)."""
+    from segan_pytorch_amd.models import Discriminator
+    from segan_pytorch_amd import losses, ops
+    torch.manual_seed(5)
+    D = Discriminator(2, [64, 128, 256, 512, 1024], 31, poolings=[4] * 5, pool_type='none',
+                      pool_slen=16, norm_type='bnorm', phase_shift=5)
+    for n_, p in D.named_parameters():
+        if n_.endswith('act.weight'):
+            if slopes == 'trained':
+                p.data.uniform_(0.05, 0.3)
+        elif n_.endswith('conv.weight'):
+            p.data.normal_(0.0, 0.02)
+    sd0 = {k: v.detach().clone() for k, v in D.state_dict().items()}
+    D = D.to(DEV).train()
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(B, 2, 16384, generator=g) * 2 - 1
+    rolls = [2, -5, 1, -1, 4]
+    D.draw_rolls = lambda: list(rolls)
+    old, oldp = ops.get_deterministic(), ops.get_precision()
+    ops.set_deterministic(True)
+    ops.set_precision(precision)
+    try:
+        y, _ = D(x[:, :1].contiguous().to(DEV), x[:, 1:].contiguous().to(DEV))
+        loss = losses.MSELoss()(y.view(-1), 1.0)
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        ops.set_deterministic(old)
+        ops.set_precision(oldp)
+    gates = gpu_discriminator_gates(D)
+    dn = dict(D.named_parameters())
+
+    def oracle64(gates_):
+        sd = {k: (v.double().requires_grad_(True) if torch.is_floating_point(v) and
+                  k.split('.')[-1] not in O._BUFFERS else
+                  (v.double() if torch.is_floating_point(v) else v.clone())) for k, v in sd0.items()}
+        yo, acts = O.discriminator_forward(sd, x.double(), rolls, [4] * 5, ret_act=True, gates=gates_)
+        lo = F.mse_loss(yo.view(-1), torch.ones(B, dtype=torch.float64))
+        keys = [k for k, v in sd.items() if torch.is_tensor(v) and v.requires_grad]
+        return yo, acts, dict(zip(keys, torch.autograd.grad(lo, [sd[k] for k in keys])))
+
+    # (1) the free-running fp64 oracle: where do the sides differ, and how close to zero is that
+    y64, acts64, g64 = oracle64(None)
+    flips = total = 0
+    worst = 0.0
+    per_layer = {}
+    for k, gate in gates.items():
+        a = acts64['a_' + k[2:]] if k.startswith('h_') else acts64['fc_a' + k[3:]]
+        diff = gate != (a > 0)
+        flips += int(diff.sum())
+        total += gate.numel()
+        per_layer[k] = int(diff.sum()) / gate.numel()
+        if diff.any():
+            worst = max(worst, float(a[diff].abs().max()))
+    free = max(l2_rel(dn[k].grad, v) for k, v in g64.items()
+               if not k.endswith('conv.bias') and v.abs().max().item() >= 1e-7)
+    # (2) the same oracle with the GPU's sides
+    _, _, g64a = oracle64(gates)
+    aligned, worst_key, zero_ok = 0.0, None, True
+    for k, gr in g64a.items():
+        if k.endswith('conv.bias'):
+            continue            # zero gradient in front of BatchNorm: roundoff on both sides
+        if gr.abs().max().item() < 1e-7:
+            zero_ok = zero_ok and dn[k].grad.abs().max().item() < 1e-6
+            continue
+        e = l2_rel(dn[k].grad, gr)
+        if e > aligned:
+            aligned, worst_key = e, k
+    out = dict(precision=precision, slopes=slopes, flips=flips, total=total, flip_share=flips / total,
+               flip_share_per_layer=per_layer, worst_abs_a_at_a_flip=worst, logits_max_rel=max_rel(y, y64),
+               free_running=free, aligned=aligned, aligned_worst_tensor=worst_key, zero_grads_ok=zero_ok)
+    print(out)
+    return out
+
+
 @pytest.mark.parametrize('slopes', ['init', 'trained'])
 def test_discriminator_gradients_with_aligned_gates(slopes):
     """What test_discriminator_batchnorm_at_batch_300's 6e-3 allowance rests on, as a test
@@ -1022,76 +1102,36 @@ def test_discriminator_gradients_with_aligned_gates(slopes):
           |a| > 5e-6) is those gates.
     slopes = 'init': PReLU slopes 0 in the conv stack and 0.25 in the head, the state the
     benchmarked step runs from (model.py:28-43); 'trained': slopes 0.05..0.3."""
-    from segan_pytorch_amd.models import Discriminator
-    from segan_pytorch_amd import losses, ops
-    B = 300
-    torch.manual_seed(5)
-    D = Discriminator(2, [64, 128, 256, 512, 1024], 31, poolings=[4] * 5, pool_type='none',
-                      pool_slen=16, norm_type='bnorm', phase_shift=5)
-    for n_, p in D.named_parameters():
-        if n_.endswith('act.weight'):
-            if slopes == 'trained':
-                p.data.uniform_(0.05, 0.3)
-        elif n_.endswith('conv.weight'):
-            p.data.normal_(0.0, 0.02)
-    sd0 = {k: v.detach().clone() for k, v in D.state_dict().items()}
-    D = D.to(DEV).train()
-    g = torch.Generator().manual_seed(1)
-    x = torch.rand(B, 2, 16384, generator=g) * 2 - 1
-    rolls = [2, -5, 1, -1, 4]
-    D.draw_rolls = lambda: list(rolls)
-    old = ops.get_deterministic()
-    ops.set_deterministic(True)
-    try:
-        y, _ = D(x[:, :1].contiguous().to(DEV), x[:, 1:].contiguous().to(DEV))
-        loss = losses.MSELoss()(y.view(-1), 1.0)
-        loss.backward()
-        torch.cuda.synchronize()
-    finally:
-        ops.set_deterministic(old)
-    gates = gpu_discriminator_gates(D)
-    dn = dict(D.named_parameters())
+    r = discriminator_aligned_gates_run(slopes, 'fp32')
+    assert r['logits_max_rel'] < 5e-5
+    assert r['flips'] <= 2e-5 * r['total'], (r['flips'], r['total'])
+    assert r['worst_abs_a_at_a_flip'] < 2e-5
+    assert r['zero_grads_ok']
+    assert r['aligned'] < 5e-5, (r['aligned_worst_tensor'], r['aligned'])
 
-    def oracle64(gates_):
-        sd = {k: (v.double().requires_grad_(True) if torch.is_floating_point(v) and
-                  k.split('.')[-1] not in O._BUFFERS else
-                  (v.double() if torch.is_floating_point(v) else v.clone())) for k, v in sd0.items()}
-        yo, acts = O.discriminator_forward(sd, x.double(), rolls, [4] * 5, ret_act=True, gates=gates_)
-        lo = F.mse_loss(yo.view(-1), torch.ones(B, dtype=torch.float64))
-        keys = [k for k, v in sd.items() if torch.is_tensor(v) and v.requires_grad]
-        return yo, acts, dict(zip(keys, torch.autograd.grad(lo, [sd[k] for k in keys])))
 
-    # (1) the free-running fp64 oracle: where do the sides differ, and how close to zero is that
-    y64, acts64, g64 = oracle64(None)
-    assert max_rel(y, y64) < 5e-5
-    flips = total = 0
-    worst = 0.0
-    for k, gate in gates.items():
-        a = acts64['a_' + k[2:]] if k.startswith('h_') else acts64['fc_a' + k[3:]]
-        diff = gate != (a > 0)
-        flips += int(diff.sum())
-        total += gate.numel()
-        if diff.any():
-            worst = max(worst, float(a[diff].abs().max()))
-    free = max(l2_rel(dn[k].grad, v) for k, v in g64.items()
-               if not k.endswith('conv.bias') and v.abs().max().item() >= 1e-7)
-    print('gate flips {} of {} ({:.2e}); largest |a| at a flip {:.2e}; free-running gradient '
-          'distance (worst tensor, rel L2) {:.2e}'.format(flips, total, flips / total, worst, free))
-    assert flips <= 2e-5 * total, (flips, total)
-    assert worst < 2e-5, worst
-    # (2) the same oracle with the GPU's sides
-    _, _, g64a = oracle64(gates)
-    worst_aligned = 0.0
-    for k, gr in g64a.items():
-        if k.endswith('conv.bias'):
-            continue            # zero gradient in front of BatchNorm: roundoff on both sides
-        if gr.abs().max().item() < 1e-7:
-            assert dn[k].grad.abs().max().item() < 1e-6, k
-            continue
-        e = l2_rel(dn[k].grad, gr)
-        worst_aligned = max(worst_aligned, e)
-        assert e < 5e-5, (k, e)
-    print('aligned-gate gradient distance (worst tensor, rel L2) {:.2e}'.format(worst_aligned))
+def test_release_scratch_frees_and_the_next_call_reallocates():
+    """ops.release_scratch (round-4 advice): the per-stream scratch buffers are handed back, also
+    those of a side stream whose torch.cuda.Stream object is gone, and the next contraction call
+    allocates what it needs again with the same results."""
+    from segan_pytorch_amd import ops
+    o = _ops()
+    x, w = rnd(4, 64, 1024, seed=1), rnd(128, 64, 31, seed=2, scale=0.05)
+    src = o.Src(x.to(DEV))
+    y0 = o.conv1d_fwd(src, w.to(DEV), None, 4)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        y1 = o.conv1d_fwd(src, w.to(DEV), None, 4)
+    torch.cuda.synchronize()
+    del side
+    assert ops.scratch_bytes() >= 2 * (128 << 20)        # one stream-K buffer per stream
+    ops.release_scratch()
+    assert ops.scratch_bytes() == 0
+    y2 = o.conv1d_fwd(src, w.to(DEV), None, 4)
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1) and torch.equal(y0, y2)
+    assert ops.scratch_bytes() >= (128 << 20)
 
 
 def test_mse_between_tensors_matches_torch():

@@ -785,6 +785,32 @@ def test_z_prefetch_keeps_the_reference_rng_stream(tiny_step):
     assert torch.equal(got, torch.get_rng_state())
 
 
+def test_z_prefetch_detects_another_user_of_the_global_generator(tiny_step):
+    """Round-4 advice: the look-ahead z draw shares torch's global CPU generator with whatever else
+    the process draws from it.  A draw on the main thread while a look-ahead is pending is DETECTED
+    at the next forward (the generator does not stand where the draw thread left it): one warning,
+    the look-ahead switches itself off for good, z is drawn synchronously, and the run goes on."""
+    fx = tiny_step
+    m = build(fx)
+    m.G.train()
+    x = fx['noisy'].to(DEV)
+    torch.manual_seed(3)
+    with torch.no_grad():
+        m.G.z_prefetch = True
+        m.G(x)
+        st = m.G.__dict__['_zstage']
+        st['job']['thread'].join()              # the look-ahead draw is done ...
+        torch.rand(7)                           # ... and something else uses the generator
+        with pytest.warns(RuntimeWarning, match='z_prefetch'):
+            y = m.G(x)
+        assert m.G.z_prefetch is False and m.G.__dict__.get('z_prefetch_disabled')
+        m.G.z_prefetch = True                   # SEGAN.train sets it every step: stays off
+        m.G(x)
+        assert 'job' not in m.G.__dict__['_zstage']
+    assert torch.isfinite(y).all()
+    m.G.cancel_z_prefetch()
+
+
 def test_full_gan_step_at_batch_300_matches_the_oracle():
     """The benchmarked configuration itself inside `-m gpu` (round-3 review, weak point 9: the
     whole-step batch-300 comparison used to live only in bench.py): one full GAN step of the default

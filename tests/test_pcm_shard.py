@@ -123,20 +123,45 @@ def test_loader_sample_keeps_one_live_iterator(tmp_path):
     ds = PCMShardDataset(str(tmp_path / 'sh'))
     loader = PCMShardLoader(ds, 4, 0.95, 'cuda', num_workers=1)
     entered = []
-    real_iter = type(loader.loader).__iter__
+    loader._sample_loader = loader._make_loader()       # sample()'s own DataLoader (lazy otherwise)
+    assert loader._sample_loader is not loader.loader
+    real_iter = type(loader._sample_loader).__iter__
 
-    class Counting(type(loader.loader)):
+    class Counting(type(loader._sample_loader)):
         def __iter__(self):
             entered.append(1)
             return real_iter(self)
-    loader.loader.__class__ = Counting
+    loader._sample_loader.__class__ = Counting
     per_epoch = len(loader)
     seen = []
-    for _ in range(2 * per_epoch + per_epoch // 2 + 1):
+    calls = 2 * per_epoch + per_epoch // 2 + 1
+    for _ in range(calls):
         names, clean, noisy, idx = loader.sample()
         for k, name in enumerate(names):
             rc, rn = want[(name, int(idx[k]))]
             assert torch.equal(clean[k].cpu(), rc) and torch.equal(noisy[k].cpu(), rn)
             seen.append((name, int(idx[k])))
-    assert len(entered) == 3, len(entered)
+    # one batch is staged ahead of the one handed out: calls + 1 fetches
+    assert len(entered) == -(-(calls + 1) // per_epoch), (len(entered), calls, per_epoch)
     assert sorted(seen[:len(ds)]) == sorted(want) and sorted(seen[len(ds):2 * len(ds)]) == sorted(want)
+
+
+@pytest.mark.gpu
+def test_loader_sample_does_not_disturb_an_epoch_in_progress(tmp_path):
+    """Round-4 advice: iterating the loader (train / evaluate) while WSEGAN samples from the same
+    object.  With one shared DataLoader the two iterators reset each other; with sample() on its
+    own DataLoader an epoch interleaved with sample() calls still yields every item exactly once,
+    and so does the sample stream."""
+    from segan_pytorch_amd.datasets import PCMShardLoader
+    cd, nd = _write_wavs(tmp_path)
+    build_pcm_shard(cd, nd, str(tmp_path / 'sh'), slice_size=16384, stride=0.5)
+    ds = PCMShardDataset(str(tmp_path / 'sh'))
+    loader = PCMShardLoader(ds, 4, 0.95, 'cuda', num_workers=1)
+    epoch, sampled = [], []
+    for names, clean, noisy, idx in loader:
+        epoch += [(n, int(i)) for n, i in zip(names, idx)]
+        sn, sc, sno, si = loader.sample()
+        sampled += [(n, int(i)) for n, i in zip(sn, si)]
+        assert torch.isfinite(sc).all() and torch.isfinite(clean).all()
+    assert len(epoch) == len(ds) == len(set(epoch))
+    assert len(sampled) == len(ds) == len(set(sampled))

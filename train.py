@@ -106,7 +106,10 @@ FLAGS = [
                              'but not the reference\'s RNG stream')),
     ('--no_prefetch_z', dict(action='store_true', default=False,
                              help='draw every z inside its own step instead of one step ahead on a host '
-                                  'thread (same numbers either way: Generator._host_z)')),
+                                  'thread (same numbers either way as long as nothing else takes from torch\'s global CPU '
+                                  'generator inside an epoch; if something does — a num_workers=0 dataset using '
+                                  'torch RNG, a hook — it is detected and the look-ahead switches itself off '
+                                  'with a warning: Generator._host_z)')),
     ('--deterministic', dict(action='store_true', default=False,
                              help='bit-reproducible kernels: the weight-gradient and dense-head contraction '
                                   'splits are added in a fixed order instead of with fp32 atomics '
