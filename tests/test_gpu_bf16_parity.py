@@ -14,7 +14,8 @@ The re-stated tolerance for bf16 GRADIENTS:
   the fp64 oracle evaluated with the GPU's own gate sides (oracle `gates=`).  That figure is
   pure operand rounding and is asserted here: see BF16_ALIGNED_TOL.
 * And what a user of config 5 needs is that training on those gradients follows the fp32
-  trajectory: a 20-step run from identical state, losses and weights compared step by step.
+  trajectory: a 20-step run from identical state, losses and weights compared step by step,
+  with the bf16x3 mode as the control for the trajectory's own sensitivity to rounding.
 """
 import os
 import random
@@ -33,10 +34,16 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda'
 
 # ---- the re-stated bf16 gradient tolerances (relative L2 per tensor, worst tensor) -----------
-BF16_FLIP_SHARE = 2e-2        # share of PReLU gates that may differ from the fp64 run's sides
-BF16_FLIP_ABS = 0.25          # ... every one of them a unit-scale value this close to zero
-BF16_ALIGNED_TOL = 3e-2       # gradient distance to fp64 with the GPU's gate sides imposed
-BF16_LOGITS_TOL = 3e-2        # D's logits (max-abs relative to the largest logit)
+# measured on MI355X (round 5, gpurun_out -> DESIGN.md section 6): D at batch 300, slopes init /
+# trained: 5.7e-4 / 5.2e-4 of the gates flipped (per layer 8e-4 .. 2.3e-3 from the second conv on),
+# largest |a| at a flip 0.025 / 0.021, logits 8.2e-3 / 6.1e-3, gradients aligned 7.4e-3 / 6.3e-3
+# (worst tensor enc_blocks.4.conv.weight / enc_blocks.3.act.weight) against 0.14 / 0.11
+# free-running; generator phase at batch 16: aligned 1.15e-2 (enc_blocks.4.act.weight) against
+# 0.18 free-running.
+BF16_FLIP_SHARE = 2e-3        # share of PReLU gates that may differ from the fp64 run's sides
+BF16_FLIP_ABS = 0.08          # ... every one of them a unit-scale value this close to zero
+BF16_ALIGNED_TOL = 2e-2       # gradient distance to fp64 with the GPU's gate sides imposed
+BF16_LOGITS_TOL = 2e-2        # D's logits (max-abs relative to the largest logit)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -149,16 +156,34 @@ def test_generator_phase_bf16_gradients_with_aligned_gates():
 
 def test_bf16_trajectory_tracks_fp32_over_20_steps():
     """Config 5 as it is USED (model.py:298-321 trains on these gradients): 20 full GAN steps of
-    the default SEGAN+ net at batch 8 from identical weights, data, z and phase shifts, once in
-    exact fp32 and once with the bf16 contractions.  Stated band: every one of the 4 x 20 logged
-    losses within 5 % (d_real / d_fake / g_adv relative to max(|loss|, 0.05); g_l1 within 1 %),
-    and the total weight update of each network after 20 steps pointing the same way
-    (cosine > 0.7 for G, > 0.5 for D: RMSprop's first steps are sign-like, +-10 lr per element,
-    so elements whose gradient is at the bf16 noise level step at random) with the same length
-    (norm ratio within 10 %)."""
+    the default SEGAN+ net at batch 32 from identical weights, data, z and phase shifts in exact
+    fp32, with the bf16x3 contractions (fp32-class rounding in a different summation order: the
+    CONTROL for how far two correct runs of this GAN drift apart on their own) and with the bf16
+    contractions.
+
+    The first steps of this training are violent by construction — RMSprop's first step moves
+    every weight by +-10 lr, D's losses jump to ~500 at step 1 and oscillate between 0.1 and 3
+    afterwards — and the trajectory amplifies rounding: at batch 8 even the CONTROL is off by
+    factors of 2-3 on single adversarial losses (tests/diag/diag_bf16_trajectory.py).  At batch 32
+    the control tracks fp32 closely, which makes a band meaningful.  Measured (round 5):
+
+                         per-step ratio to fp32, worst of 20     geometric mean over 20 steps
+                         d_real  d_fake  g_adv   g_l1            d_real  d_fake  g_adv   g_l1
+      bf16x3 (control)   1.10    1.06    1.07    1.002           1.003   1.004   1.005   1.0005
+      bf16               2.10    1.54    2.13    1.002           1.035   0.984   1.029   0.9987
+
+      total weight update after 20 steps against fp32's: cosine G 0.73 / D 0.885 (control 0.88 /
+      0.96 — RMSprop's early steps are sign-like, so elements whose gradient is at the noise
+      level step at random), length within 0.5 %.
+
+    Stated band (asserted): bf16 — the L1 term (the quantity the generator is trained on, 100 x)
+    within 1 % at EVERY step; every adversarial / discriminator loss within a factor 4 of fp32's
+    and their geometric mean over the 20 steps within 15 %; update cosine G > 0.5, D > 0.7, length
+    within 2 %.  Control — factor 1.5, mean within 3 %, cosine G > 0.7, D > 0.9."""
+    import math
     from segan_pytorch_amd import losses, ops
     from segan_pytorch_amd.models import SEGAN
-    B, STEPS = 8, 20
+    B, STEPS = 32, 20
     opts, m0, gsd0, dsd0, clean, noisy = _default_model(B)
     del m0
     zs = [torch.randn(B, 1024, 16, generator=torch.Generator().manual_seed(100 + i)) for i in range(STEPS)]
@@ -167,8 +192,9 @@ def test_bf16_trajectory_tracks_fp32_over_20_steps():
              for _ in range(STEPS)]
 
     def run(prec):
-        oldp = ops.get_precision()
+        oldp, oldd = ops.get_precision(), ops.get_deterministic()
         ops.set_precision(prec)
+        ops.set_deterministic(True)
         try:
             m = SEGAN(SimpleNamespace(**opts))
             m.G.load_state_dict(gsd0)
@@ -184,34 +210,41 @@ def test_bf16_trajectory_tracks_fp32_over_20_steps():
                 out = m.gan_step(cg, ng, Gopt, Dopt, losses.MSELoss(), 100.0, z=zs[i].to(DEV))
                 log.append([float(v) for v in out])
             torch.cuda.synchronize()
-            return log, {k: v.detach().cpu().double() for k, v in m.G.state_dict().items()}, \
-                {k: v.detach().cpu().double() for k, v in m.D.state_dict().items()
-                 if torch.is_floating_point(v) and k.split('.')[-1] not in O._BUFFERS}
+            g = torch.cat([(v.detach().cpu().double() - gsd0[k].double()).flatten()
+                           for k, v in m.G.state_dict().items()])
+            d = torch.cat([(v.detach().cpu().double() - dsd0[k].double()).flatten()
+                           for k, v in m.D.state_dict().items()
+                           if torch.is_floating_point(v) and k.split('.')[-1] not in O._BUFFERS])
+            return log, g, d
         finally:
             ops.set_precision(oldp)
+            ops.set_deterministic(oldd)
 
-    l32, g32, d32 = run('fp32')
-    l16, g16, d16 = run('bf16')
-    worst = [0.0] * 4
-    for a, b in zip(l32, l16):
-        for j in range(4):
-            den = max(abs(a[j]), 0.05) if j < 3 else abs(a[j])
-            worst[j] = max(worst[j], abs(a[j] - b[j]) / den)
-
-    def update(after, before):
-        return torch.cat([(after[k] - before[k].double()).flatten() for k in after])
-
-    fig = {}
-    for name, a32, a16, s0 in (('G', g32, g16, gsd0), ('D', d32, d16, dsd0)):
-        u32, u16 = update(a32, s0), update(a16, s0)
-        fig[name + '_update_cosine'] = (torch.dot(u32, u16) / (u32.norm() * u16.norm())).item()
-        fig[name + '_update_norm_ratio'] = (u16.norm() / u32.norm()).item()
-    print(dict(loss_band_worst=dict(zip(('d_real', 'd_fake', 'g_adv', 'g_l1'), worst)), **fig,
-               last_fp32=l32[-1], last_bf16=l16[-1]))
-    assert all(np.isfinite(v) for row in l16 for v in row)
-    assert worst[0] < 5e-2 and worst[1] < 5e-2 and worst[2] < 5e-2 and worst[3] < 1e-2, worst
-    assert fig['G_update_cosine'] > 0.7 and fig['D_update_cosine'] > 0.5, fig
-    assert abs(fig['G_update_norm_ratio'] - 1) < 0.1 and abs(fig['D_update_norm_ratio'] - 1) < 0.1, fig
+    ref = run('fp32')
+    bands = {'bf16x3': dict(step=1.5, mean=0.03, l1=0.005, cos_g=0.7, cos_d=0.9, norm=0.02),
+             'bf16': dict(step=4.0, mean=0.15, l1=0.01, cos_g=0.5, cos_d=0.7, norm=0.02)}
+    for prec, bd in bands.items():
+        log, g, d = run(prec)
+        assert all(math.isfinite(v) and v > 0 for row in log for v in row)
+        worst, mean = [0.0] * 4, [0.0] * 4
+        for a, b in zip(ref[0], log):
+            for j in range(4):
+                r = math.log(b[j] / a[j])
+                worst[j] = max(worst[j], abs(r))
+                mean[j] += r / STEPS
+        fig = dict(precision=prec, step_ratio_worst=[round(math.exp(w), 4) for w in worst],
+                   geo_mean_ratio=[round(math.exp(v), 4) for v in mean],
+                   G_update_cosine=(torch.dot(ref[1], g) / (ref[1].norm() * g.norm())).item(),
+                   D_update_cosine=(torch.dot(ref[2], d) / (ref[2].norm() * d.norm())).item(),
+                   G_update_norm_ratio=(g.norm() / ref[1].norm()).item(),
+                   D_update_norm_ratio=(d.norm() / ref[2].norm()).item())
+        print(fig)
+        for j in range(3):
+            assert math.exp(worst[j]) < bd['step'], (prec, j, fig)
+            assert abs(math.exp(mean[j]) - 1) < bd['mean'], (prec, j, fig)
+        assert math.exp(worst[3]) - 1 < bd['l1'], (prec, fig)
+        assert fig['G_update_cosine'] > bd['cos_g'] and fig['D_update_cosine'] > bd['cos_d'], fig
+        assert abs(fig['G_update_norm_ratio'] - 1) < bd['norm'] and abs(fig['D_update_norm_ratio'] - 1) < bd['norm'], fig
 
 
 def test_wsegan_step_at_batch_300_matches_the_oracle():
