@@ -727,8 +727,17 @@ def main():
     modes = {}
     if args.precision == 'fp32' and not args.no_modes:
         for prec in ('bf16x3', 'bf16'):
+            host_gen = None
             try:
                 _ops.set_precision(prec)
+                if prec == 'bf16' and not args.device_z:
+                    # as train.py --precision bf16 runs it: z drawn on the GPU — a bf16 step takes about
+                    # as long as the single-threaded host randn of one z (~25 ms), which would
+                    # otherwise be the critical path (train.py --host_z restores the host draw)
+                    model.G.cancel_z_prefetch()
+                    model.G.z_prefetch = False
+                    host_gen = True
+                    model.G.z_generator = torch.Generator(device=dev).manual_seed(rank)
                 for _ in range(2):
                     one_step()
                 mt = None
@@ -749,6 +758,8 @@ def main():
                     dm = float(t.item())
                 modes[prec] = {'value': B * world * args.steps / dm, 'unit': 'chunks/s',
                                'ms_per_step': 1e3 * dm / args.steps,
+                               'z': 'device generator (train.py --precision bf16 default)'
+                                    if (host_gen or args.device_z) else 'host randn one step ahead + H2D',
                                'losses_finite': all(bool(torch.isfinite(x)) for x in lo)}
                 if mt is not None:
                     # bf16: one bf16 MFMA per product; bf16x3: six, so the peak
@@ -769,6 +780,9 @@ def main():
                 break
             finally:
                 _ops.set_precision('fp32')
+                if host_gen:
+                    model.G.z_generator = None
+                    model.G.z_prefetch = not args.wsegan
 
     if rank == 0:
         chunks = B * world * args.steps

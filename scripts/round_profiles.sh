@@ -18,6 +18,15 @@ for p in fp32 bf16; do
   python scripts/pmc_traffic.py $O/pmc_${p}_FETCH_SIZE/run_counter_collection.csv $O/pmc_${p}_WRITE_SIZE/run_counter_collection.csv 3 $O/pmc_hbm_traffic_$p.json
   rm -rf $O/pmc_${p}_FETCH_SIZE $O/pmc_${p}_WRITE_SIZE
 done
+# the 11-layer stride-2 shape gets its OWN counters (round-4 review, weak 8: its bench line used to
+# carry the SEGAN+ profile's traffic / pipe-busy figures): kernel stats + the two PMC passes
+rocprofv3 --kernel-trace --stats -d $O/prof_v11 -o run -- $B --steps 6 --warmup 1 --shape vanilla11 > $O/bench_prof_v11.log 2>&1
+python scripts/rocpd_stats.py $O/prof_v11/*results.db $O/kernel_stats_vanilla11.csv 7 > /dev/null 2>&1; rm -rf $O/prof_v11
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace -d $O/pmc_v11_$c -o run --output-format csv -- $B --steps 2 --warmup 1 --shape vanilla11 > $O/pmc_v11_$c.log 2>&1
+done
+python scripts/pmc_traffic.py $O/pmc_v11_FETCH_SIZE/run_counter_collection.csv $O/pmc_v11_WRITE_SIZE/run_counter_collection.csv 3 $O/pmc_hbm_traffic_vanilla11.json
+rm -rf $O/pmc_v11_FETCH_SIZE $O/pmc_v11_WRITE_SIZE
 # every contraction of the SEGAN+ nets in isolation
 python scripts/bench_layers.py --iters 3 > $O/layers_fp32.txt 2>&1
 SEGAN_PRECISION=bf16 python scripts/bench_layers.py --iters 3 > $O/layers_bf16.txt 2>&1

@@ -384,53 +384,119 @@ __device__ __forceinline__ bool tile_is_dead(const CorrArgs& a, int m0) {
 // from LDS before the MFMAs of step s are issued (three named register sets; everything is
 // unrolled so all indices are static); sched_barrier pins that order so the LDS latency of the
 // next operands is covered by the MFMAs instead of being exposed.
-template <int MB, int U, int KC, int NI, int NJ, bool SHIFT>
+//
+// K = 31 taps are padded to 32, so one contraction row in 32 multiplies zeros — half of one
+// v_mfma_f32_32x32x2_f32 (two rows per instruction).  Two such halves are merged into one
+// instruction (round 5; 1/32 of the F / T forms' matrix work):
+//  * FMODE (F form, chunk = the 32 (r,u) rows of ONE input channel, the zero tap is row 31, paired
+//    with row 30 in the last step).  Channels are processed in pairs (A = even, B = A + 1): the
+//    packing stores A's row-30 weights in B's row 31 (segan_pack.hip, `f_pair`).  FMODE 1 = chunk
+//    A with its partner following in this piece: steps 0..14 only, the row-30 activations are kept
+//    in `b30` (all lanes read the lower half's address).  FMODE 2 = chunk B: 16 steps, the upper
+//    half of the last step's activation operand is b30 — zero when the piece began with B (A's
+//    row 30 is then added by the piece that held A: an A that ends its piece runs FMODE 0, whose
+//    row 31 holds zeros).  FMODE 0 = the plain 16 steps.
+//  * ZP >= 0 (T form, chunk = CV input channels x U taps, rows (c, u'); the zero tap is u' = 0 of
+//    output phase ZP, i.e. of the 32-row blocks i with (32 i) / NPT == ZP).  Those blocks skip the
+//    CV steps (c; u' = 0, 1) and run CV / 2 merged steps instead whose lower / upper half is row
+//    (2p, 1) / (2p + 1, 1): operand offsets aoffx = aoff + h (U-1) MB, boffx = boff + h (RLs-1).
+template <int MB, int U, int KC, int NI, int NJ, bool SHIFT, int FMODE = 0, int ZP = -1, int NPT = 32>
 __device__ __forceinline__ void corr_mma_chunk(const float* Wl, const float* Il, int RLs,
                                                const int (&aoff)[NI], const int (&boff)[NJ],
-                                               const int (&rsh)[NI], f32x16 (&acc)[NI][NJ]) {
+                                               const int (&rsh)[NI], f32x16 (&acc)[NI][NJ],
+                                               float (&b30)[NJ], int h, const int (&aoffx)[NI],
+                                               const int (&boffx)[NJ]) {
+  static_assert(FMODE == 0 || (!SHIFT && ZP < 0), "the pair trick of the F form has no row shifts");
   constexpr int NBI = SHIFT ? NI : 1;
+  constexpr int CVC = KC / U;                           // channels (T) / phases (F) per chunk
+  constexpr bool ZT = ZP >= 0 && CVC >= 2;
+  // volatile LDS pointers: every operand read stays a ds_read_b32 with an immediate offset
+  // (merged ds_read2 forms need a VALU address add per step, which costs MFMA issue time)
+  typedef const volatile __attribute__((address_space(3))) float* ldsp;
+  auto special = [](int i) { return ZT && (32 * i) / NPT == ZP; };
+  auto skipped = [&](int i, int s) { return special(i) && ((2 * s) % U) == 0; };
   float av0[NI], av1[NI], bv0[NBI][NJ], bv1[NBI][NJ];
   auto read_step = [&](int s, float (&av)[NI], float (&bv)[NBI][NJ]) {
     const int kk = 2 * s;
     const int c = kk / U, u = kk % U;
-    // volatile LDS pointers: every operand read stays a ds_read_b32 with an immediate offset
-    // (merged ds_read2 forms need a VALU address add per step, which costs MFMA issue time)
-    typedef const volatile __attribute__((address_space(3))) float* ldsp;
     ldsp wr = (ldsp)(Wl + kk * MB);
     ldsp ir = (ldsp)(Il + c * RLs + u);
 #pragma unroll
-    for (int i = 0; i < NI; ++i) av[i] = wr[aoff[i]];
+    for (int i = 0; i < NI; ++i)
+      if (!skipped(i, s)) av[i] = wr[aoff[i]];
 #pragma unroll
     for (int i = 0; i < NBI; ++i)
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) bv[i][j] = ir[boff[j] + (SHIFT ? rsh[i] : 0)];
+      for (int j = 0; j < NJ; ++j)
+        if (!(SHIFT && skipped(i, s))) bv[i][j] = ir[boff[j] + (SHIFT ? rsh[i] : 0)];
   };
-  auto mma_step = [&](const float (&av)[NI], const float (&bv)[NBI][NJ]) {
+  constexpr int NS = FMODE == 1 ? KC / 2 - 1 : KC / 2;
+  auto mma_step = [&](int s, const float (&av)[NI], float (&bv)[NBI][NJ]) {
+    if (FMODE == 2 && s == NS - 1) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) bv[0][j] = h ? b30[j] : bv[0][j];
+    }
 #pragma unroll
     for (int i = 0; i < NI; ++i)
 #pragma unroll
       for (int j = 0; j < NJ; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[SHIFT ? i : 0][j], acc[i][j],
-                                                         0, 0, 0);
+        if (!skipped(i, s))
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[SHIFT ? i : 0][j], acc[i][j],
+                                                           0, 0, 0);
   };
+  if (FMODE == 1) {
+    // row 30 = (phase S-1, tap U-2) of this channel, at the LOWER half's address in every lane
+    ldsp ir = (ldsp)(Il + (CVC - 1) * RLs + (U - 2));
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) b30[j] = ir[boff[j] - h];
+  }
+  // the merged steps of the T form's zero-tap phase: operands first, MFMAs after the pipeline's
+  // first two reads are in flight
+  float avx[ZT ? CVC / 2 : 1][NI], bvx[ZT ? CVC / 2 : 1][NBI][NJ];
+  if (ZT) {
+#pragma unroll
+    for (int p = 0; p < CVC / 2; ++p) {
+      ldsp wr = (ldsp)(Wl + (2 * p * U + 1) * MB);
+      ldsp ir = (ldsp)(Il + 2 * p * RLs + 1);
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+        if (special(i)) avx[p][i] = wr[aoffx[i]];
+#pragma unroll
+      for (int i = 0; i < NBI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          if (!SHIFT || special(i)) bvx[p][i][j] = ir[boffx[j] + (SHIFT ? rsh[i] : 0)];
+    }
+  }
   // operands are read TWO steps ahead of the MFMAs that use them (three register sets)
   float av2[NI], bv2[NBI][NJ];
-  constexpr int NS = KC / 2;
   read_step(0, av0, bv0);
   read_step(1, av1, bv1);
+  if (ZT) {
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int p = 0; p < CVC / 2; ++p)
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          if (special(i))
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(avx[p][i], bvx[p][SHIFT ? i : 0][j],
+                                                             acc[i][j], 0, 0, 0);
+  }
 #pragma unroll
   for (int s = 0; s < NS; s += 3) {
     if (s + 2 < NS) read_step(s + 2, av2, bv2);
     __builtin_amdgcn_sched_barrier(0);
-    mma_step(av0, bv0);
+    mma_step(s, av0, bv0);
     __builtin_amdgcn_sched_barrier(0);
     if (s + 3 < NS) read_step(s + 3, av0, bv0);
     __builtin_amdgcn_sched_barrier(0);
-    if (s + 1 < NS) mma_step(av1, bv1);
+    if (s + 1 < NS) mma_step(s + 1, av1, bv1);
     __builtin_amdgcn_sched_barrier(0);
     if (s + 4 < NS) read_step(s + 4, av1, bv1);
     __builtin_amdgcn_sched_barrier(0);
-    if (s + 2 < NS) mma_step(av2, bv2);
+    if (s + 2 < NS) mma_step(s + 2, av2, bv2);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -561,8 +627,14 @@ __global__ __launch_bounds__(256, 2) void corr_kernel(const CorrArgs a) {
     float* Wl = Wl0 + buf * (KC * MB);
     float* Il = Il0 + buf * (CV * RLs);
 #pragma unroll
-    for (int p = 0; p < NPASS; ++p)
+    for (int p = 0; p < NPASS; ++p) {
+      // f_pair packings keep the even partner's row-30 weights in row 31 of an odd channel (for
+      // corr2_kernel's merged step): this kernel runs the plain 16 steps, where that row is the
+      // zero tap
+      if (IN_HI && a.f_pair && ((ch * KC + wrow + RPP * p) & 63) == 63)
+        wreg[p] = f32x4{0.f, 0.f, 0.f, 0.f};
       *reinterpret_cast<f32x4*>(Wl + (wrow + RPP * p) * MB + 4 * wc4) = wreg[p];
+    }
 #pragma unroll
     for (int c = 0; c < CV; ++c) {
       const int cv = ch * CV + c;
@@ -580,6 +652,7 @@ __global__ __launch_bounds__(256, 2) void corr_kernel(const CorrArgs a) {
     }
   };
 
+  float b30_unused[NJ] = {};
   load_chunk(c0);
   store_chunk(c0, 0);
   __syncthreads();
@@ -587,7 +660,7 @@ __global__ __launch_bounds__(256, 2) void corr_kernel(const CorrArgs a) {
     const int buf = (ch - c0) & 1;
     if (ch + 1 < c1) load_chunk(ch + 1);
     corr_mma_chunk<MB, U, KC, NI, NJ, SHIFT>(Wl0 + buf * (KC * MB), Il0 + buf * (CV * RLs), RLs,
-                                             aoff, boff, rsh, acc);
+                                             aoff, boff, rsh, acc, b30_unused, h, aoff, boff);
     if (ch + 1 < c1) store_chunk(ch + 1, buf ^ 1);
     __syncthreads();
   }
@@ -615,13 +688,20 @@ __global__ __launch_bounds__(256, 2) void corr_kernel(const CorrArgs a) {
 // ====================================================================================
 #define CORR2_KC 32
 #define CORR2_NLD 4
+template <int V>
+struct IntC {
+  static constexpr int value = V;
+};
 
 __device__ __forceinline__ float buf_load_f32(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
 
 template <int MB, int NB, int WM, int U, bool IN_HI, bool OUT_HI, bool SHIFT, bool XF, bool BLK = false>
-__global__ __launch_bounds__(256, 2) void corr2_kernel(const CorrArgs a) {
+// F form: 4 waves per SIMD (<= 128 VGPRs; 4 workgroups of 40 KB LDS per CU) as before round 5 — the
+// pair loop needs 129-131 registers left alone; the T form (158-161) and the blocked-accumulation
+// variants (2 waves) keep the bound of two
+__global__ __launch_bounds__(256, (IN_HI && !BLK) ? 4 : 2) void corr2_kernel(const CorrArgs a) {
   using G = TileGeom<MB, NB, WM, U>;
   constexpr int S = G::S, WN = G::WN, NI = G::NI, NJ = G::NJ, NPT = G::NPT;
   constexpr int KC = CORR2_KC;
@@ -716,6 +796,16 @@ __global__ __launch_bounds__(256, 2) void corr2_kernel(const CorrArgs a) {
   }
   int col_b[NJ], col_t[NJ];
   lane_columns<NB, WN, NJ>(a, ct, wn, l31, h, col_b, col_t, boff);
+  // the 31-of-32-taps merges (corr_mma_chunk): operand offsets of the T form's merged steps,
+  // the carried row-30 activations of the F form's channel pairs (zero: no partner seen yet)
+  int aoffx[NI], boffx[NJ];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) aoffx[i] = aoff[i] + h * (U - 1) * MB;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) boffx[j] = boff[j] + h * (RLs - 1);
+  float b30[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) b30[j] = 0.0f;
 
   f32x16 acc[NI][NJ];
 #pragma unroll
@@ -788,21 +878,57 @@ __global__ __launch_bounds__(256, 2) void corr2_kernel(const CorrArgs a) {
   load_chunk(c0, 0);
   store_chunk(0);
   __syncthreads();
-  // BLK: blocks of SEGAN_ACC_BLOCK chunks; the inner loop is the plain MFMA pipeline, the block
-  // sum is folded into accs between blocks (nested loops keep the accumulators in place)
-  constexpr int CBLK = BLK ? SEGAN_ACC_BLOCK : (1 << 30);
-  for (int cb = c0; cb < c1; cb += CBLK) {
-    const int ce = BLK ? min(cb + CBLK, c1) : c1;
-    for (int ch = cb; ch < ce; ++ch) {
-      const int buf = (ch - c0) & 1;
-      if (ch + 1 < c1) load_chunk(ch + 1, buf ^ 1);
-      corr_mma_chunk<MB, U, KC, NI, NJ, SHIFT>(Wl0 + buf * (KC * MB), Il0 + buf * (CV * RLs), RLs,
-                                               aoff, boff, rsh, acc);
-      if (ch + 1 < c1) store_chunk(buf ^ 1);
-      __syncthreads();
+  // one chunk: the next chunk's loads go out, this one's MFMAs run, the next one's LDS stores follow.
+  // FM / ZP select the 31-of-32-taps merges of corr_mma_chunk at COMPILE time: the variants run in
+  // separate loops (or back to back inside one loop body), never behind a branch inside a loop — a
+  // branch between two unrolled MFMA bodies costs a second copy of the 64 accumulator registers
+  auto one_chunk = [&](auto fm, auto zp, int ch, auto sbuf) {
+    // sbuf: the LDS buffer when the caller knows it statically (the pair loop), else -1
+    int buf = decltype(sbuf)::value >= 0 ? decltype(sbuf)::value : (ch - c0) & 1;
+    // opaque to the optimiser: with two chunks in one loop body it would otherwise keep the LDS
+    // addresses of BOTH buffers in registers across the loop (+18 VGPRs: one wave per SIMD less)
+    // instead of re-deriving them per chunk with a few VALU adds like the one-chunk loop does
+    asm volatile("" : "+s"(buf));
+    if (ch + 1 < c1) load_chunk(ch + 1, buf ^ 1);
+    corr_mma_chunk<MB, U, KC, NI, NJ, SHIFT, decltype(fm)::value, decltype(zp)::value, NPT>(
+        Wl0 + buf * (KC * MB), Il0 + buf * (CV * RLs), RLs, aoff, boff, rsh, acc, b30, h, aoffx, boffx);
+    if (ch + 1 < c1) store_chunk(buf ^ 1);
+    __syncthreads();
+  };
+  using Plain = IntC<0>;
+  using NoZ = IntC<-1>;
+  if constexpr (BLK) {
+    // blocks of SEGAN_ACC_BLOCK chunks; the inner loop is the plain MFMA pipeline, the block sum is
+    // folded into accs between blocks (nested loops keep the accumulators in place)
+    for (int cb = c0; cb < c1; cb += SEGAN_ACC_BLOCK) {
+      const int ce = min(cb + SEGAN_ACC_BLOCK, c1);
+      for (int ch = cb; ch < ce; ++ch) one_chunk(Plain{}, NoZ{}, ch, NoZ{});
+      acc_block_flush<NI, NJ>(acc, accs);
     }
-    if constexpr (BLK) acc_block_flush<NI, NJ>(acc, accs);
-    else break;
+  } else if constexpr (IN_HI && !SHIFT) {
+    // F form.  K = 31 with paired channels (f_pair): every piece is whole pairs (even A, odd B) —
+    // the channel count is even and the launcher keeps the stream-K cuts on even chunks
+    if (a.f_pair) {
+      for (int ch = c0; ch < c1; ch += 2) {
+        one_chunk(IntC<1>{}, NoZ{}, ch, IntC<0>{});        // c0 is even: A in buffer 0, B in 1
+        one_chunk(IntC<2>{}, NoZ{}, ch + 1, IntC<1>{});
+      }
+    } else {
+      for (int ch = c0; ch < c1; ++ch) one_chunk(Plain{}, NoZ{}, ch, NoZ{});
+    }
+  } else if constexpr (OUT_HI && U == 8) {
+    // T form, stride 4.  K = 31: the output phase whose tap u' = 0 is the padding tap is 2 for the
+    // deconv forward (pad 13: the SHIFT variant) and 3 for the conv data gradient; any other
+    // geometry runs the plain steps.  (Stride 2 — phase 1 for both — is left alone: the merged
+    // steps cost the U = 16 variants 20 registers and with them the third wave per SIMD.)
+    constexpr int ZPK = SHIFT ? 2 : 3;
+    if (a.zphase == ZPK) {
+      for (int ch = c0; ch < c1; ++ch) one_chunk(Plain{}, IntC<ZPK>{}, ch, NoZ{});
+    } else {
+      for (int ch = c0; ch < c1; ++ch) one_chunk(Plain{}, NoZ{}, ch, NoZ{});
+    }
+  } else {
+    for (int ch = c0; ch < c1; ++ch) one_chunk(Plain{}, NoZ{}, ch, NoZ{});
   }
   if constexpr (BLK) {
 #pragma unroll
@@ -996,6 +1122,7 @@ __global__ __launch_bounds__(256, 2) void conv_dgrad_short_kernel(const ShortArg
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
   const int nch = a.M / KC;
+  float b30_unused[NJ] = {};
   load_chunk(0, 0);
   __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0): the DMA of chunk 0 has landed
   __syncthreads();
@@ -1003,7 +1130,7 @@ __global__ __launch_bounds__(256, 2) void conv_dgrad_short_kernel(const ShortArg
     const int buf = ch & 1;
     if (ch + 1 < nch) load_chunk(ch + 1, buf ^ 1);
     corr_mma_chunk<MB, 1, KC, NI, NJ, false>(Wl0 + buf * (KC * MB), Il0 + buf * (KC * NB), NB, aoff,
-                                             boff, rsh, acc);
+                                             boff, rsh, acc, b30_unused, h, aoff, boff);
     __builtin_amdgcn_s_waitcnt(0x0f70);
     __syncthreads();
   }
@@ -1138,6 +1265,9 @@ static unsigned plan_streamk(CorrArgs& a, int ntiles, int nch, int occ, size_t s
   if (rem == 0) return (unsigned)ntiles;
   a.sk_total = (long)rem * nch;
   a.sk_units = (int)((a.sk_total + G - 1) / G);
+  // paired channels (f_pair: nch = the even channel count): cuts on even chunks only, so that
+  // every piece is whole (A, B) pairs
+  if (a.f_pair) a.sk_units += a.sk_units & 1;
   return (unsigned)G;
 }
 
@@ -1373,6 +1503,7 @@ extern "C" int segan_conv1d_fwd(const segan_src* x, const void* wf, const float*
   a.NP = 1; a.Nout = 0;
   a.OC0 = M; a.OC1 = 0; a.Lout = a.Tcols; a.act = SEGAN_ACT_NONE;
   a.out0_elems = (size_t)B * M * a.Tcols;
+  a.f_pair = f_pair(N, K); a.zphase = -1;
   if (precision) {
     CorrArgs a2 = a;
     const int e = segan_corr_bf2_f(a2, U, wf, precision, scratch, scratch_bytes, (hipStream_t)stream);
@@ -1413,6 +1544,7 @@ extern "C" int segan_deconv1d_dgrad(const float* dy, const void* wf, float* dx0,
   a.Lout = Ls; a.act = SEGAN_ACT_NONE;
   a.out0_elems = (size_t)B * a.OC0 * Ls;
   a.out1_elems = (size_t)B * a.OC1 * Ls;
+  a.f_pair = f_pair(N, K); a.zphase = -1;
   if (precision) {
     CorrArgs a2 = a;
     const int e = segan_corr_bf2_f(a2, U, wf, precision, scratch, scratch_bytes, (hipStream_t)stream);
@@ -1459,6 +1591,7 @@ extern "C" int segan_deconv1d_fwd(const segan_src* x, const void* wt, const floa
   a.OC0 = N; a.OC1 = 0; a.Lout = S * Ls; a.act = act;
   a.o_padL = 0; a.o_roll = 0; a.o_padR = 0;
   a.out0_elems = (size_t)B * N * S * Ls;
+  a.f_pair = 0; a.zphase = t_zphase(K, S, pad);
   if (w && N <= 2) return segan_launch_tsmall(a, w, K, M, N, S, pad, (hipStream_t)stream);
   if (precision && act == SEGAN_ACT_NONE) {
     CorrArgs a2 = a;
@@ -1509,6 +1642,7 @@ extern "C" int segan_conv1d_dgrad(const float* da, const void* wt, const float* 
   a.o_padL = padL; a.o_roll = roll; a.o_padR = padR;
   a.out0_elems = (size_t)B * N * L;
   a.halo_elems = (size_t)B * N * (padL + padR);
+  a.f_pair = 0; a.zphase = t_zphase(K, S, 0);      // the conv's Wt is packed for pad_t = 0
   set_scratch(a, scratch, scratch_bytes);
   int e;
   if (w && N <= 2) {

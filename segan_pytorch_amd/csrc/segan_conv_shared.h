@@ -81,6 +81,8 @@ struct CorrArgs {
   int xf_mode;                 // input transform: 0 identity, 1 scale / slope (a zero stays zero), 2 with a shift
   int acc_block;               // fp32: blocked accumulation (SEGAN_PREC_FP32_BLOCKED; segan_common.h)
   int RLv, nld;                // corr2: valid window positions (RLs is the padded row), loads per lane
+  int f_pair;                  // F form, K = 31: the packing pairs the channels (f_pair() below)
+  int zphase;                  // T form, K = 31: the output phase whose tap u' = 0 is the zero tap, else -1
 };
 
 // (*) 16-byte buffer stores take their row offset in the VECTOR offset, never in an SGPR soffset.
@@ -135,6 +137,17 @@ static inline int t_pitch(int N, int S) { return S * t_np(N, S); }
 static inline int t_rows(int M, int S) { return round_up(M * (32 / S), KCH); }
 
 // argument checks shared by the C-ABI translation units
+// F form with K = 31 taps: the 32nd (padding) row of every ODD input channel of the packed
+// weights holds row 30 of its even partner, so that the contraction kernel can merge the two
+// half-empty MFMA steps of a channel pair into one (corr_mma_chunk in segan_conv.hip).  Decided by
+// (N, K) alone: the packing and every consumer of the packed buffer agree by construction.
+static inline int f_pair(int N, int K) { return K == 31 && N > 2 && (N & 1) == 0; }
+// T form with K = 31 taps packed for padding `pad_t`: output phase r reads tap S*(U-1-u') + rho(r),
+// rho = (r + pad_t) % S, so u' = 0 is the padding tap k = 31 for the phase with rho = S - 1.
+static inline int t_zphase(int K, int S, int pad_t) {
+  return (K == 31 && S > 1) ? (((S - 1 - pad_t) % S) + S) % S : -1;
+}
+
 static inline bool stride_ok(int S) { return S == 1 || S == 2 || S == 4; }
 static inline bool precision_ok(int p) { return p == 0 || p == 1 || p == 3; }
 static inline int check_src(const segan_src* s, int C, const char* what) {

@@ -11,7 +11,7 @@
 // coalesced.  grid.x = tiles of 64 along the transposed axis, grid.y = the other axis.
 __global__ __launch_bounds__(256) void pack_f_kernel(const float* __restrict__ w,
                                                      float* __restrict__ wf, int M, int N, int K,
-                                                     int S, int U, int pitch, int rows) {
+                                                     int S, int U, int pitch, int rows, int pair) {
   __shared__ float t[64][33];
   const int n = blockIdx.y;                 // may run past N into the zero padding rows
   const int m0 = blockIdx.x * 64;
@@ -20,6 +20,13 @@ __global__ __launch_bounds__(256) void pack_f_kernel(const float* __restrict__ w
     const int ml = e >> 5, k = e & 31;
     const int m = m0 + ml;
     t[ml][k] = (m < M && n < N && k < K) ? w[((size_t)m * N + n) * K + k] : 0.0f;
+  }
+  // f_pair (K = 31): row 31 = (r, u) = (S-1, U-1), the padding tap k = 31, of an ODD channel
+  // holds row 30 = (S-1, U-2), i.e. tap k = 31 - S, of its even partner n - 1 (segan_conv_shared.h)
+  __syncthreads();
+  if (pair && (n & 1) && n < N && tid < 64) {
+    const int m = m0 + tid;
+    t[tid][31] = m < M ? w[((size_t)m * N + n - 1) * K + (31 - S)] : 0.0f;
   }
   __syncthreads();
   for (int e = tid; e < 32 * 64; e += 256) {
@@ -80,7 +87,7 @@ extern "C" int segan_pack_weights(const float* w, float* wf, float* wt, int M, i
     const int pitch = f_pitch(M), rows = f_rows(N);
     // rows = round_up(N*32, 64): cover the padding rows with one extra n when N is odd
     hipLaunchKernelGGL(pack_f_kernel, dim3(pitch / 64, ceil_div(rows, 32)), dim3(256), 0, st, w,
-                       wf, M, N, K, S, U, pitch, rows);
+                       wf, M, N, K, S, U, pitch, rows, f_pair(N, K));
   }
   if (wt) {
     const int NP = t_np(N, S);

@@ -50,8 +50,20 @@ def deconv_pad(K, S):
     return max(0, (S - K) // -2)
 
 
-def pack_f(w, S):
-    """[m, n, K] -> Wf[(n, r), u, m]  with Wf = w[m, n, S*u + r] (0 past K)."""
+def f_pair(N, K):
+    """Does the F packing of an [m, N, K] weight pair its channels?  (segan_conv_shared.h)"""
+    return K == 31 and N > 2 and N % 2 == 0
+
+
+def pack_f(w, S, pair=None):
+    """[m, n, K] -> Wf[(n, r), u, m]  with Wf = w[m, n, S*u + r] (0 past K).
+
+    K = 31 (`f_pair`): the 32nd row of a channel — (r, u) = (S-1, U-1), the padding tap k = 31 —
+    multiplies zeros, half of one two-row MFMA.  For every ODD channel n that row holds row 30
+    = (S-1, U-2), i.e. tap k = 31 - S, of the even partner n - 1 instead: the contraction kernel
+    runs 15 two-row steps on the even channel, 16 on the odd one, and the odd channel's last
+    step contracts (its own row 30, the partner's row 30) — against the partner's row-30
+    activations in the upper half (`corr_f` below restates that schedule)."""
     w = np.asarray(w)
     M, N, K = w.shape
     U = taps_per_phase(S)
@@ -61,6 +73,8 @@ def pack_f(w, S):
             k = S * u + r
             if k < K:
                 out[r::S, u, :] = w[:, :, k].T        # row index n*S + r
+    if f_pair(N, K) if pair is None else pair:
+        out[2 * S - 1::2 * S, U - 1, :] = w[:, 0::2, 31 - S].T     # rows (odd n, S-1), tap slot U-1
     return out
 
 
@@ -135,10 +149,31 @@ def corr_f(x, w, S, padL, mode, roll=0):
     X = hi_phases(x, S, padL, mode, roll, Ls + U - 1)
     Wf = pack_f(w, S)                     # [(n,r), u, m]
     out = np.zeros((B, M, Ls), dtype=np.float64)
-    for u in range(U):
-        # [B, CV, Ls] x [CV, M]
-        out += np.einsum('bct,cm->bmt', X[:, :, u:u + Ls].astype(np.float64),
-                         Wf[:, u, :].astype(np.float64))
+    if not f_pair(N, w.shape[2]):
+        for u in range(U):
+            # [B, CV, Ls] x [CV, M]
+            out += np.einsum('bct,cm->bmt', X[:, :, u:u + Ls].astype(np.float64),
+                             Wf[:, u, :].astype(np.float64))
+        return out
+    # the paired schedule of corr2_kernel: rows (r, u) of a channel in order, two per step
+    Xd, Wd = X.astype(np.float64), Wf.astype(np.float64)
+    rows = [(r, u) for r in range(S) for u in range(U)]          # row 30 = (S-1, U-2), 31 = (S-1, U-1)
+
+    def row(n, i, xn=None):
+        r, u = rows[i]
+        xs = Xd[:, (n if xn is None else xn) * S + r, u:u + Ls]           # [B, Ls]
+        return np.einsum('bt,m->bmt', xs, Wd[n * S + r, u, :])
+
+    for a in range(0, N, 2):
+        b = a + 1
+        for i in range(30):                       # chunk A: 15 steps, row 30 deferred
+            out += row(a, i)
+        for i in range(31):                       # chunk B: rows 0 .. 30 ...
+            out += row(b, i)
+        # ... and the upper half of its last step: B's row 31 (= A's row-30 weights) against
+        # A's row-30 activations
+        r30, u30 = rows[30]
+        out += np.einsum('bt,m->bmt', Xd[:, a * S + r30, u30:u30 + Ls], Wd[b * S + S - 1, U - 1, :])
     return out
 
 

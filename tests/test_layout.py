@@ -53,6 +53,37 @@ def test_deconv_forms(S, K):
     assert np.abs(lay.wgrad(x, dy, S, K, pad, lay.PAD_ZERO) - wt.grad.numpy()).max() < 1e-12
 
 
+@pytest.mark.parametrize('S', [4, 2, 1])
+def test_paired_f_packing_of_31_taps(S):
+    """K = 31, an even number (> 2) of contraction channels: the F packing stores the even
+    channel's row-30 weights in the zero-tap row of its odd partner and the contraction runs the
+    paired schedule (15 + 16 two-row steps per channel pair instead of 16 + 16; layout.corr_f
+    restates what corr2_kernel does).  Same results as torch for the conv forward and the deconv
+    data gradient; the packed buffer differs from the plain one in exactly those rows."""
+    rng = np.random.default_rng(2)
+    B, N, M, L, K = 2, 6, 5, 64, 31
+    assert lay.f_pair(N, K) and not lay.f_pair(3, K) and not lay.f_pair(2, K) and not lay.f_pair(N, 32)
+    x = rng.standard_normal((B, N, L))
+    w = rng.standard_normal((M, N, K))
+    pl, pr = lay.conv_pad(K, S)
+    a = F.conv1d(F.pad(torch.tensor(x), (pl, pr), mode='reflect'), torch.tensor(w), stride=S)
+    assert np.abs(lay.corr_f(x, w, S, pl, lay.PAD_REFLECT, 0) - a.numpy()).max() < 1e-12
+    U = lay.taps_per_phase(S)
+    plain, paired = lay.pack_f(w, S, pair=False), lay.pack_f(w, S)
+    diff = np.argwhere(np.abs(plain - paired).max(axis=2) > 0)
+    assert sorted(map(tuple, diff)) == [((2 * p + 1) * S + S - 1, U - 1) for p in range(N // 2)]
+    assert np.array_equal(paired[S + S - 1, U - 1], w[:, 0, 31 - S])      # channel 1 <- channel 0's row 30
+    # deconv data gradient: the F form over the deconv's OUTPUT channels
+    Mi, No, Ls = 3, 4, 16
+    xd = torch.tensor(rng.standard_normal((B, Mi, Ls)), requires_grad=True)
+    wd = rng.standard_normal((Mi, No, K))
+    pad = lay.deconv_pad(K, S)
+    y = F.conv_transpose1d(xd, torch.tensor(wd), stride=S, padding=pad)[:, :, :S * Ls]
+    dy = rng.standard_normal(tuple(y.shape))
+    y.backward(torch.tensor(dy))
+    assert np.abs(lay.corr_f(dy, wd, S, pad, lay.PAD_ZERO, 0) - xd.grad.numpy()).max() < 1e-12
+
+
 def test_hi_index_matches_reflect_and_roll():
     L, padL, padR = 20, 14, 15
     x = torch.arange(L, dtype=torch.float64).view(1, 1, L)

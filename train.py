@@ -104,6 +104,16 @@ FLAGS = [
                         help='draw the generator\'s z on the GPU (per-rank generator) instead of on the '
                              'host like the reference (generator.py:197): no host randn + copy per step, '
                              'but not the reference\'s RNG stream')),
+    ('--precision', dict(type=str, default=None, choices=['fp32', 'bf16x3', 'bf16'],
+                         help='contraction precision of the conv / deconv kernels (default: $SEGAN_PRECISION '
+                              'or fp32 = exact fp32 MFMA).  bf16 = mixed precision on the bf16 matrix cores '
+                              '(BASELINE config 5: bf16 operands, fp32 accumulation, everything else fp32; '
+                              'tolerances in DESIGN.md section 6); bf16x3 = fp32 operands split exactly into '
+                              '3 bf16 planes (fp32-class results).  With bf16 z is drawn on the GPU by default '
+                              '(--device_z): a step takes about as long as the single-threaded host randn of '
+                              'one z, so the host draw would be the critical path; --host_z keeps it')),
+    ('--host_z', dict(action='store_true', default=False,
+                      help='with --precision bf16: draw z on the host like the reference anyway')),
     ('--no_prefetch_z', dict(action='store_true', default=False,
                              help='draw every z inside its own step instead of one step ahead on a host '
                                   'thread (same numbers either way as long as nothing else takes from torch\'s global CPU '
@@ -147,6 +157,11 @@ def main(opts):
         raise NotImplementedError('AEWSEGAN is broken in the reference (model.py:823) and is '
                                   'not implemented')
     segan = (WSEGAN if opts.wsegan else SEGAN)(opts)
+    from segan_pytorch_amd import ops as _sops
+    if getattr(opts, 'precision', None):
+        _sops.set_precision(opts.precision)
+    if _sops.get_precision() == 'bf16' and not getattr(opts, 'host_z', False):
+        opts.device_z = True
     if getattr(opts, 'device_z', False):
         segan.G.z_generator = torch.Generator(device=device).manual_seed(opts.seed + rank)
     opts.prefetch_z = not getattr(opts, 'no_prefetch_z', False)
