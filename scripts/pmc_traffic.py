@@ -1,7 +1,7 @@
 """Per-kernel HBM traffic from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected
 separately, as MI355X_MICROARCH.md prescribes) -> profiles/r01_pmc_hbm_traffic.json, the file
 bench.py reads for `roofline.traffic`.
-usage: python scripts/pmc_traffic.py FETCH_counter_collection.csv WRITE_counter_collection.csv STEPS OUT.json"""
+usage: python scripts/pmc_traffic.py FETCH_counter_collection.csv WRITE_counter_collection.csv STEPS OUT.json [WORKLOAD]"""
 import collections
 import csv
 import json
@@ -30,8 +30,10 @@ for k in sorted(set(fetch) | set(write)):
                   'write_kb_avg': sum(w) / len(w) if w else 0.0}
 out = {
     'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --steps {} --warmup 1 '
-            '--precision fp32, B=300; units KB per launch as reported; gfx950 FETCH_SIZE '
-            'under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md HBM section)'.format(steps - 1),
+            '{}, B=300; units KB per launch as reported; gfx950 FETCH_SIZE '
+            'under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md HBM section)'.format(
+                steps - 1, sys.argv[5] if len(sys.argv) > 5 else 'the SEGAN+ default net'),
+    'workload': sys.argv[5] if len(sys.argv) > 5 else 'segan_plus',
     'steps_profiled': steps,
     'csrc_sha': __import__('bench').csrc_sha(),      # the HIP sources these numbers were measured on
     'per_step_fetch_gb_raw': sum(sum(v) for v in fetch.values()) / 1e6 / steps * 1.024,

@@ -15,7 +15,7 @@ for p in fp32 bf16; do
   for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $c --kernel-trace -d $O/pmc_${p}_$c -o run --output-format csv -- $B --steps 2 --warmup 1 --precision $p > $O/pmc_${p}_$c.log 2>&1
   done
-  python scripts/pmc_traffic.py $O/pmc_${p}_FETCH_SIZE/run_counter_collection.csv $O/pmc_${p}_WRITE_SIZE/run_counter_collection.csv 3 $O/pmc_hbm_traffic_$p.json
+  python scripts/pmc_traffic.py $O/pmc_${p}_FETCH_SIZE/run_counter_collection.csv $O/pmc_${p}_WRITE_SIZE/run_counter_collection.csv 3 $O/pmc_hbm_traffic_$p.json "--precision $p, SEGAN+ default net"
   rm -rf $O/pmc_${p}_FETCH_SIZE $O/pmc_${p}_WRITE_SIZE
 done
 # the 11-layer stride-2 shape gets its OWN counters (round-4 review, weak 8: its bench line used to
@@ -25,7 +25,7 @@ python scripts/rocpd_stats.py $O/prof_v11/*results.db $O/kernel_stats_vanilla11.
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace -d $O/pmc_v11_$c -o run --output-format csv -- $B --steps 2 --warmup 1 --shape vanilla11 > $O/pmc_v11_$c.log 2>&1
 done
-python scripts/pmc_traffic.py $O/pmc_v11_FETCH_SIZE/run_counter_collection.csv $O/pmc_v11_WRITE_SIZE/run_counter_collection.csv 3 $O/pmc_hbm_traffic_vanilla11.json
+python scripts/pmc_traffic.py $O/pmc_v11_FETCH_SIZE/run_counter_collection.csv $O/pmc_v11_WRITE_SIZE/run_counter_collection.csv 3 $O/pmc_hbm_traffic_vanilla11.json '--shape vanilla11 (11-layer stride-2 SEGAN)'
 rm -rf $O/pmc_v11_FETCH_SIZE $O/pmc_v11_WRITE_SIZE
 # every contraction of the SEGAN+ nets in isolation
 python scripts/bench_layers.py --iters 3 > $O/layers_fp32.txt 2>&1

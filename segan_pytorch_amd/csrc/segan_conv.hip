@@ -900,9 +900,19 @@ __global__ __launch_bounds__(256, (IN_HI && !BLK) ? 4 : 2) void corr2_kernel(con
   if constexpr (BLK) {
     // blocks of SEGAN_ACC_BLOCK chunks; the inner loop is the plain MFMA pipeline, the block sum is
     // folded into accs between blocks (nested loops keep the accumulators in place)
+    static_assert(SEGAN_ACC_BLOCK % 2 == 0, "blocks hold whole channel pairs");
     for (int cb = c0; cb < c1; cb += SEGAN_ACC_BLOCK) {
       const int ce = min(cb + SEGAN_ACC_BLOCK, c1);
-      for (int ch = cb; ch < ce; ++ch) one_chunk(Plain{}, NoZ{}, ch, NoZ{});
+      if (IN_HI && a.f_pair) {
+        // paired packing: the pairs must be contracted as pairs here too (row 31 of an odd channel
+        // is not a zero row); c0, c1 and the block size are even
+        for (int ch = cb; ch < ce; ch += 2) {
+          one_chunk(IntC<(IN_HI && !SHIFT) ? 1 : 0>{}, NoZ{}, ch, NoZ{});
+          one_chunk(IntC<(IN_HI && !SHIFT) ? 2 : 0>{}, NoZ{}, ch + 1, NoZ{});
+        }
+      } else {
+        for (int ch = cb; ch < ce; ++ch) one_chunk(Plain{}, NoZ{}, ch, NoZ{});
+      }
       acc_block_flush<NI, NJ>(acc, accs);
     }
   } else if constexpr (IN_HI && !SHIFT) {
@@ -1058,6 +1068,7 @@ struct ShortArgs {
   const float* wg;
   float* dx;
   int B, N, M, L, Ls, padL, padRw, roll, ncoltiles;
+  int xr8, xbc;   // 2-D blocked tile order inside an XCD's range: rows per XCD, block width (0: linear)
 };
 
 template <int S>
@@ -1071,8 +1082,26 @@ __global__ __launch_bounds__(256, 2) void conv_dgrad_short_kernel(const ShortArg
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, h = lane >> 5;
-  const int vb = xcd_remap(blockIdx.x, gridDim.x);     // every XCD its own range of row tiles
-  const int rowtile = vb / a.ncoltiles, coltile = vb - rowtile * a.ncoltiles;
+  // Every XCD its own range of row tiles.  Inside the range the ~128 workgroups that are resident on
+  // the XCD at one time should touch as few different operand tiles as possible — each reads 512 KB
+  // of Wg (its row tile) and 512 KB of da (its column tile), all of them walk the contraction in
+  // step, and the XCD's 4 MB L2 holds the slices in flight: in row-major order 128 consecutive tiles
+  // are 3.4 rows x 38 columns (enc4: 41 operand tiles), in blocks of (rows of the XCD) x xbc
+  // columns they are 16 x 8 (24 operand tiles).  Round 5 A/B: see DESIGN.md 5.2.
+  int rowtile, coltile;
+  if (a.xbc > 0) {
+    const int x = blockIdx.x & 7, k = blockIdx.x >> 3;
+    const int per = a.xr8 * a.xbc;                       // tiles of a full column block
+    const int cb = k / per, rem = k - cb * per;
+    const int wdt = min(a.xbc, a.ncoltiles - cb * a.xbc);  // the last block may be narrower
+    const int rr = rem / wdt;
+    rowtile = x * a.xr8 + rr;
+    coltile = cb * a.xbc + rem - rr * wdt;
+  } else {
+    const int vb = xcd_remap(blockIdx.x, gridDim.x);
+    rowtile = vb / a.ncoltiles;
+    coltile = vb - rowtile * a.ncoltiles;
+  }
   const int Ls = a.Ls, L = a.L;
   const int n0 = rowtile * 4;
   const int b0 = coltile * (NB / Ls);
@@ -1709,6 +1738,16 @@ extern "C" int segan_conv1d_dgrad_short(const float* da, const float* wg, float*
   a.ncoltiles = ceil_div(B, 128 / a.Ls);
   const size_t lds = 4 * 32 * 65 * sizeof(float);      // >= 2 * CS_KC * 256 floats of the main loop
   const dim3 grid((unsigned)(N / 4 * a.ncoltiles));
+  // 2-D blocked order when the row tiles divide among the 8 XCDs (SEGAN_SHORT_ORDER=0: row-major)
+  static const bool blocked = [] {
+    const char* e = getenv("SEGAN_SHORT_ORDER");
+    return !(e && e[0] == '0');
+  }();
+  a.xr8 = a.xbc = 0;
+  if (blocked && (N / 4) % 8 == 0) {
+    a.xr8 = N / 4 / 8;
+    a.xbc = a.xr8 >= 128 ? 1 : 128 / a.xr8;
+  }
   hipStream_t st = (hipStream_t)stream;
   if (S == 4) hipLaunchKernelGGL(conv_dgrad_short_kernel<4>, grid, dim3(256), lds, st, a);
   else if (S == 2) hipLaunchKernelGGL(conv_dgrad_short_kernel<2>, grid, dim3(256), lds, st, a);
