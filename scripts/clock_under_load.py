@@ -19,6 +19,8 @@ lib = ctypes.CDLL(so)
 lib.clock_probe_launch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
 dev = 'cuda'
 B, K, S = 300, 31, 4
+PREC = ops.get_precision()          # SEGAN_PRECISION=bf16: the bf16 contractions against the 2.5 PF dense peak
+PEAK = 2500.0 if PREC == 'bf16' else 2500.0 / 6 if PREC == 'bf16x3' else 157.3
 side = torch.cuda.Stream()
 
 
@@ -46,8 +48,9 @@ def probe(fn, reps, what, flops):
             'clock_mhz_loaded_median': float(mhz[lo:hi].median()),
             'clock_mhz_loaded_min': float(mhz[lo:hi].min()), 'clock_mhz_loaded_max': float(mhz[lo:hi].max()),
             'clock_mhz_idle_head': float(mhz[:20].median()),
-            'fp32_mfma_peak_at_loaded_clock_tflops': 157.3 * float(mhz[lo:hi].median()) / 2400.0,
-            'frac_of_peak_at_loaded_clock': flops / ms / 1e9 / (157.3 * float(mhz[lo:hi].median()) / 2400.0)}
+            'mfma_peak_at_loaded_clock_tflops': PEAK * float(mhz[lo:hi].median()) / 2400.0,
+            'frac_of_nominal_peak': flops / ms / 1e9 / PEAK,
+            'frac_of_peak_at_loaded_clock': flops / ms / 1e9 / (PEAK * float(mhz[lo:hi].median()) / 2400.0)}
 
 
 rows = []
@@ -64,4 +67,6 @@ x = torch.randn(B, M, Ls, device=dev); w = torch.randn(M, N, K, device=dev) * 0.
 b = torch.zeros(N, device=dev); pk = ops.WeightPack(); src = ops.Src(x)
 rows.append(probe(lambda: ops.deconv1d_fwd(src, w, b, S, pack=pk), 12, 'dec2 deconv fwd (T form)', 2.0 * B * M * N * K * Ls))
 print(json.dumps({'note': 'shader clock sampled by a one-wave probe kernel on a side stream while the kernel under '
-                          'test runs back to back (B=300, fp32)', 'rows': rows}, indent=1))
+                          'test runs back to back (B=300, precision {}; bf16 rows include the packing pass of the entry '
+                          'point, so the clock is that of the contraction kernel but the rate is the entry point\'s)'.format(PREC),
+                  'precision': PREC, 'nominal_peak_tflops': PEAK, 'rows': rows}, indent=1))

@@ -31,6 +31,13 @@ for layer in layers:
         wc = c.get('SQ_WAVE_CYCLES', 0.0) or 1.0
         res.setdefault(layer, {})[k] = {
             'launches': n[(k, 'SQ_WAVE_CYCLES')],
+            # issued matrix work per launch: every v_mfma_f32_32x32x16_bf16 is 32768 FLOP, every
+            # v_mfma_f32_32x32x2_f32 4096 — against the layer's useful FLOPs (bench_layers: enc2
+            # 156.03 GFLOP, dec2 312.06 GFLOP per call) this is the share of the issued matrix work
+            # that is padding (the 32nd tap, halo columns, edge tiles)
+            'mfma_insts_per_launch': mf / max(1, n[(k, 'SQ_INSTS_MFMA')]),
+            'mfma_gflop_issued_per_launch': mf / max(1, n[(k, 'SQ_INSTS_MFMA')]) *
+                                            (32768 if 'bf' in k else 4096) / 1e9,
             'mfma_busy_cycles_over_4x_busy_cycles': c.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / (4.0 * (c.get('SQ_BUSY_CYCLES', 0) or 1.0)),
             'valu_per_mfma': c.get('SQ_INSTS_VALU', 0) / mf,
             'lds_per_mfma': c.get('SQ_INSTS_LDS', 0) / mf,
