@@ -778,34 +778,63 @@ class ConvBlockFn(torch.autograd.Function):
 
 
 class DeconvBlockFn(torch.autograd.Function):
-    """h = GDeconv1DBlock(x): transposed conv, trim, PReLU or Tanh."""
+    """h = GDeconv1DBlock(x): transposed conv, trim, (BatchNorm,) PReLU or Tanh
+    (modules.py:135-141)."""
 
     @staticmethod
     def forward(ctx, blk, x, *params):
         x = x.contiguous()
         src = Src(x)
-        act = ACT_TANH if blk.is_tanh else ACT_NONE
         W = _Weights()
-        a = ops.deconv1d_fwd(src, W.get(blk.deconv), blk.deconv.bias, blk.stride, act,
+        bn = blk.norm if isinstance(blk.norm, torch.nn.BatchNorm1d) else None
+        # with a BatchNorm between the deconv and the activation the tanh cannot ride in the
+        # contraction's epilogue: c, then bn(c) through tanh / PReLU in one pointwise pass
+        act = ACT_TANH if (blk.is_tanh and bn is None) else ACT_NONE
+        c = ops.deconv1d_fwd(src, W.get(blk.deconv), blk.deconv.bias, blk.stride, act,
                              pack=blk._pack)
-        h = a if blk.is_tanh else ops.affine_prelu(a, slope=blk.act.weight)
+        bn_saved = None
+        if bn is None:
+            h = c if blk.is_tanh else ops.affine_prelu(c, slope=blk.act.weight)
+        else:
+            if blk.training:
+                mean, rstd, scale, shift = _bn_train_stats(c, bn)
+                if bn.num_batches_tracked is not None:
+                    bn.num_batches_tracked += 1
+                bn_saved = (mean, rstd, bn.weight, bn.bias)
+            else:
+                rstd = torch.rsqrt(bn.running_var + bn.eps)
+                scale = (bn.weight.detach() * rstd).contiguous()
+                shift = (bn.bias.detach() - bn.running_mean * scale).contiguous()
+                bn_saved = 'eval'
+            h = ops.affine_tanh(c, scale, shift) if blk.is_tanh else \
+                ops.affine_prelu(c, scale, shift, blk.act.weight)
         ctx.blk = blk
         ctx.x_needs = x.requires_grad
-        ctx.state = (src, a, W)
+        ctx.state = (src, c, h if (blk.is_tanh and bn is not None) else None, bn_saved, W)
         return h
 
     @staticmethod
     def backward(ctx, dh):
         blk = ctx.blk
-        src, a, W = ctx.state
+        src, c, y, bn, W = ctx.state
         K, S = blk.kwidth, blk.stride
         w = W.get(blk.deconv)
         dh = dh.contiguous()
+        if bn == 'eval':
+            raise RuntimeError('GDeconv1DBlock backward with BatchNorm in eval() is unsupported')
+        bnm = blk.norm if bn is not None else None
         if blk.is_tanh:
-            da = ops.tanh_bwd(a, dh, dbias=_gb(blk.deconv.bias))
-        else:
-            da = ops.act_bwd(a, dh, slope=blk.act.weight, dslope=_gb(blk.act.weight),
+            if bn is None:
+                da = ops.tanh_bwd(c, dh, dbias=_gb(blk.deconv.bias))
+            else:       # y = tanh(bn(c)): through the Tanh, then through the BatchNorm
+                da = _act_bwd_bn(c, ops.tanh_bwd(y, dh), None, bn, None, _gb(bnm.weight),
+                                 _gb(bnm.bias), _gb(blk.deconv.bias))
+        elif bn is None:
+            da = ops.act_bwd(c, dh, slope=blk.act.weight, dslope=_gb(blk.act.weight),
                              dbias=_gb(blk.deconv.bias))
+        else:
+            da = _act_bwd_bn(c, dh, blk.act.weight, bn, _gb(blk.act.weight), _gb(bnm.weight),
+                             _gb(bnm.bias), _gb(blk.deconv.bias))
         if W.needs_grad(blk.deconv):
             gw = W.grad_target(blk.deconv)
             ops.wgrad(src, Src(da), gw, K, S, ops.deconv_pad(K, S), PAD_ZERO)

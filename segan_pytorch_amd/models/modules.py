@@ -97,9 +97,5 @@ class GDeconv1DBlock(nn.Module):
         if x.dim() != 3 or x.shape[1] != self.deconv.in_channels:
             raise ValueError('expected input [B, {}, L], got {}'.format(
                 self.deconv.in_channels, tuple(x.shape)))
-        if isinstance(self.norm, nn.BatchNorm1d):
-            raise NotImplementedError('a GDeconv1DBlock with BatchNorm runs inside the Generator '
-                                      '(functional.GeneratorFn); the stand-alone call is not '
-                                      'implemented')
         params = [p for p in self.parameters()]
         return Fn.DeconvBlockFn.apply(self, x, *params)

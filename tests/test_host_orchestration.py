@@ -178,6 +178,40 @@ def test_blocks_standalone(tiny_step):
                     4).square().sum().backward()
     assert max_rel(xqg.grad, xqd.grad) < 1e-4
     assert max_rel(db.deconv.weight.grad, sd['deconv.weight'].grad) < 1e-4
+    # deconv block WITH BatchNorm, stand-alone (modules.py:109-141 with norm_type='bnorm'): PReLU and
+    # Tanh flavours — the Tanh cannot ride in the contraction's epilogue behind a BatchNorm
+    for act in (None, 'Tanh'):
+        torch.manual_seed(11)
+        dbn = GDeconv1DBlock(10, 4, 31, stride=4, norm_type='bnorm', act=act)
+        if act is None:
+            dbn.act.weight.data.uniform_(0.1, 0.3)
+        dbn.norm.weight.data.uniform_(0.5, 1.5)
+        dbn.norm.bias.data.uniform_(-0.2, 0.2)
+        xb = torch.randn(3, 10, 32)
+        xbg = xb.clone().requires_grad_(True)
+        cw = torch.randn(3, 4, 128)
+        yb = dbn(xbg)
+        (yb * cw).sum().backward()
+        sd = {k: v.detach().double() for k, v in dbn.state_dict().items()}
+        keys = ['deconv.weight', 'deconv.bias', 'norm.weight', 'norm.bias'] + (['act.weight'] if act is None else [])
+        for k in keys:
+            sd[k].requires_grad_(True)
+        bn = {'weight': sd['norm.weight'], 'bias': sd['norm.bias'],
+              'running_mean': torch.zeros(4, dtype=torch.float64),
+              'running_var': torch.ones(4, dtype=torch.float64)}
+        xbd = xb.detach().double().requires_grad_(True)
+        yr = O.gdeconv_block(xbd, sd['deconv.weight'], sd['deconv.bias'], sd.get('act.weight'), 4,
+                             tanh=act is not None, bn=bn)
+        (yr * cw.double()).sum().backward()
+        assert max_rel(yb, yr) < 2e-5, act
+        assert max_rel(xbg.grad, xbd.grad) < 1e-4, act
+        for k in keys:
+            if k == 'deconv.bias':
+                continue        # cancelled by the BatchNorm: roundoff on both sides
+            mod, name = k.split('.')
+            assert max_rel(getattr(getattr(dbn, mod), name).grad, sd[k].grad) < 1e-4, (act, k)
+        assert max_rel(dbn.norm.running_mean, bn['running_mean']) < 1e-4
+        assert max_rel(dbn.norm.running_var, bn['running_var']) < 1e-4
 
 
 @pytest.mark.parametrize('golden', ['tiny_wsegan2.pt', 'tiny_wsegan_snorm.pt'])
