@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SEGAN_ABI_VERSION 11
+#define SEGAN_ABI_VERSION 12
 
 #define SEGAN_PAD_REFLECT 0
 #define SEGAN_PAD_ZERO 1
@@ -65,7 +65,13 @@ size_t segan_packed_t_bytes(int M, int N, int S);
 /* Re-lay w[m][n][K] into the two polyphase packings the contraction kernels read
  * (either destination may be NULL).  `pad_t` is the transposed-form padding: the
  * ConvTranspose1d padding for a deconv weight (modules.py:115), 0 for a conv
- * weight (whose T form is its data gradient in padded coordinates). */
+ * weight (whose T form is its data gradient in padded coordinates).
+ * The packed buffers are OPAQUE operands of the entry points below: consume them only through
+ * segan_conv1d_fwd / segan_deconv1d_dgrad (wf) and segan_deconv1d_fwd / segan_conv1d_dgrad (wt) called
+ * with the same (M, N, K, S, pad_t).  (Since ABI v12 the F packing of a K = 31 weight with an even
+ * channel count N > 2 keeps, in the padding-tap row of every odd channel, the row-30 weights of its
+ * even partner — the contraction kernels merge the two half-empty MFMA steps of a channel pair —
+ * so wf is no longer a plain zero-padded transpose of w.) */
 int segan_pack_weights(const float* w, float* wf, float* wt, int M, int N, int K, int S,
                        int pad_t, void* stream);
 

@@ -14,7 +14,7 @@ PAD_REFLECT = 0
 PAD_ZERO = 1
 ACT_NONE = 0
 ACT_TANH = 1
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class SeganSrc(Structure):

@@ -137,7 +137,7 @@ def test_bench_launches_its_own_ranks():
     assert sorted(a['arena_floats'] // 1000000 for a in c['arenas']) == [25, 64]
     for a in c['arenas']:
         assert a['buckets'] == len(a['bucket_mb']) >= 2 and a['finishes'] == 2
-        assert abs(sum(a['bucket_mb']) - a['arena_floats'] * 4 / 2 ** 20) < 0.01
+        assert abs(sum(a['bucket_mb']) - a['arena_floats'] * 4 / 2 ** 20) < 0.006 * a['buckets']   # sizes rounded to 0.01
         assert a['late_buckets'] <= a['buckets'] * a['finishes']
         # buckets run from the last parameter backwards (the order the backward finishes them in), so
         # every bucket closes inside the backward pass: none — and in particular none of the big ones
