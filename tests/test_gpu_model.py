@@ -432,16 +432,48 @@ def test_vanilla11_step_matches_reference(vanilla11_b8, deterministic):
     ref = O.gan_step(g0, d0, clean, noisy, z, fx['rolls'], st, 100.0, 5e-5)
     m.D.load_state_dict({k: ref['D'][k] if k in ref['D'] else v for k, v in d0.items()})
     ops.bump_weights_epoch()
+    with torch.no_grad():       # G's PReLU sides of this step's forward (same bits), for the aligned check
+        _, hall = m.G(ng, z=zg, ret_hid=True)
+    n_dec = len(m.G.dec_blocks)
+    gg = {k: (v > 0).cpu() for k, v in hall.items() if k != 'enc_zc' and k != 'dec_{}'.format(n_dec - 1)}
     g_adv, g_l1 = m.g_phase(Genh, cg, ng, Gopt, crit, 100.0)
     torch.cuda.synchronize()
     assert max_rel(g_adv, ref['g_adv_loss']) < 1e-4
     assert max_rel(g_l1, ref['g_l1_loss']) < ACT_TOL
+    # Free-running against the fp32 CPU oracle: 22 ReLU-like layers of G and 11 of D deep, which
+    # pre-activations within roundoff of zero fall on which side is a lottery that every change of a
+    # summation order re-draws (until round 4 every tensor was within 2e-3; with round 5's channel
+    # pairing the worst is 3.9e-3) — bounded loosely here, and settled below with the gates aligned:
+    # 8e-6
+    free = 0.0
     for k, g in ref['g_grads'].items():
         a, b = gn[k].grad.detach().double().cpu(), g.double()
-        assert ((a - b).norm() / b.norm().clamp_min(1e-300)).item() < VTOL, ('G vs oracle', k)
+        free = max(free, ((a - b).norm() / b.norm().clamp_min(1e-300)).item())
+        assert ((a - b).norm() / b.norm().clamp_min(1e-300)).item() < 5 * VTOL, ('G vs oracle', k)
         assert max_rel(gn[k].grad, g) < 10 * VTOL, ('G vs oracle', k)   # isolated ReLU-gate flips
     for k, c in fx['g_grads'].items():
         _chk(gn[k].grad, c, 1e-1)      # vs the recorded run: conditioning, see tests/test_oracle.py
+    # ---- the generator phase on the fp64 oracle with the GPU's PReLU sides imposed on both
+    # networks: the lottery is gone, what remains is fp32 roundoff through 33 layers
+    import torch.nn.functional as F
+    from test_gpu_kernels import gpu_discriminator_gates
+    gd = gpu_discriminator_gates(m.D)
+    G64 = {k: v.double().requires_grad_(True) for k, v in g0.items()}
+    D64 = {k: (v.double() if torch.is_floating_point(v) else v.clone()) for k, v in ref['D'].items()}
+    genh = O.generator_forward(G64, noisy.double(), z.double(), st, gates=gg)
+    d = O.discriminator_forward(D64, torch.cat((genh, noisy.double()), 1), fx['rolls'][2], st, gates=gd)
+    loss = F.mse_loss(d.view(-1), torch.ones(fx['batch'], dtype=torch.float64)) + \
+        100.0 * F.l1_loss(genh, clean.double())
+    keys = list(G64.keys())
+    worst, worst_k = 0.0, None
+    for k, g in zip(keys, torch.autograd.grad(loss, [G64[k] for k in keys])):
+        a, b = gn[k].grad.detach().double().cpu(), g
+        e = ((a - b).norm() / b.norm().clamp_min(1e-300)).item()
+        if e > worst:
+            worst, worst_k = e, k
+    print('vanilla11 generator gradients: free-running {:.2e}, gate-aligned vs fp64 {:.2e} ({})'.format(
+        free, worst, worst_k))
+    assert worst < 2e-4, (worst_k, worst)
 
 
 def test_generator_full_batch_is_per_sample_independent():
