@@ -61,6 +61,69 @@ def test_two_rank_gloo_allreduce_broadcast_shard():
     assert res[0][3] == [0.0, 2.0, 4.0] and res[1][3] == [6.0, 8.0, 10.0]
 
 
+def test_gradient_buckets_follow_the_backward_order():
+    """GradReducer builds its buckets from the LAST parameter backwards (round 5): the backward
+    passes finish the layers in reverse registration order, so every bucket closes inside the
+    pass and what is left for its end — the exposed part of the exchange — is the small early
+    layers.  Pinned on the default SEGAN+ nets (16 MiB target): the bucket sizes, that the buckets
+    tile the flat arena in order without gaps, that every parameter sits in exactly one bucket
+    and that the bucket holding the FIRST parameters (the last to be ready) is the 1 MB one."""
+    import sys
+    from types import SimpleNamespace
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import bench
+    from segan_pytorch_amd import distributed as sdist
+    from segan_pytorch_amd.models import SEGAN
+    o = SimpleNamespace(**bench.default_opts())
+    m = SEGAN(o)
+    Gopt, Dopt = m.build_optimizers(o)
+    want = {'G': [40.71, 124.0, 62.01, 19.38, 0.98], 'D': [16.13, 62.02, 19.39, 0.99]}
+    for name, opt in (('G', Gopt), ('D', Dopt)):
+        r = sdist.GradReducer(opt, 16 << 20)
+        mb = [round((hi - lo) * 4 / 2 ** 20, 2) for lo, hi in r.buckets]
+        assert mb == want[name], (name, mb)
+        spans = sorted(r.buckets)
+        assert spans[0][0] == 0 and spans[-1][1] == opt._total
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        assert sum(r.members) == len(opt._params) == len(r.bucket_of)
+        first = r.bucket_of[id(opt._params[0])]
+        assert mb[first] < 1.0 and first == len(r.buckets) - 1      # built last, sent last
+        # a bucket is a run of CONSECUTIVE parameters
+        for b, (lo, hi) in enumerate(r.buckets):
+            idx = [i for i, p in enumerate(opt._params) if r.bucket_of[id(p)] == b]
+            assert idx == list(range(idx[0], idx[-1] + 1))
+            assert opt._offsets[idx[0]] == lo
+
+
+def test_ranks_are_pinned_to_disjoint_core_slices():
+    """distributed.pin_host_threads: every rank of a node gets its own contiguous slice of the
+    CPUs the process may run on and torch's intra-op pool is sized to it (at most 16); one rank
+    alone, or SEGAN_NO_PIN=1, is left untouched.  Run in a child process (affinity is sticky)."""
+    import subprocess
+    import sys
+    code = (
+        "import os, json, torch\n"
+        "from segan_pytorch_amd import distributed as sd\n"
+        "all_ = sorted(os.sched_getaffinity(0))\n"
+        "assert sd.pin_host_threads(0, 1) is None and sorted(os.sched_getaffinity(0)) == all_\n"
+        "r = sd.pin_host_threads(1, 2)\n"
+        "mine = sorted(os.sched_getaffinity(0))\n"
+        "print(json.dumps({'all': all_, 'mine': mine, 'r': r, 'threads': torch.get_num_threads()}))\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, cwd=root, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    import json
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    if len(d['all']) < 2:
+        assert d['r'] is None
+        return
+    per = len(d['all']) // 2
+    assert d['mine'] == d['all'][per:2 * per]
+    assert d['r']['cpus_per_rank'] == per and d['threads'] == min(per, 16) == d['r']['torch_threads']
+
+
 def test_single_process_is_a_noop():
     from segan_pytorch_amd import distributed as sdist
     assert sdist.world_size() == 1 and sdist.rank() == 0
