@@ -1110,6 +1110,28 @@ def test_discriminator_gradients_with_aligned_gates(slopes):
     assert r['aligned'] < 5e-5, (r['aligned_worst_tensor'], r['aligned'])
 
 
+@pytest.mark.parametrize('S', [4, 2, 1])
+@pytest.mark.parametrize('M,N,K', [(128, 64, 31), (96, 6, 31), (40, 5, 31), (64, 8, 32), (64, 8, 11), (16, 2, 31)])
+def test_packed_f_buffer_is_what_layout_py_states(S, M, N, K):
+    """segan_pack_weights' F buffer against layout.pack_f — including the K = 31 channel pairing
+    (an even channel count > 2: the padding-tap row of every odd channel holds row 30 of its even
+    partner) and the cases that must NOT pair (odd count, two channels, K != 31): bit for bit,
+    padding rows / columns zero."""
+    from segan_pytorch_amd import layout as lay
+    o = _ops()
+    w = rnd(M, N, K, seed=S + M)
+    buf = o.WeightPack().f(w.to(DEV), S).cpu()
+    rows = -(-N * 32 // 64) * 64
+    pitch = 64 if M <= 64 else -(-M // 128) * 128
+    assert buf.numel() == rows * pitch
+    got = buf.view(rows, pitch)
+    want = torch.from_numpy(lay.pack_f(w.numpy(), S)).reshape(N * 32, M)        # [(n, r, u), m]
+    assert torch.equal(got[:N * 32, :M], want)
+    assert float(got[N * 32:].abs().max()) == 0.0 if rows > N * 32 else True
+    assert float(got[:, M:].abs().max()) == 0.0 if pitch > M else True
+    assert lay.f_pair(N, K) == (K == 31 and N > 2 and N % 2 == 0)
+
+
 def test_release_scratch_frees_and_the_next_call_reallocates():
     """ops.release_scratch (round-4 advice): the per-stream scratch buffers are handed back, also
     those of a side stream whose torch.cuda.Stream object is gone, and the next contraction call
