@@ -60,7 +60,9 @@ def l2_rel(a, b):
     return ((a - b).norm() / b.norm().clamp_min(1e-300)).item()
 
 
-@pytest.mark.parametrize('slopes', ['init', 'trained'])
+# 'trained' (PReLU slopes 0.05..0.3; measured 5.2e-4 flips, 6.3e-3 aligned) costs another two fp64
+# oracle evaluations at batch 300 (~40 s of host time): run with SEGAN_TEST_FULL=1
+@pytest.mark.parametrize('slopes', ['init'] + (['trained'] if os.environ.get('SEGAN_TEST_FULL') == '1' else []))
 def test_discriminator_bf16_gradients_with_aligned_gates(slopes):
     """test_discriminator_gradients_with_aligned_gates with ops.set_precision('bf16'): one D
     forward + backward at batch 300 (BatchNorm over 300 x L) on the bf16 matrix cores against the
