@@ -1,8 +1,8 @@
 # First GPU call of a round (≈ 2 min of box time): the numbers every later decision starts from.
-#   bash scripts/next_round_first.sh r05
+#   bash scripts/next_round_first.sh r06
 # -> gpurun_out/<round>_first/{bench.json, bf16_tile_probe.json, layers_bf16.txt}
 set -u
-R=${1:-r05}
+R=${1:-r06}
 cd $GRAFT_REPO_ROOT; O=gpurun_out/${R}_first; mkdir -p $O
 # headline + deterministic + blocked + bf16x3 + bf16 legs, no CPU oracle (that is 3 of a default run's 4 minutes)
 python bench.py --no-cpu-baseline > $O/bench.json 2> $O/bench.err
