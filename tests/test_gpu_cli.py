@@ -42,6 +42,25 @@ def test_train_then_clean(tmp_path):
     assert rate == 16000 and enh.shape[0] == 21000 and np.isfinite(enh).all()
 
 
+@pytest.mark.parametrize('extra,host', [([], False), (['--host_z'], True)])
+def test_train_with_bf16_contractions(tmp_path, extra, host):
+    """`train.py --precision bf16` (BASELINE config 5 through the entry point): the run trains with
+    finite losses, the choice is recorded in train.opts, and z is drawn on the GPU by default —
+    on the host, like the reference, with --host_z."""
+    ck = str(tmp_path / 'ckpt')
+    cmd = [sys.executable, os.path.join(ROOT, 'train.py'), '--save_path', ck, '--synthetic', '16',
+           '--batch_size', '4', '--epoch', '1', '--save_freq', '1', '--no_train_gen', '--precision', 'bf16',
+           '--genc_fmaps', '16', '32', '64', '--denc_fmaps', '16', '32', '64', '--genc_poolings',
+           '4', '4', '4', '--denc_poolings', '4', '4', '4', '--z_dim', '64', '--slice_size', '4096',
+           '--num_workers', '0'] + extra
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert 'btime' in out.stdout and 'nan' not in out.stdout.lower()
+    opts = json.load(open(os.path.join(ck, 'train.opts')))
+    assert opts['precision'] == 'bf16' and opts['host_z'] is host
+    assert any(n.startswith('weights_EOE_G-Generator-') for n in os.listdir(ck))
+
+
 def test_train_wsegan_snorm_from_a_pcm_shard(tmp_path):
     """The run_wsegan_train.sh flavour end to end: int16 shard -> GPU normalise / pre-emphasis
     -> WSEGAN step with the misaligned pair, spectral norm in D and Adam."""
