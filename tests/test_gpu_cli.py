@@ -51,7 +51,7 @@ def test_train_with_bf16_contractions(tmp_path, extra, host):
     cmd = [sys.executable, os.path.join(ROOT, 'train.py'), '--save_path', ck, '--synthetic', '16',
            '--batch_size', '4', '--epoch', '1', '--save_freq', '1', '--no_train_gen', '--precision', 'bf16',
            '--genc_fmaps', '16', '32', '64', '--denc_fmaps', '16', '32', '64', '--genc_poolings',
-           '4', '4', '4', '--denc_poolings', '4', '4', '4', '--z_dim', '64', '--slice_size', '4096',
+           '4', '4', '4', '--denc_poolings', '4', '4', '4', '--z_dim', '64', '--slice_size', '1024',
            '--num_workers', '0'] + extra
     out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
