@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SEGAN_ABI_VERSION 12
+#define SEGAN_ABI_VERSION 13
 
 #define SEGAN_PAD_REFLECT 0
 #define SEGAN_PAD_ZERO 1
@@ -57,6 +57,15 @@ typedef struct segan_src {
 
 int segan_abi_version(void);
 const char* segan_last_error(void);
+
+/* Workgroup slots the launch planners leave free for OTHER kernels (default 0, or the environment's
+ * SEGAN_RESERVED_SLOTS): the contraction kernels run persistent grids of one workgroup per resident
+ * slot with equal shares of the work, so a foreign kernel that holds n slots while one is launched
+ * (RCCL's channels during a data-parallel step: one 256-thread workgroup each) delays it by a
+ * whole share (+25-33 %), not by n / slots.  With a reserve of n the grids are planned for n fewer
+ * workgroups.  Process-wide; returns the previous value.  (There is no reference counterpart: the
+ * reference is single-GPU, README.md:79.) */
+int segan_set_reserved_slots(int n);
 
 /* Bytes of packed-weight workspace segan_pack_weights needs for each form. */
 size_t segan_packed_f_bytes(int M, int N, int S);

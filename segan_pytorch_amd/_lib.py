@@ -14,7 +14,7 @@ PAD_REFLECT = 0
 PAD_ZERO = 1
 ACT_NONE = 0
 ACT_TANH = 1
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 class SeganSrc(Structure):
@@ -29,6 +29,7 @@ _SRC = POINTER(SeganSrc)
 # name -> (restype, argtypes); mirrors include/segan_hip.h one to one
 SIGNATURES = {
     'segan_abi_version': (c_int, []),
+    'segan_set_reserved_slots': (c_int, [c_int]),
     'segan_last_error': (c_char_p, []),
     'segan_packed_f_bytes': (c_size_t, [c_int, c_int, c_int]),
     'segan_packed_t_bytes': (c_size_t, [c_int, c_int, c_int]),

@@ -1,6 +1,7 @@
 // segan_api.hip — error reporting and version of libsegan_hip.
 #include "segan_common.h"
 #include <string.h>
+#include <stdlib.h>
 
 static thread_local char g_err[512] = "";
 
@@ -18,6 +19,21 @@ int segan_check_launch(const char* what) {
     return SEGAN_ELAUNCH;
   }
   return SEGAN_OK;
+}
+
+static int g_reserved_slots = -1;      // -1: not set yet (environment default)
+int segan_reserved_slots_value(void) {
+  if (g_reserved_slots < 0) {
+    const char* e = getenv("SEGAN_RESERVED_SLOTS");
+    const int v = e ? atoi(e) : 0;
+    g_reserved_slots = v < 0 ? 0 : (v > 512 ? 512 : v);
+  }
+  return g_reserved_slots;
+}
+extern "C" int segan_set_reserved_slots(int n) {
+  const int prev = segan_reserved_slots_value();
+  g_reserved_slots = n < 0 ? 0 : (n > 512 ? 512 : n);
+  return prev;
 }
 
 extern "C" int segan_abi_version(void) { return SEGAN_ABI_VERSION; }

@@ -47,6 +47,18 @@ __device__ __forceinline__ void acc_block_flush(f32x16 (&acc)[NI][NJ], f32x16 (&
     }
 }
 
+// Workgroup slots the grid planners leave free (segan_set_reserved_slots / SEGAN_RESERVED_SLOTS).
+// The contraction kernels run on PERSISTENT grids of one workgroup per resident slot (256 CUs x
+// occupancy) with equal shares of the work: a foreign kernel that holds n slots while such a grid
+// is launched (RCCL's channels, one 256-thread workgroup each, during a data-parallel step) makes n
+// of its workgroups wait for the others to finish — the launch then takes one more share's time,
+// +25..33 %, not n / slots.  With a reserve of n the grids are planned for slots - n workgroups.
+int segan_reserved_slots_value(void);
+static inline int segan_grid_slots(int occ) {
+  const int g = 256 * occ - segan_reserved_slots_value();
+  return g < 64 ? 64 : g;
+}
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
 

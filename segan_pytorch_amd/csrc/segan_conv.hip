@@ -1284,10 +1284,10 @@ static unsigned plan_streamk(CorrArgs& a, int ntiles, int nch, int occ, size_t s
     // striding over the whole tiles) rather than one workgroup per tile: measured (round 4,
     // alternating runs) +3-4 % on launches of short tiles — enc1's data gradient, 4834 tiles of 64
     // chunks: 1.35 -> 1.31 ms — and nothing on long ones (dec3: 4800 tiles of 128 chunks)
-    if (allow && a.act == SEGAN_ACT_NONE && ntiles >= 2 * 256 * occ) return (unsigned)(256 * occ);
+    if (allow && a.act == SEGAN_ACT_NONE && ntiles >= 2 * 256 * occ) return (unsigned)segan_grid_slots(occ);
     return (unsigned)ntiles;
   }
-  const int G = 256 * occ;
+  const int G = segan_grid_slots(occ);
   if (a.sk_ws == nullptr || a.sk_ws_floats < (size_t)G * 2 * slab_floats) return (unsigned)ntiles;
   a.sk_nfull = (ntiles / G) * G;
   const int rem = ntiles - a.sk_nfull;

@@ -892,7 +892,7 @@ static int launch_bf2(CorrArgs a, Bf2Extra x, hipStream_t st) {
       occ[dev] = nb > 4 ? 4 : nb;
       occ_lds[dev] = lds;
     }
-    const int G = 256 * occ[dev];
+    const int G = segan_grid_slots(occ[dev]);
     const int rem = ntiles - (ntiles / G) * G;
     if (rem > 0 && a.sk_ws != nullptr && a.sk_ws_floats >= (size_t)G * 2 * MB * NB) {
       a.sk_nfull = ntiles - rem;

@@ -672,7 +672,7 @@ static void wgrad2_plan(const WgradArgs& a, int U, int occ, int& tiles, int& nsp
   const int ncol = ceil_div(a.Cv, 128 / U), nrow = ceil_div(a.M, 128);
   tiles = ncol * nrow;
   nch = ceil_div(a.Ctot, WG2_TK);
-  const int G = 256 * occ;
+  const int G = segan_grid_slots(occ);
   // equal work per workgroup: aim at whole rounds of resident workgroups
   int best = 1;
   double best_eff = 0.0;

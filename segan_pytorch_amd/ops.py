@@ -213,6 +213,13 @@ def _stream_scratch(nbytes, device):
     return buf
 
 
+def set_reserved_slots(n):
+    """Workgroup slots the launch planners of the contraction kernels leave free for other kernels
+    (segan_set_reserved_slots; default 0 or $SEGAN_RESERVED_SLOTS): RCCL's channels during a
+    data-parallel step.  Returns the previous value."""
+    return int(_lib.load().segan_set_reserved_slots(int(n)))
+
+
 def release_scratch(device=None):
     """Hand the per-stream scratch buffers (the stream-K slabs of the fp32 contractions, 128 MiB
     per device + stream, and the grow-only call scratch of the bf16 / weight-gradient calls, 134+ MB
