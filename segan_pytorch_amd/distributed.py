@@ -361,8 +361,8 @@ def comm_stats():
     return {'backend': 'native (libsegan_hip RCCL communicators)' if _native is not None else
             'torch.distributed ({})'.format(dist.get_backend() if dist.is_initialized() else 'none'),
             'sync_bn': sync_bn_enabled(), 'bucket_target_mb': _bucket_bytes / 2 ** 20, 'arenas': out,
-            # what bounds RCCL's footprint beside the contraction kernels (the 4 % CU
-            # budget assumes <= 32 channels = 32 workgroups of 256 threads): whatever the
+            # what bounds RCCL's footprint beside the contraction kernels (the
+            # measured 1.9 % is for 32 channels = 32 workgroups of 256 threads): whatever the
             # environment sets is recorded with the line
             'rccl_env': {k: v for k, v in os.environ.items()
                          if k.startswith(('NCCL_', 'RCCL_')) and 'CHANNEL' in k or k in ('NCCL_ALGO', 'NCCL_PROTO')}}
