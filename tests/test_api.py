@@ -291,6 +291,22 @@ def test_resaving_the_same_step_names_keeps_every_new_file(tmp_path, async_save)
     assert float(probe.weight.detach()[0, 0]) == 601.0
 
 
+def test_reserved_slots_setter_round_trips():
+    """segan_set_reserved_slots (ABI v13): process-wide, clamps to [0, 512], returns the previous
+    value; 0 by default (a static reserve costs more than the overlap it protects)."""
+    from segan_pytorch_amd import ops
+    first = ops.set_reserved_slots(32)
+    try:
+        assert first == int(os.environ.get('SEGAN_RESERVED_SLOTS', '0'))
+        assert ops.set_reserved_slots(-5) == 32
+        assert ops.set_reserved_slots(100000) == 0
+        assert ops.set_reserved_slots(0) == 512
+    finally:
+        ops.set_reserved_slots(first)
+    hdr = open(os.path.join(ROOT, 'include', 'segan_hip.h')).read()
+    assert 'int segan_set_reserved_slots(int n);' in hdr
+
+
 def test_accumulation_mode_switch():
     """ops.set_accumulation: 'plain' (default) / 'blocked' select SEGAN_PREC_FP32 /
     SEGAN_PREC_FP32_BLOCKED for the fp32 forward / data-gradient entry points."""
