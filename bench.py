@@ -92,6 +92,17 @@ def gflop_per_chunk(o, T=16384, wsegan=False, executed=False):
     return 2.0 * (3 * g + ((12 if wsegan else 9) - (1 if executed else 0)) * d) / 1e9
 
 
+def z_lookahead_ok(wsegan):
+    """Is the next step's z drawn one step ahead on a host thread in this workload's training loop?
+    SEGAN.train: yes (models/model.py).  WSEGAN.train: yes since round 6 on the full-rate input path
+    (train.py --pcm_shard: PCMShardLoader.sample() draws from a private generator, so nothing but the z
+    draws takes from torch's global CPU generator between two steps); with a plain DataLoader the
+    reference's per-step next(iter(dloader)) reseeds from the global generator between two z draws
+    (model.py:526-535, generator.py:197) and WSEGAN.train keeps the synchronous draw.  The bench's
+    resident batch stands for the full-rate path."""
+    return True
+
+
 class KernelTimer(object):
     """Brackets every launch of the contraction entry points with HIP events on torch's
     current stream (the stream the kernels are launched on) and books the algorithmic
@@ -123,14 +134,16 @@ class KernelTimer(object):
         if name == 'wgrad':
             lo, hi, dw = args[0], args[1], args[2]
             return 2.0 * lo.B * dw.shape[0] * dw.shape[1] * dw.shape[2] * lo.L
+        if name == 'gemm':      # gemm(A, sam, sak, Bm, sbk, sbn, C, M, N, K, overwrite)
+            return 2.0 * args[7] * args[8] * args[9]
         return 0.0
 
     def install(self):
         from segan_pytorch_amd import ops
-        for name in self.CORR + ('wgrad',):
+        for name in self.CORR + ('wgrad', 'gemm'):
             fn = getattr(ops, name)
             self._saved[name] = fn
-            fam = 'wgrad' if name == 'wgrad' else 'corr'
+            fam = name if name in ('wgrad', 'gemm') else 'corr'
 
             def wrapped(*a, _fn=fn, _name=name, _fam=fam, **k):
                 e0 = torch.cuda.Event(enable_timing=True)
@@ -148,9 +161,14 @@ class KernelTimer(object):
             setattr(ops, name, fn)
         self._saved = {}
 
+    def booked_flops(self):
+        """All FLOPs the timed launches were booked with: the matrix work the engine EXECUTED (conv /
+        deconv forward, data and weight gradients, the dense-head and STFT GEMMs)."""
+        return sum(r[1] for r in self.records)
+
     def summary(self):
         out = {}
-        for fam in ('corr', 'wgrad'):
+        for fam in ('corr', 'wgrad', 'gemm'):
             rs = [r for r in self.records if r[0] == fam]
             if not rs:
                 continue
@@ -493,6 +511,172 @@ def pmc_traffic(main=('corr2_kernel', 'corr_kernel<', 'conv_dgrad_short_kernel')
         return None, None
 
 
+def make_workload(shape, wsegan, dev, rank, B, device_z=False):
+    """Build one benchmark workload on `dev`: the nets (random init, seed 111), their optimizers, a
+    resident synthetic batch and `one_step()` = the full GAN step exactly as the training loop runs it
+    (z=None: the Generator draws z itself).  Returns a namespace."""
+    from segan_pytorch_amd import distributed as sdist
+    from segan_pytorch_amd import losses
+    from segan_pytorch_amd.datasets import synthetic_pairs
+    from segan_pytorch_amd.models import SEGAN, WSEGAN
+    opts = default_opts()
+    if shape == 'vanilla11':
+        opts.update(VANILLA11)
+    gflop = gflop_per_chunk(opts, wsegan=wsegan)
+    gflop_exec = gflop_per_chunk(opts, wsegan=wsegan, executed=True)
+    random.seed(111); np.random.seed(111); torch.manual_seed(111)
+    if wsegan:
+        opts.update(dict(misalign_pair=True, interf_pair=False, pow_weight=0.001, vanilla_gan=False,
+                         n_fft=2048))
+        model = WSEGAN(SimpleNamespace(**opts)).to(dev)
+    else:
+        model = SEGAN(SimpleNamespace(**opts)).to(dev)
+    o = SimpleNamespace(**opts)
+    Gopt, Dopt = model.build_optimizers(o)
+    sdist.broadcast_params(model.G)
+    sdist.broadcast_params(model.D)
+    model.G.train()
+    model.D.train()
+    criterion = losses.MSELoss()
+    clean, noisy = synthetic_pairs(B, 16384, seed=rank, device=dev)
+    clean, noisy = clean.unsqueeze(1).contiguous(), noisy.unsqueeze(1).contiguous()
+    random.seed(1000 + rank)
+    torch.manual_seed(2000 + rank)
+    if device_z:
+        model.G.z_generator = torch.Generator(device=dev).manual_seed(rank)
+    else:
+        model.G.z_prefetch = z_lookahead_ok(wsegan)     # as the training loops run it: next z one step ahead
+    names = ['utt_additive_{}'.format(i) if i % 2 == 0 else 'utt_{}'.format(i) for i in range(B)]
+
+    def one_step():
+        # z=None: Generator.forward draws it, exactly as inside train.py's loop
+        if wsegan:
+            return model.wgan_step(names, clean, noisy, Gopt, Dopt, 100.0, z=None)
+        return model.gan_step(clean, noisy, Gopt, Dopt, criterion, 100.0, z=None)
+
+    return SimpleNamespace(opts=opts, gflop=gflop, gflop_exec=gflop_exec, model=model, Gopt=Gopt, Dopt=Dopt,
+                           criterion=criterion, clean=clean, noisy=noisy, names=names, one_step=one_step,
+                           shape=shape, wsegan=wsegan)
+
+
+def measure_host(one_step, reps=5):
+    """What the HOST side of a step costs, and what the GPU side costs when the host is never the one
+    being waited for (round-5 review, weak 4 / next 3c):
+
+    * host_enqueue_ms_per_step — wall time of one_step() with the device synchronised BEFORE it and not
+      after: python + ctypes + the caching allocator + the HIP launches of one step, no GPU in the way
+      (median of `reps`; any hidden device sync inside the step would show up here as a step time);
+    * gpu_ms_per_step_unstarved — HIP-event time of one step whose launches were ALL enqueued while the
+      device was still busy with a blocker (torch.cuda._sleep, sized above the enqueue time): the step as
+      the GPU executes it back to back, i.e. what a kernel trace's per-step kernel sum + launch gaps
+      would read.  `unstarved_ok` says the host did finish enqueueing before the blocker ended.
+
+    The timed steps' ms_per_step minus gpu_ms_per_step_unstarved is the time per step the GPU idled
+    waiting for the host (`gpu_idle_ms_per_step` in the line)."""
+    torch.cuda.synchronize()
+    enq = []
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        one_step()
+        enq.append(1e3 * (time.perf_counter() - t0))
+    torch.cuda.synchronize()
+    enq_med = sorted(enq)[len(enq) // 2]
+    # calibrate the blocker: cycles per millisecond of torch.cuda._sleep
+    cyc = 20000000
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda._sleep(1000)
+    torch.cuda.synchronize()
+    e0.record(); torch.cuda._sleep(cyc); e1.record()
+    torch.cuda.synchronize()
+    per_ms = cyc / max(e0.elapsed_time(e1), 1e-3)
+    block_ms = 1.5 * max(enq) + 20.0
+    gpu, ok = [], True
+    for _ in range(3):
+        torch.cuda.synchronize()
+        s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        torch.cuda._sleep(int(block_ms * per_ms))
+        s0.record()
+        one_step()
+        s1.record()
+        host_ms = 1e3 * (time.perf_counter() - t0)
+        torch.cuda.synchronize()
+        gpu.append(s0.elapsed_time(s1))
+        ok = ok and host_ms < block_ms
+    return {'host_enqueue_ms_per_step': enq_med, 'host_enqueue_ms_all': [round(e, 2) for e in enq],
+            'gpu_ms_per_step_unstarved': sorted(gpu)[len(gpu) // 2],
+            'gpu_ms_unstarved_all': [round(g, 3) for g in gpu], 'blocker_ms': block_ms, 'unstarved_ok': ok}
+
+
+def roofline_blocks(summary, peak_tf, wall_ms_total, fp32_run=True):
+    """`roofline` / `roofline_wgrad` sub-blocks of a workload from the live KernelTimer summary."""
+    out = {}
+    for fam, key, what in (('corr', 'roofline', 'conv/deconv forward + data gradient'),
+                           ('wgrad', 'roofline_wgrad', 'weight gradients')):
+        r = summary.get(fam)
+        if r:
+            out[key] = {'bound': 'mfma', 'kernel': what + (' (fp32 MFMA)' if fp32_run else ' (bf16 MFMA)'),
+                        'achieved': r['tflops'], 'peak': peak_tf, 'unit': 'TFLOP/s',
+                        'frac': r['tflops'] / peak_tf, 'avg_launch_us': r['avg_us'], 'launches': r['launches'],
+                        'gflop_per_launch': r['flops_per_launch'] / 1e9,
+                        'share_of_step_time': r['total_ms'] / wall_ms_total, 'traffic': None}
+    return out
+
+
+def side_workload(shape, wsegan, dev, rank, world, B, steps, warmup, barrier, device_z=False):
+    """One of BASELINE.json's other fp32 configurations timed like the headline (same barrier /
+    max-over-ranks protocol, same KernelTimer), for the `other_workloads` block of the line: config 4
+    (WSEGAN --misalign_pair) and the literal 11-layer stride-2 shape of config 2."""
+    w = make_workload(shape, wsegan, dev, rank, B, device_z)
+    try:
+        for _ in range(warmup):
+            w.one_step()
+        timer = KernelTimer()
+        timer.install()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            lo = w.one_step()
+        barrier()
+        dt = time.perf_counter() - t0
+        timer.uninstall()
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = float(t.item())
+        ms = 1e3 * dt / steps
+        value = B * world * steps / dt
+        booked = timer.booked_flops() / (B * steps) / 1e9
+        out = {'workload': ('WSEGAN step with --misalign_pair (model.py:577-669; BASELINE config 4)' if wsegan
+                            else 'original SEGAN shape: 11+11 layers of stride 2, k31 (train.py:199-205 flags; '
+                                 'the shape BASELINE config 2 words as "11-layer enc/dec")' if shape == 'vanilla11'
+                            else 'SEGAN+ default G+D') + ', batch {} x 16384-sample chunks per GPU, fp32, '
+                                                         'full GAN step, RMSprop'.format(B),
+               'value': value, 'unit': 'chunks/s', 'ms_per_step': ms, 'steps': steps, 'warmup': warmup,
+               'n_gpus': world, 'gflop_per_chunk': w.gflop, 'gflop_per_chunk_executed': booked,
+               'step_tflops': w.gflop * value / 1e3,
+               'step_frac_of_f32_mfma_peak': w.gflop * value / 1e3 / PEAK_F32_MFMA_TF / world,
+               'step_frac_executed': booked * value / 1e3 / PEAK_F32_MFMA_TF / world,
+               'losses_finite': all(bool(torch.isfinite(x)) for x in lo),
+               'z': 'device generator' if device_z else 'host randn one step ahead on a host thread + H2D'}
+        out.update(roofline_blocks(timer.summary(), PEAK_F32_MFMA_TF, 1e3 * dt))
+        if world == 1:
+            h = measure_host(w.one_step)
+            out['host'] = h
+            out['host_enqueue_ms_per_step'] = h['host_enqueue_ms_per_step']
+            out['gpu_ms_per_step_unstarved'] = h['gpu_ms_per_step_unstarved']
+            out['gpu_idle_ms_per_step'] = ms - h['gpu_ms_per_step_unstarved']
+        return out
+    finally:
+        from segan_pytorch_amd import distributed as sdist
+        w.model.G.cancel_z_prefetch()
+        sdist.drop_reducer(w.Gopt)
+        sdist.drop_reducer(w.Dopt)
+        del w
+        torch.cuda.empty_cache()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -507,6 +691,10 @@ def main():
                          'reference (generator.py:197); the default times what train.py runs')
     ap.add_argument('--no-kernel-timer', action='store_true')
     ap.add_argument('--no-modes', action='store_true', help='skip the bf16x3 / bf16 side measurements')
+    ap.add_argument('--no-side-workloads', action='store_true',
+                    help='skip the `other_workloads` block (WSEGAN = BASELINE config 4, the 11-layer stride-2 '
+                         'shape = config 2 as worded) that the default fp32 SEGAN+ run carries')
+    ap.add_argument('--side-steps', type=int, default=10, help='timed steps per side workload')
     ap.add_argument('--comm-ab', action='store_true',
                     help='world > 1: also time the steps with the OTHER gradient transport (libsegan_hip\'s '
                          'own RCCL communicators vs torch.distributed); opt-in — the native transport has '
@@ -569,42 +757,10 @@ def main():
         devices_seen = [int(t[1]) for t in allr]
         assert ranks_seen == list(range(world)), ranks_seen
 
-    opts = default_opts()
-    if args.shape == 'vanilla11':
-        opts.update(VANILLA11)
-    gflop = gflop_per_chunk(opts, wsegan=args.wsegan)
-    gflop_exec = gflop_per_chunk(opts, wsegan=args.wsegan, executed=True)
-    random.seed(111); np.random.seed(111); torch.manual_seed(111)
-    if args.wsegan:
-        opts.update(dict(misalign_pair=True, interf_pair=False, pow_weight=0.001, vanilla_gan=False,
-                         n_fft=2048))
-        model = WSEGAN(SimpleNamespace(**opts)).to(dev)
-    else:
-        model = SEGAN(SimpleNamespace(**opts)).to(dev)
-    o = SimpleNamespace(**opts)
-    Gopt, Dopt = model.build_optimizers(o)
-    sdist.broadcast_params(model.G)
-    sdist.broadcast_params(model.D)
-    model.G.train()
-    model.D.train()
-    criterion = losses.MSELoss()
     B = args.batch
-    clean, noisy = synthetic_pairs(B, 16384, seed=rank, device=dev)
-    clean, noisy = clean.unsqueeze(1).contiguous(), noisy.unsqueeze(1).contiguous()
-    random.seed(1000 + rank)
-    torch.manual_seed(2000 + rank)
-    if args.device_z:
-        model.G.z_generator = torch.Generator(device=dev).manual_seed(rank)
-    else:
-        model.G.z_prefetch = not args.wsegan      # as SEGAN.train runs it: next z drawn one step ahead
-
-    names = ['utt_additive_{}'.format(i) if i % 2 == 0 else 'utt_{}'.format(i) for i in range(B)]
-
-    def one_step():
-        # z=None: Generator.forward draws it, exactly as inside train.py's loop
-        if args.wsegan:
-            return model.wgan_step(names, clean, noisy, Gopt, Dopt, 100.0, z=None)
-        return model.gan_step(clean, noisy, Gopt, Dopt, criterion, 100.0, z=None)
+    wl = make_workload(args.shape, args.wsegan, dev, rank, B, args.device_z)
+    opts, gflop, gflop_exec = wl.opts, wl.gflop, wl.gflop_exec
+    model, Gopt, Dopt, one_step = wl.model, wl.Gopt, wl.Dopt, wl.one_step
 
     def barrier():
         if world > 1:
@@ -632,6 +788,17 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     finite = all(bool(torch.isfinite(x)) for x in losses_out)
+    if timer is not None and timer.records:
+        # what the engine EXECUTED, from the FLOPs the timed launches were booked with (round-5 review,
+        # weak 7: the formula's "one D forward less" missed the skipped z half of dec0's data gradient
+        # and the first layers' data gradients)
+        gflop_exec = timer.booked_flops() / (B * args.steps) / 1e9
+    host = None
+    if world == 1 and not args.no_modes:
+        try:
+            host = measure_host(one_step)
+        except Exception as e:      # a side measurement must never cost the headline line
+            host = {'error': repr(e)}
 
     # ---- the first multi-GPU run diagnoses itself (round-3 review, item 6): what the gradient
     # exchange cost in the timed steps, and the same steps with the OTHER transport ----
@@ -782,7 +949,20 @@ def main():
                 _ops.set_precision('fp32')
                 if host_gen:
                     model.G.z_generator = None
-                    model.G.z_prefetch = not args.wsegan
+                    model.G.z_prefetch = z_lookahead_ok(args.wsegan)
+
+    # BASELINE.json's other fp32 configurations, timed like the headline and carried by the SAME line
+    # (round-5 review, next 1): config 4 (WSEGAN --misalign_pair) and config 2's literal 11-layer shape
+    side = {}
+    if args.precision == 'fp32' and args.shape == 'segan_plus' and not args.wsegan and \
+            not args.no_side_workloads:
+        model.G.cancel_z_prefetch()
+        for key, shp, ws_ in (('wsegan', 'segan_plus', True), ('vanilla11', 'vanilla11', False)):
+            try:
+                side[key] = side_workload(shp, ws_, dev, rank, world, B, args.side_steps, args.warmup,
+                                          barrier, args.device_z)
+            except Exception as e:      # a side measurement must never cost the headline line
+                side[key] = {'error': repr(e)}
 
     if rank == 0:
         chunks = B * world * args.steps
@@ -835,7 +1015,17 @@ def main():
             'step_frac_note': 'step_frac_of_f32_mfma_peak divides the REFERENCE accounting (SURVEY.md 8d: '
                               'it counts the D weight gradients of the generator phase, which the reference '
                               'computes and discards) by the time; step_frac_executed counts only what this '
-                              'engine executes (one D forward-equivalent less)',
+                              'engine executes: the FLOPs its timed launches were booked with (no D weight '
+                              'gradients in the generator phase, no z half of dec0\'s data gradient, no '
+                              'first-layer data gradients)',
+            'gflop_per_chunk_executed_source': ('FLOPs booked by the timed launches (conv/deconv forward, data and '
+                                                'weight gradients, dense-head / STFT GEMMs)'
+                                                if timer is not None else 'formula (no kernel timer)'),
+            'host': host,
+            'host_enqueue_ms_per_step': host.get('host_enqueue_ms_per_step') if host else None,
+            'gpu_ms_per_step_unstarved': host.get('gpu_ms_per_step_unstarved') if host else None,
+            'gpu_idle_ms_per_step': (ms - host['gpu_ms_per_step_unstarved']
+                                     if host and 'gpu_ms_per_step_unstarved' in host else None),
             'step_hbm_gbs_algorithmic': MB_PER_CHUNK * value / 1e3 / world,
             'step_frac_of_hbm_roofline': MB_PER_CHUNK * value / 1e3 / world / PEAK_HBM_GBS,
         }
@@ -884,6 +1074,13 @@ def main():
                                               pmc_mfma_busy('wgrad2', wl) if fp32_run else
                                               pmc_mfma_busy('wgrad_bf2', '_bf16' + wl) if args.precision == 'bf16'
                                               else None)}
+        if side:
+            side['note'] = ('BASELINE.json configs beside the headline, each a full fp32 GAN step at the same '
+                            'per-GPU batch, timed with the same barrier / max-over-ranks protocol: `wsegan` = '
+                            'config 4 (run_wsegan_train.sh flags), `vanilla11` = the 11-layer stride-2 shape '
+                            'config 2 words; roofline blocks from the live HIP-event kernel timer; host_* / '
+                            'gpu_* from measure_host (N = 1 only)')
+            line['other_workloads'] = side
         if modes:
             modes['note'] = ('same workload, contractions on the bf16 MFMA: bf16x3 = fp32 operands '
                              'split exactly into 3 bf16 planes, 6 partial products, fp32 accumulate '

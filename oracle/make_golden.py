@@ -36,6 +36,14 @@ tiny_nobias.pt / segan_plus_nobias_b2.pt (python oracle/make_golden.py nobias) -
                  theirs (modules.py:116-119 ignores the flag), D keeps all of its biases.  One
                  GAN step of the tiny net (full tensors) and of the default net at B=2
                  (checksums, like segan_plus_b2.pt).
+tiny_corners.pt  (python oracle/make_golden.py corners) three corners train.py reaches that had no
+                 reference golden until round 6: 'vanillagan' = the literal ``WSEGAN.train`` with
+                 --vanilla_gan --misalign_pair (BCE-with-logits cost, model.py:582-585), two
+                 iterations; 'constantskip' = --skip_type constant (generator.py:25,40,59: a
+                 fixed per-channel scale, requires_grad False, so Model.parameters — core.py:
+                 196-198 — hides it from the optimizer): one manual GAN step (skip_init randn)
+                 and the literal ``SEGAN.train`` for two batches; 'mseloss' = --reg_loss mse_loss
+                 (train.py:179, model.py:79): one manual step and the literal loop.
 tiny_wsegan_interf.pt (python oracle/make_golden.py interf) the literal ``WSEGAN.train`` with
                  --interf_pair (model.py:606-628), two iterations each: 'both' =
                  --misalign_pair --interf_pair (four D forwards per step, d_weight 1/4),
@@ -96,8 +104,9 @@ def grads_of(m):
     return {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
 
 
-def manual_step(ref, segan, clean, noisy, z, roll_seed, l1_weight=100.0, lr=5e-5):
-    """model.py:292-321 with the reference's modules, explicit z, seeded shifts."""
+def manual_step(ref, segan, clean, noisy, z, roll_seed, l1_weight=100.0, lr=5e-5, reg=F.l1_loss):
+    """model.py:292-321 with the reference's modules, explicit z, seeded shifts.  `reg`: the
+    regression loss getattr(F, opts.reg_loss) of model.py:79 (segan.reg_loss for --reg_loss)."""
     Gopt = torch.optim.RMSprop(segan.G.parameters(), lr=lr)
     Dopt = torch.optim.RMSprop(segan.D.parameters(), lr=lr)
     criterion = nn.MSELoss()
@@ -120,7 +129,7 @@ def manual_step(ref, segan, clean, noisy, z, roll_seed, l1_weight=100.0, lr=5e-5
     Gopt.zero_grad()
     d_fake_, _ = segan.infer_D(Genh, noisy)
     g_adv = criterion(d_fake_.view(-1), label.clone().fill_(1))
-    g_l1 = l1_weight * F.l1_loss(Genh, clean)
+    g_l1 = l1_weight * reg(Genh, clean)
     (g_adv + g_l1).backward()
     out['g_grads'] = grads_of(segan.G)
     Gopt.step()
@@ -410,10 +419,111 @@ def make_interf(ref):
     print('tiny_wsegan_interf.pt done')
 
 
+def _literal_segan_train(ref, o, data_seeds, seed):
+    """The reference's literal SEGAN.train over a two-batch loader (its own z / phase-shift draws,
+    replayable from `seed`), from a seed-111 init: the sub-fixture the *_train2 tests replay."""
+    seed_all(111)
+    segan = ref.SEGAN(SimpleNamespace(**o))
+    batches = [synth(3, 1024, s_) for s_ in data_seeds]
+    loader = [[['u'] * 3, c, n, torch.zeros(3)] for c, n in batches]
+    fx = {'batches': batches, 'seed': seed}         # opts / G0 / D0: the parent fixture's (same init)
+    g0, d0 = clone_sd(segan.G), clone_sd(segan.D)
+    seed_all(seed)
+    segan.train(SimpleNamespace(**o), loader, nn.MSELoss(), o['l1_weight'], o['l1_dec_step'],
+                o['l1_dec_epoch'], 1000, va_dloader=None, device='cpu')
+    fx['G_final'] = clone_sd(segan.G)
+    fx['D_final'] = clone_sd(segan.D)
+    return fx, g0, d0
+
+
+def make_corners(ref):
+    out = {}
+    small = dict(genc_fmaps=[4, 8, 16], denc_fmaps=[4, 8, 16], z_dim=16)     # small fixture, like VARIANTS
+    # ---- --vanilla_gan through the literal WSEGAN.train (harness patches as for tiny_wsegan2) ----
+    _stft = torch.stft
+    torch.stft = lambda *a, **k: torch.view_as_real(_stft(*a, return_complex=True, **k))
+    _cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        ow = tiny_opts()
+        ow.update(small)
+        ow.update(dict(wsegan=True, misalign_pair=True, vanilla_gan=True, cuda=False, save_freq=1000))
+        seed_all(111)
+        wseg = ref.WSEGAN(SimpleNamespace(**ow))
+        assert wseg.vanilla_gan is True
+        c1, n1 = synth(3, 1024, 34)
+        names = ['utt_additive_0', 'utt_1', 'utt_additive_2']
+        loader = [[names, c1, n1, torch.zeros(3)]]
+        fxw = {'opts': ow, 'G0': clone_sd(wseg.G), 'D0': clone_sd(wseg.D), 'clean': c1,
+               'noisy': n1, 'names': names, 'seed': 53, 'iters': 2}
+        ow2 = dict(ow)
+        ow2['epoch'] = 2
+        seed_all(53)
+        wseg.train(SimpleNamespace(**ow2), loader, None, ow['l1_weight'], ow['l1_dec_step'],
+                   ow['l1_dec_epoch'], 1000, va_dloader=None, device='cpu')
+        fxw['G_final'] = clone_sd(wseg.G)
+        fxw['D_final'] = clone_sd(wseg.D)
+        out['vanillagan'] = fxw
+        print('corners: vanillagan done')
+    finally:
+        torch.stft = _stft
+        torch.Tensor.cuda = _cuda
+    # ---- --skip_type constant ----
+    o = tiny_opts()
+    o.update(small)
+    o.update(dict(skip_type='constant', skip_init='randn'))
+    seed_all(111)
+    segan = ref.SEGAN(SimpleNamespace(**o))
+    consts = sorted(k for k in segan.G.state_dict() if k.endswith('skip_k'))
+    named = dict(segan.G.named_parameters())
+    assert consts and all(not named[k].requires_grad for k in consts)
+    # Model.parameters (core.py:196-198) is what build_optimizers hands to the optimizer: no skip_k
+    seen = {id(p) for p in segan.G.parameters()}
+    assert all(id(named[k]) not in seen for k in consts)
+    clean, noisy = synth(3, 1024, 30)
+    clean, noisy = clean.unsqueeze(1), noisy.unsqueeze(1)
+    z = torch.randn(3, 16, 16, generator=torch.Generator().manual_seed(31))
+    fx = {'opts': o, 'G0': clone_sd(segan.G), 'D0': clone_sd(segan.D), 'clean': clean,
+          'noisy': noisy, 'z': z, 'roll_seed': 19, 'constants': consts,
+          'n_params_G': segan.G.get_n_params(),
+          'rolls': ref_harness.ReplayRandom(19).rolls(3, o['phase_shift'], 3)}
+    fx.update(manual_step(ref, segan, clean, noisy, z, 19))
+    assert all(k not in fx['g_grads'] for k in consts)
+    assert all(torch.equal(fx['G_after'][k], fx['G0'][k]) for k in consts)
+    fx['train2'], g0, d0 = _literal_segan_train(ref, o, (32, 33), 29)
+    assert all(torch.equal(g0[k], fx['G0'][k]) for k in g0) and all(torch.equal(d0[k], fx['D0'][k]) for k in d0)
+    assert all(torch.equal(fx['train2']['G_final'][k], fx['G0'][k]) for k in consts)
+    out['constantskip'] = fx
+    print('corners: constantskip done', consts, fx['n_params_G'])
+    # ---- --reg_loss mse_loss ----
+    o = tiny_opts()
+    o.update(small)
+    o['reg_loss'] = 'mse_loss'
+    seed_all(111)
+    segan = ref.SEGAN(SimpleNamespace(**o))
+    assert segan.reg_loss is F.mse_loss
+    clean, noisy = synth(3, 1024, 36)
+    clean, noisy = clean.unsqueeze(1), noisy.unsqueeze(1)
+    z = torch.randn(3, 16, 16, generator=torch.Generator().manual_seed(37))
+    fx = {'opts': o, 'G0': clone_sd(segan.G), 'D0': clone_sd(segan.D), 'clean': clean,
+          'noisy': noisy, 'z': z, 'roll_seed': 23,
+          'rolls': ref_harness.ReplayRandom(23).rolls(3, o['phase_shift'], 3)}
+    fx.update(manual_step(ref, segan, clean, noisy, z, 23, reg=segan.reg_loss))
+    fx['train2'], g0, d0 = _literal_segan_train(ref, o, (38, 39), 43)
+    assert all(torch.equal(g0[k], fx['G0'][k]) for k in g0) and all(torch.equal(d0[k], fx['D0'][k]) for k in d0)
+    out['mseloss'] = fx
+    print('corners: mseloss done', float(fx['g_l1_loss']))
+    torch.save(out, os.path.join(OUT, 'tiny_corners.pt'))
+    print('tiny_corners.pt done')
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = ref_harness.import_reference()
     torch.set_num_threads(max(1, os.cpu_count() or 1))
+    if len(sys.argv) > 1 and sys.argv[1] == 'corners':
+        make_corners(ref)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'nobias':
         make_nobias(ref)
         return

@@ -240,10 +240,13 @@ def discriminator_forward(sd, x, rolls, strides, training=True, ret_act=False, p
 _BUFFERS = ('running_mean', 'running_var', 'num_batches_tracked', 'weight_u', 'weight_v')
 
 
-def _leafs(sd):
+def _leafs(sd, frozen=()):
+    """Leaf copies of a state dict: parameters require grad, buffers — and the `frozen` keys
+    (--skip_type constant: skip_k.requires_grad = False, generator.py:40-41, so core.py:196-198
+    never hands it to the optimizer) — do not."""
     out = {}
     for k, v in sd.items():
-        if k.split('.')[-1] in _BUFFERS:
+        if k.split('.')[-1] in _BUFFERS or k in frozen:
             out[k] = v.clone()
         else:
             out[k] = v.clone().requires_grad_(True)
@@ -262,11 +265,13 @@ def rmsprop_update(p, g, sq, lr, alpha=0.99, eps=1e-8):
 
 def gan_step(g_sd, d_sd, clean, noisy, z, rolls3, strides, l1_weight=100.0, lr=5e-5,
              g_sq=None, d_sq=None, update=True, dec_strides=None, d_strides=None,
-             skip_merge='concat', pool_type='none'):
+             skip_merge='concat', pool_type='none', reg_loss='l1_loss', frozen=()):
     """One SEGAN step, model.py:292-321.  rolls3 = three roll lists (D real, D fake,
-    D fake-for-G).  Returns a dict with outputs, losses, gradients and (when `update`)
-    the updated parameters / RMSprop state."""
-    G = _leafs(g_sd)
+    D fake-for-G).  `reg_loss`: 'l1_loss' | 'mse_loss' = getattr(F, opts.reg_loss) of model.py:79
+    (train.py:179); `frozen`: generator keys that are not trained (--skip_type constant).
+    Returns a dict with outputs, losses, gradients and (when `update`) the updated parameters /
+    RMSprop state."""
+    G = _leafs(g_sd, frozen)
     D = _leafs(d_sd)
     out = {}
     gen = lambda: generator_forward(G, noisy, z, strides, dec_strides, skip_merge=skip_merge)
@@ -294,7 +299,7 @@ def gan_step(g_sd, d_sd, clean, noisy, z, rolls3, strides, l1_weight=100.0, lr=5
     # (3) generator update through the updated D
     d_fake_ = disc(torch.cat((Genh, noisy), 1), rolls3[2])
     g_adv = F.mse_loss(d_fake_.view(-1), torch.ones(clean.size(0), dtype=clean.dtype))
-    g_l1 = l1_weight * F.l1_loss(Genh, clean)
+    g_l1 = l1_weight * getattr(F, reg_loss)(Genh, clean)
     gkeys = [k for k in G if G[k].requires_grad]
     ggr = torch.autograd.grad(g_adv + g_l1, [G[k] for k in gkeys], allow_unused=True)
     # a skip the forward never takes (pooling-1 decoder level) has no gradient: like
@@ -343,8 +348,10 @@ def interf_squares(n, T):
 
 
 def wsegan_step(g_sd, d_sd, clean, noisy, z, rolls, perm, names, strides, l1_weight=100.0,
-                pow_weight=0.001, lr=5e-5, n_fft=2048, g_sq=None, d_sq=None, squares=None):
-    """One WSEGAN step, model.py:577-669 (LSGAN cost).  rolls: the roll lists in call order
+                pow_weight=0.001, lr=5e-5, n_fft=2048, g_sq=None, d_sq=None, squares=None,
+                vanilla_gan=False):
+    """One WSEGAN step, model.py:577-669 (LSGAN cost; `vanilla_gan`: the BCE-with-logits cost of
+    model.py:582-585 for every adversarial term).  rolls: the roll lists in call order
     (D real, D fake, [D misaligned,] [D interference,] D fake-for-G); perm: the batch
     permutation random.shuffle produced for --misalign_pair (model.py:598-600) or None;
     squares: the --interf_pair square waves [B, 1, T] (model.py:606-628) or None.  The weight
@@ -358,16 +365,17 @@ def wsegan_step(g_sd, d_sd, clean, noisy, z, rolls, perm, names, strides, l1_wei
     d_real = discriminator_forward(D, torch.cat((clean, noisy), 1), rolls.pop(0), strides)
     Genh = generator_forward(G, noisy, z, strides)
     d_fake = discriminator_forward(D, torch.cat((Genh.detach(), noisy), 1), rolls.pop(0), strides)
-    d_loss = F.mse_loss(d_fake, zeros) + F.mse_loss(d_real, ones)
+    cost = F.binary_cross_entropy_with_logits if vanilla_gan else F.mse_loss
+    d_loss = cost(d_fake, zeros) + cost(d_real, ones)
     d_weight = 0.5
     if perm is not None:
         d_shuf = discriminator_forward(D, torch.cat((clean, clean[perm]), 1), rolls.pop(0), strides)
-        d_loss = d_loss + F.mse_loss(d_shuf, zeros)
+        d_loss = d_loss + cost(d_shuf, zeros)
         d_weight = 1 / 3
     if squares is not None:
         d_int = discriminator_forward(D, torch.cat((clean + squares, noisy), 1), rolls.pop(0),
                                       strides)
-        d_loss = d_loss + F.mse_loss(d_int, zeros)
+        d_loss = d_loss + cost(d_int, zeros)
         d_weight = 1 / 4
     d_loss = d_weight * d_loss
     dkeys = [k for k in D if _is_param(k)]
@@ -378,7 +386,7 @@ def wsegan_step(g_sd, d_sd, clean, noisy, z, rolls, perm, names, strides, l1_wei
         for k, g in zip(dkeys, dgr):
             rmsprop_update(D[k], g, d_sq[k], lr)
     d_fake_ = discriminator_forward(D, torch.cat((Genh, noisy), 1), rolls.pop(0), strides)
-    g_adv = F.mse_loss(d_fake_, ones)
+    g_adv = cost(d_fake_, ones)
     pow_loss = pow_weight * F.l1_loss(stft_pow_db(Genh, n_fft), stft_pow_db(clean, n_fft))
     mask = torch.zeros(B, 1, Genh.size(2), dtype=clean.dtype)
     for i, n in enumerate(names):

@@ -11,6 +11,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--batch', type=int, default=300)
 ap.add_argument('--iters', type=int, default=5)
 ap.add_argument('--only', default='')
+ap.add_argument('--shape', default='segan_plus', choices=['segan_plus', 'vanilla11'])
 ap.add_argument('--verbose', action='store_true')
 args = ap.parse_args()
 B, K, S = args.batch, 31, 4
@@ -42,6 +43,16 @@ def report(name, flops, ms):
 
 enc = [(1, 64, 16384), (64, 128, 4096), (128, 256, 1024), (256, 512, 256), (512, 1024, 64)]
 dec = [(2048, 512, 16), (1024, 256, 64), (512, 128, 256), (256, 64, 1024), (128, 1, 4096)]
+if args.shape == 'vanilla11':       # the original 11-layer stride-2 SEGAN (train.py:199-205 flags)
+    S = 2
+    fm = [16, 32, 32, 64, 64, 128, 128, 256, 256, 512, 1024]
+    enc, cin, L = [], 1, 16384
+    for c in fm:
+        enc.append((cin, c, L)); cin = c; L //= 2
+    dec, cin = [], 2 * fm[-1]
+    for i, c in enumerate(fm[::-1][1:] + [1]):
+        dec.append((cin, c, L)); cin = 2 * c; L *= 2
+PADC, PADD = (14, 13) if S == 4 else (ops.conv_pad(K, S)[0], ops.deconv_pad(K, S))
 for i, (N, M, L) in enumerate(enc):
     for tag, Nin in (('G', N), ('D', 2 if i == 0 else N)):
         if i > 0 and tag == 'D':
@@ -59,7 +70,7 @@ for i, (N, M, L) in enumerate(enc):
         da = torch.randn(B, M, L // S, device=dev)
         report(name + ' dgrad', fl, timeit(lambda: ops.conv1d_dgrad(da, w, L, S, roll=3, pack=pk)))
         dw = torch.zeros_like(w)
-        report(name + ' wgrad', fl, timeit(lambda: ops.wgrad(ops.Src(da), src, dw, K, S, 14, ops.PAD_REFLECT)))
+        report(name + ' wgrad', fl, timeit(lambda: ops.wgrad(ops.Src(da), src, dw, K, S, PADC, ops.PAD_REFLECT)))
 for i, (M, N, Ls) in enumerate(dec):
     name = 'G.dec%d' % i
     if args.only and args.only not in name:
@@ -74,12 +85,12 @@ for i, (M, N, Ls) in enumerate(dec):
     dy = torch.randn(B, N, S * Ls, device=dev)
     report(name + ' dgrad', fl, timeit(lambda: ops.deconv1d_dgrad(dy, w, S, 0, pack=pk)))
     dw = torch.zeros_like(w)
-    report(name + ' wgrad', fl, timeit(lambda: ops.wgrad(src, ops.Src(dy), dw, K, S, 13, ops.PAD_ZERO)))
+    report(name + ' wgrad', fl, timeit(lambda: ops.wgrad(src, ops.Src(dy), dw, K, S, PADD, ops.PAD_ZERO)))
 # packing
 w = torch.randn(2048, 512, 31, device=dev)
 pk = ops.WeightPack()
 def repack():
-    ops.bump_weights_epoch(); pk.f(w, 4); pk.t(w, 4, 13)
+    ops.bump_weights_epoch(); pk.f(w, S); pk.t(w, S, PADD)
 report('pack f+t 2048x512x31', 2048 * 512 * 31 * 4.0 * 4, timeit(repack))
 tot_ms = sum(r[2] for r in rows[:-1]); tot_fl = sum(r[1] for r in rows[:-1])
 print('TOTAL %.1f GFLOP %.2f ms -> %.1f TF/s' % (tot_fl, tot_ms, tot_fl / tot_ms))

@@ -269,13 +269,14 @@ class PCMShardLoader(object):
         self.loader = self._make_loader()
         self._sample_loader = None      # sample()'s own loader: see there
 
-    def _make_loader(self):
+    def _make_loader(self, sampler=None, generator=None):
         from torch.utils.data import BatchSampler, DataLoader
         nw = self._num_workers
         return DataLoader(_BatchIndexDataset(self.shard), batch_size=None,
-                          sampler=BatchSampler(self.sampler, self._batch_size, self._drop_last),
+                          sampler=BatchSampler(sampler if sampler is not None else self.sampler,
+                                               self._batch_size, self._drop_last),
                           num_workers=nw, pin_memory=True, prefetch_factor=2 if nw > 0 else None,
-                          persistent_workers=nw > 0)
+                          persistent_workers=nw > 0, generator=generator)
 
     def __len__(self):
         return len(self.loader)
@@ -322,6 +323,21 @@ class PCMShardLoader(object):
             noisy.record_stream(main)
             yield [names, clean, noisy, idx]
 
+    def _ensure_sample_loader(self):
+        if self._sample_loader is None:
+            import copy
+            from torch.utils.data import RandomSampler
+            g = torch.Generator()
+            g.manual_seed(int(torch.empty((), dtype=torch.int64).random_().item()))
+            if isinstance(self.sampler, RandomSampler):
+                smp = RandomSampler(self.shard, replacement=self.sampler.replacement,
+                                    num_samples=self.sampler._num_samples, generator=g)
+            else:
+                smp = copy.copy(self.sampler)
+            self._sample_sampler, self._sample_gen = smp, g
+            self._sample_loader = self._make_loader(smp, g)
+        return self._sample_loader
+
     def sample(self):
         """One random batch per call from ONE live iterator, re-created only when the epoch is
         exhausted — for WSEGAN's `sample_dloader`, which the reference writes as
@@ -330,14 +346,21 @@ class PCMShardLoader(object):
         throw away up to three prefetched ones, every step (round-3 advice).  Batches then come
         from a shuffled pass without replacement instead of a fresh shuffle per step.
 
-        The iterator lives on a SECOND DataLoader of the same shard and sampler (created on first
-        use): a DataLoader with persistent workers has one shared `_iterator`, so sampling from
-        the loader that `__iter__` walks — train / evaluate over this object while WSEGAN samples
-        from it — would make the two iterators reset each other (dropped or duplicated batches;
-        round-4 advice).  The next sample batch is staged (H2D + prep kernel) on the side stream
-        while the caller computes on this one, like `__iter__` does."""
-        if self._sample_loader is None:
-            self._sample_loader = self._make_loader()
+        The iterator lives on a SECOND DataLoader of the same shard (created on first use): a
+        DataLoader with persistent workers has one shared `_iterator`, so sampling from the loader
+        that `__iter__` walks — train / evaluate over this object while WSEGAN samples from it —
+        would make the two iterators reset each other (dropped or duplicated batches; round-4
+        advice).  That loader has its OWN sampler and its OWN torch.Generator (round-5 advice): a
+        RandomSampler seeded by ONE draw from torch's global generator when the loader is created
+        (a copy of a DistributedSampler keeps that sampler's seed and gets its own epoch counter), and
+        the DataLoader's base seed comes from the same private generator — so after the first call
+        `sample()` never touches torch's global CPU generator again and never changes the main
+        sampler's epoch: the main loader's shuffles are what they would be without it, and the
+        generator's z look-ahead (Generator.z_prefetch) stays valid across sample() calls, which is
+        what lets WSEGAN.train keep the next z off the critical path (`sample_keeps_global_rng`).
+        The next sample batch is staged (H2D + prep kernel) on the side stream while the caller
+        computes on this one, like `__iter__` does."""
+        self._ensure_sample_loader()
 
         def fetch():
             it = getattr(self, '_live', None)
@@ -346,9 +369,9 @@ class PCMShardLoader(object):
             try:
                 return next(it)
             except StopIteration:
-                if hasattr(self.sampler, 'set_epoch'):
+                if hasattr(self._sample_sampler, 'set_epoch'):
                     self._epoch = getattr(self, '_epoch', 0) + 1
-                    self.sampler.set_epoch(self._epoch)
+                    self._sample_sampler.set_epoch(self._epoch)
                 it = self._live = iter(self._sample_loader)
                 return next(it)
 
@@ -364,6 +387,15 @@ class PCMShardLoader(object):
         clean.record_stream(main)
         noisy.record_stream(main)
         return [names, clean, noisy, idx]
+
+    # sample() draws from a private generator: WSEGAN.train may keep the z look-ahead on
+    sample_keeps_global_rng = True
+
+    def close(self):
+        """Drop sample()'s loader (its worker processes and pinned buffers) and the staged batch."""
+        self._sample_next = None
+        self._live = None
+        self._sample_loader = None
 
 
 class PCMShardCollate(object):

@@ -63,6 +63,9 @@ def init_from_env(backend=None):
     backend = backend or os.environ.get('SEGAN_DIST_BACKEND')
     if 'SEGAN_LOCAL_DEVICE' in os.environ:
         lr = int(os.environ['SEGAN_LOCAL_DEVICE'])
+    # before any communicator exists: threads created from here on (RCCL's proxies, the z-draw thread,
+    # loader workers) inherit this rank's CPU slice
+    pin_host_threads(int(os.environ.get('LOCAL_RANK', lr)), int(os.environ.get('LOCAL_WORLD_SIZE', ws)))
     if not dist.is_initialized():
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
@@ -86,35 +89,161 @@ def init_from_env(backend=None):
         else:
             dist.init_process_group(backend, rank=rk, world_size=ws)
     _init_native(rk, ws)
-    pin_host_threads(int(os.environ.get('LOCAL_RANK', lr)), int(os.environ.get('LOCAL_WORLD_SIZE', ws)))
     return rk, ws, lr
 
 
 _host_pin = None
 
 
+def _read_int(path):
+    try:
+        with open(path) as f:
+            return int(f.read().strip())
+    except Exception:
+        return None
+
+
+def host_topology(cpus):
+    """{cpu: (numa node, package, core id)} of the given logical CPUs from sysfs (None entries where the
+    kernel does not say).  Linux enumerates the physical cores first and their SMT siblings after
+    them on most two-socket hosts (cpu 0-127 = cores, 128-255 = siblings), so nothing about the
+    topology can be read off the CPU numbers themselves (round-5 advice)."""
+    import glob
+    topo = {}
+    for c in cpus:
+        base = '/sys/devices/system/cpu/cpu{}'.format(c)
+        node = None
+        for nd in glob.glob(base + '/node[0-9]*'):
+            node = int(os.path.basename(nd)[4:])
+        topo[c] = (node, _read_int(base + '/topology/physical_package_id'),
+                   _read_int(base + '/topology/core_id'))
+    return topo
+
+
+def gpu_numa_nodes(n):
+    """NUMA node of local GPUs 0..n-1 (/sys/bus/pci/devices/<bdf>/numa_node), None where unknown."""
+    out = []
+    for i in range(n):
+        node = None
+        try:
+            pr = torch.cuda.get_device_properties(i)
+            bdf = '{:04x}:{:02x}:{:02x}.0'.format(pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+            node = _read_int('/sys/bus/pci/devices/{}/numa_node'.format(bdf))
+            if node is not None and node < 0:
+                node = None
+        except Exception:
+            node = None
+        out.append(node)
+    return out
+
+
+def plan_host_slices(local_world, cpus, topo=None, gpu_nodes=None):
+    """Disjoint CPU lists, one per local rank — or None when there are fewer CPUs than ranks.
+
+    With the topology known the unit is the PHYSICAL core (all its SMT siblings go to one rank: two
+    ranks never share a core's execution units) and a rank whose GPU reports a NUMA node gets cores of
+    that node (its pinned H2D staging buffers, the z draw and the loader workers stay on the socket
+    the GPU hangs off); the ranks of one node split its cores evenly.  Where a node has fewer cores
+    than ranks that want it, or the topology is unknown, the allowed CPUs are ordered by (node,
+    package, core, cpu) and cut into equal runs — whole cores when there are enough, logical CPUs
+    otherwise.  Pure function of its arguments (tests/test_dist_cpu.py)."""
+    cpus = sorted(cpus)
+    if local_world < 1 or len(cpus) < local_world:
+        return None
+    topo = topo or {}
+
+    def key(c):
+        n, p, k = topo.get(c, (None, None, None))
+        return (n if n is not None else 1 << 20, p if p is not None else 1 << 20,
+                k if k is not None else c, c)
+
+    cores = {}
+    for c in sorted(cpus, key=key):
+        n, p, k = topo.get(c, (None, None, None))
+        cores.setdefault((n, p, k if k is not None else ('cpu', c)), []).append(c)
+    core_list = list(cores.items())          # ordered by node, package, core
+    gpu_nodes = list(gpu_nodes) if gpu_nodes is not None else [None] * local_world
+    gpu_nodes = (gpu_nodes + [None] * local_world)[:local_world]
+    if all(n is not None for n in gpu_nodes):
+        by_node = {}
+        for r, n in enumerate(gpu_nodes):
+            by_node.setdefault(n, []).append(r)
+        out, ok = [None] * local_world, True
+        for n, ranks in by_node.items():
+            mine = [cs for (nn, _p, _k), cs in core_list if nn == n]
+            if len(mine) < len(ranks):
+                ok = False
+                break
+            per = len(mine) // len(ranks)
+            for j, r in enumerate(ranks):
+                out[r] = sorted(c for cs in mine[j * per:(j + 1) * per] for c in cs)
+        if ok:
+            return out
+    if len(core_list) >= local_world:
+        per = len(core_list) // local_world
+        return [sorted(c for _k, cs in core_list[r * per:(r + 1) * per] for c in cs)
+                for r in range(local_world)]
+    flat = [c for _k, cs in core_list for c in cs]
+    per = len(flat) // local_world
+    return [sorted(flat[r * per:(r + 1) * per]) for r in range(local_world)]
+
+
+def _ranges(cpus):
+    """'0-15,128-143' for a sorted CPU list."""
+    out, i = [], 0
+    while i < len(cpus):
+        j = i
+        while j + 1 < len(cpus) and cpus[j + 1] == cpus[j] + 1:
+            j += 1
+        out.append(str(cpus[i]) if i == j else '{}-{}'.format(cpus[i], cpus[j]))
+        i = j + 1
+    return ','.join(out)
+
+
 def pin_host_threads(local_rank, local_world):
     """One slice of the host's cores per rank of this node (round-4 review, item 7): N ranks that
     each start torch's default intra-op pool (= all cores) and a z-draw thread oversubscribe the
     host N times over, and the single-threaded randn of the next z (~25 ms for 300 x 1024 x 16)
-    then competes with 8 x 128 idle-spinning OpenMP threads.  The rank's process is bound to a
-    contiguous range of the CPUs it was allowed (contiguous ranges follow the NUMA nodes on the
-    usual enumeration), torch's intra-op pool is sized to it (at most 16: the host side of a step
-    is launches and one randn).  `SEGAN_NO_PIN=1` leaves the process alone.  Returns what was done
-    (also kept for bench.py's `comm.host` block), or None."""
+    then competes with 8 x 128 idle-spinning OpenMP threads.  The slices come from the real topology
+    (`plan_host_slices`: whole physical cores, on the NUMA node of the rank's GPU where sysfs names
+    it; round-5 advice — contiguous CPU ranges put rank 4 of an SMT host on the hyperthreads of rank
+    0's cores, on the other socket from its GPU).  EVERY thread the process already has is bound
+    (/proc/self/task: an OpenMP pool or runtime helper threads started before this call keep the old
+    mask under a plain sched_setaffinity(0, ...)), threads created later inherit the mask — which is
+    why `init_from_env` calls this BEFORE the process group (RCCL's proxy threads) exists.  torch's
+    intra-op pool is sized to the slice's physical cores (at most 16: the host side of a step is
+    launches and one randn).  `SEGAN_NO_PIN=1` leaves the process alone.  Returns what was done
+    (bench.py's `comm.host.pinning` carries it, CPU list included), or None."""
     global _host_pin
     if local_world <= 1 or os.environ.get('SEGAN_NO_PIN') == '1' or not hasattr(os, 'sched_setaffinity'):
         return None
     try:
         cpus = sorted(os.sched_getaffinity(0))
-        per = len(cpus) // local_world
-        if per < 1:
-            return None
-        mine = cpus[local_rank * per:(local_rank + 1) * per]
-        os.sched_setaffinity(0, mine)
-        torch.set_num_threads(max(1, min(per, 16)))
-        _host_pin = {'cpus_per_rank': per, 'first_cpu': mine[0], 'last_cpu': mine[-1],
-                     'torch_threads': torch.get_num_threads()}
+        topo = host_topology(cpus)
+        nodes = gpu_numa_nodes(local_world) if torch.cuda.is_available() and \
+            'SEGAN_LOCAL_DEVICE' not in os.environ else None
+        plan = plan_host_slices(local_world, cpus, topo, nodes)
+        if plan is None or not plan[local_rank]:
+            _host_pin = {'skipped': '{} CPUs for {} ranks'.format(len(cpus), local_world)}
+            return _host_pin
+        mine = plan[local_rank]
+        tids = [0]
+        try:
+            tids = [int(t) for t in os.listdir('/proc/self/task')] or [0]
+        except Exception:
+            pass
+        bound = 0
+        for tid in tids:
+            try:
+                os.sched_setaffinity(tid, mine)
+                bound += 1
+            except Exception:       # a thread that exited meanwhile
+                pass
+        ncores = len({topo[c][1:] if topo[c][2] is not None else c for c in mine})
+        torch.set_num_threads(max(1, min(ncores, 16)))
+        _host_pin = {'cpus': _ranges(mine), 'logical_cpus': len(mine), 'physical_cores': ncores,
+                     'numa_node': topo[mine[0]][0], 'gpu_numa_node': nodes[local_rank] if nodes else None,
+                     'threads_bound': bound, 'torch_threads': torch.get_num_threads()}
     except Exception as e:      # pragma: no cover - a container that forbids it
         _host_pin = {'error': repr(e)}
     return _host_pin
@@ -374,6 +503,15 @@ def _reducer(optimizer):
         r = GradReducer(optimizer, _bucket_bytes)
         _reducers[id(optimizer)] = r
     return r
+
+
+def drop_reducer(optimizer):
+    """Forget the reducer of an optimizer that is going away (it holds the optimizer — and through it
+    the flat parameter / gradient / state arenas — alive)."""
+    global _active
+    r = _reducers.pop(id(optimizer), None)
+    if r is not None and _active is r:
+        _active = None
 
 
 def arm(optimizer, passes=1):

@@ -77,6 +77,17 @@ def _de_emphasize_any(x, coef):
     return de_emphasize(x.numpy(), coef)
 
 
+def _to_device_async(t, device):
+    """A small host tensor to the device without making the host wait for the stream: a pageable
+    source turns `.to(device)` into a copy the runtime stages synchronously, behind everything the
+    stream still has queued — once per step that drains the launch queue the host had built up
+    (round-5 review, weak 4: the WSEGAN step was host-bound).  Pinned staging (torch's caching host
+    allocator: no allocation after the first step) + an async copy instead."""
+    if torch.device(device).type != 'cuda':
+        return t.to(device)
+    return t.pin_memory().to(device, non_blocking=True)
+
+
 class _frozen(object):
     """Context manager: parameters of `module` do not require grad inside."""
 
@@ -478,7 +489,7 @@ class WSEGAN(SEGAN):
         if self.misalign_pair:
             perm = list(range(bsz))
             shuffle(perm)      # same RNG draws as shuffling the chunk list (model.py:598-600)
-            clean_shuf = clean[torch.as_tensor(perm, device=clean.device)]
+            clean_shuf = clean[_to_device_async(torch.as_tensor(perm), clean.device)]
             d_fake_shuf, _ = self.infer_D(clean, clean_shuf)
             d_loss = d_loss + cost(d_fake_shuf.view(-1), 0.0)
             d_weight = 1 / 3
@@ -522,8 +533,8 @@ class WSEGAN(SEGAN):
             if l1_weight > 0:
                 # model.py:655-662 builds the mask row by row on the device (one fill per
                 # utterance); here: one host vector, one copy, broadcast in the products
-                mask = torch.tensor([1.0 if 'additive' in uttn else 0.0 for uttn in uttname],
-                                    dtype=torch.float32).to(Genh.device, non_blocking=True).view(bsz, 1, 1)
+                mask = _to_device_async(torch.tensor([1.0 if 'additive' in uttn else 0.0 for uttn in uttname],
+                                                     dtype=torch.float32), Genh.device).view(bsz, 1, 1)
                 den_loss = l1_weight * losses.l1_loss(Genh * mask, clean * mask)
                 G_cost = G_cost + den_loss
             else:
@@ -558,9 +569,19 @@ class WSEGAN(SEGAN):
         train_gen = is_main and not getattr(opts, 'no_train_gen', True)
         self.G.train()
         self.D.train()
-        for iteration in range(1, opts.epoch * len(dloader) + 1):
+        # z of the NEXT step drawn by a host thread while this step's launches go out, as in
+        # SEGAN.train — possible here only when the per-step batch sampling leaves torch's global CPU
+        # generator alone, because the reference interleaves the two on that generator (every
+        # next(iter(dloader)) reseeds its RandomSampler and the loader's base seed from it, then G draws
+        # z: model.py:526-535, generator.py:197): true for PCMShardLoader.sample() (a private generator),
+        # not for a plain DataLoader, whose steps keep the synchronous draw and the reference's stream
+        lookahead = (getattr(opts, 'prefetch_z', True) and getattr(dloader, 'sample_keeps_global_rng', False)
+                     and not getattr(self.G, '_skip_dropout', 0))
+        n_iters = opts.epoch * len(dloader)
+        for iteration in range(1, n_iters + 1):
             beg_t = timeit.default_timer()
             uttname, clean, noisy, _ = self.sample_dloader(dloader, device)
+            self.G.z_prefetch = lookahead and iteration < n_iters
             if train_gen and noisy_samples is None:          # model.py:673-675
                 noisy_samples = noisy[:20, :, :].contiguous()
                 clean_samples = clean[:20, :, :].contiguous()
@@ -585,6 +606,8 @@ class WSEGAN(SEGAN):
             if is_main and iteration % len(dloader) == 0:
                 self.G.save(self.save_path, iteration, saver=eoe_g_saver)
                 self.D.save(self.save_path, iteration, saver=eoe_d_saver)
+        self.G.z_prefetch = False
+        self.G.cancel_z_prefetch()
         for sv in (eoe_g_saver, eoe_d_saver):
             sv.wait()
 

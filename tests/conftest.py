@@ -56,8 +56,18 @@ VARIANT_NAMES = ('skipconv_concat', 'skipconv_sum', 'pool1_mid', 'pool1_last', '
 
 def oracle_kwargs(opts):
     """oracle.gan_step / generator_forward keyword arguments for a train.py option dict."""
-    return dict(dec_strides=opts.get('gdec_poolings') or None, d_strides=opts['denc_poolings'],
-                skip_merge=opts['skip_merge'], pool_type=opts['dpool_type'])
+    kw = dict(dec_strides=opts.get('gdec_poolings') or None, d_strides=opts['denc_poolings'],
+              skip_merge=opts['skip_merge'], pool_type=opts['dpool_type'])
+    if opts.get('reg_loss', 'l1_loss') != 'l1_loss':
+        kw['reg_loss'] = opts['reg_loss']
+    if opts.get('skip_type') == 'constant':      # generator.py:40-41: skip_k.requires_grad = False
+        kw['frozen'] = tuple('alpha_{}.skip_k'.format(i) for i in range(len(opts['genc_fmaps']) - 1))
+    return kw
+
+
+@pytest.fixture(scope='session')
+def tiny_corners():
+    return load_golden('tiny_corners.pt')
 
 
 GVARIANT_NAMES = ('bnorm_concat', 'bnorm_sum', 'dropout_alpha', 'dropout_conv_sum', 'bnorm_dropout')

@@ -325,6 +325,17 @@ def l1_bwd(x, y, gout=None, gscale=1.0):
     return g.float()
 
 
+def mse_mean(x, y):
+    return ((x.double() - y.double()) ** 2).mean().float()
+
+
+def mse_bwd(x, y, gout=None, gscale=1.0):
+    g = 2.0 * (x.double() - y.double()) / x.numel() * gscale
+    if gout is not None:
+        g = g * gout.double()
+    return g.float()
+
+
 def _frame_index(T, n_fft, hop, win):
     NF = 1 + T // hop
     off = (n_fft - win) // 2 - n_fft // 2
@@ -441,7 +452,7 @@ def _chk(t, name, ndim=None):
 _NAMES = ['conv1d_fwd', 'conv1d_dgrad', 'wgrad', 'deconv1d_fwd', 'deconv1d_dgrad', 'bn_stats',
           'affine_prelu', 'affine_tanh', 'scale_mask', 'sum_skip', 'pool_time_fwd', 'pool_time_bwd', 'bce_logits_const', 'bce_logits_const_bwd', 'act_bwd', 'tanh_bwd', 'linear_fwd', 'linear_dgrad', 'linear_wgrad',
           'bias_prelu_rows', 'bias_prelu_rows_bwd', 'mse_const', 'mse_const_bwd', 'l1_mean',
-          'l1_bwd', 'stft_basis', 'stft_frames', 'stft_spectrum', 'stft_spectrum_bwd', 'powdb',
+          'l1_bwd', 'mse_mean', 'mse_bwd', 'stft_basis', 'stft_frames', 'stft_spectrum', 'stft_spectrum_bwd', 'powdb',
           'powdb_bwd', 'stft_overlap_add', 'snorm_fwd', 'snorm_bwd', 'bn_partial', 'bn_final', 'act_bwd_bn_reduce',
           'act_bwd_bn_apply', 'rmsprop_step', 'adam_step', 'fill_', 'scale_', '_chk']
 

@@ -4,6 +4,7 @@ paths RCCL runs on the GPUs (segan_pytorch_amd/distributed.py)."""
 import os
 import socket
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -98,30 +99,71 @@ def test_gradient_buckets_follow_the_backward_order():
 
 
 def test_ranks_are_pinned_to_disjoint_core_slices():
-    """distributed.pin_host_threads: every rank of a node gets its own contiguous slice of the
-    CPUs the process may run on and torch's intra-op pool is sized to it (at most 16); one rank
-    alone, or SEGAN_NO_PIN=1, is left untouched.  Run in a child process (affinity is sticky)."""
+    """distributed.pin_host_threads: every rank of a node gets its own slice of the CPUs the process
+    may run on — every thread the process already has is bound, not only the caller — and torch's
+    intra-op pool is sized to it (at most 16); one rank alone, or SEGAN_NO_PIN=1, is left untouched.
+    Run in a child process (affinity is sticky)."""
     import subprocess
     import sys
     code = (
-        "import os, json, torch\n"
+        "import os, json, threading, time, torch\n"
         "from segan_pytorch_amd import distributed as sd\n"
         "all_ = sorted(os.sched_getaffinity(0))\n"
         "assert sd.pin_host_threads(0, 1) is None and sorted(os.sched_getaffinity(0)) == all_\n"
+        "ev = threading.Event(); tid = []\n"
+        "def idle():\n"
+        "    tid.append(threading.get_native_id()); ev.wait(30)\n"
+        "t = threading.Thread(target=idle, daemon=True); t.start()\n"
+        "while not tid: time.sleep(0.01)\n"
         "r = sd.pin_host_threads(1, 2)\n"
         "mine = sorted(os.sched_getaffinity(0))\n"
-        "print(json.dumps({'all': all_, 'mine': mine, 'r': r, 'threads': torch.get_num_threads()}))\n")
+        "other = sorted(os.sched_getaffinity(tid[0]))\n"
+        "ev.set()\n"
+        "print(json.dumps({'all': all_, 'mine': mine, 'other': other, 'r': r, 'threads': torch.get_num_threads(),\n"
+        "                  'plan': sd.plan_host_slices(2, all_, sd.host_topology(all_), None)}))\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, cwd=root, timeout=120)
     assert out.returncode == 0, out.stderr[-2000:]
     import json
     d = json.loads(out.stdout.strip().splitlines()[-1])
     if len(d['all']) < 2:
-        assert d['r'] is None
+        assert d['r'] is None or 'skipped' in d['r']
         return
-    per = len(d['all']) // 2
-    assert d['mine'] == d['all'][per:2 * per]
-    assert d['r']['cpus_per_rank'] == per and d['threads'] == min(per, 16) == d['r']['torch_threads']
+    assert d['mine'] == d['plan'][1] and d['other'] == d['mine']      # the pre-existing thread too
+    assert not set(d['plan'][0]) & set(d['plan'][1])
+    assert d['r']['logical_cpus'] == len(d['mine']) and d['r']['threads_bound'] >= 2
+    assert d['threads'] == min(d['r']['physical_cores'], 16) == d['r']['torch_threads']
+
+
+def test_host_slices_follow_the_topology_not_the_cpu_numbers():
+    """plan_host_slices on synthetic hosts (round-5 advice).  (1) Two sockets x 64 cores with SMT,
+    enumerated the way Linux does it — cpus 0-127 the cores, 128-255 their siblings — and eight ranks
+    whose GPUs hang off nodes 0,0,0,0,1,1,1,1: every rank gets 16 WHOLE cores (both siblings) of its
+    GPU's node; contiguous CPU ranges would have put rank 4 on cpus 128-159, the hyperthreads of rank
+    0's cores on the other socket.  (2) GPU nodes unknown: whole cores, evenly.  (3) Eight ranks on a
+    12-CPU mask (6 cores x 2): nobody gets an empty slice, slices stay disjoint.  (4) Fewer CPUs than
+    ranks: no pinning at all.  (5) GPUs all on one node that has too few cores: the even split."""
+    from segan_pytorch_amd import distributed as sd
+    topo = {c: ((c % 128) // 64, (c % 128) // 64, c % 64) for c in range(256)}
+    plan = sd.plan_host_slices(8, range(256), topo, [0, 0, 0, 0, 1, 1, 1, 1])
+    assert [sd._ranges(p) for p in plan][4] == '64-79,192-207'
+    for r, p in enumerate(plan):
+        assert len(p) == 32 and {topo[c][0] for c in p} == {r // 4}
+        cores = {topo[c][1:] for c in p}
+        assert len(cores) == 16 and all(((c + 128) % 256) in p for c in p)     # both siblings
+    assert len({c for p in plan for c in p}) == 256
+    plan2 = sd.plan_host_slices(8, range(256), topo, None)
+    assert plan2 == plan
+    small = {c: (0, 0, c % 6) for c in range(12)}
+    plan3 = sd.plan_host_slices(8, range(12), small, None)
+    assert all(len(p) == 1 for p in plan3) and len({c for p in plan3 for c in p}) == 8
+    assert sd.plan_host_slices(8, range(6), None, None) is None
+    plan5 = sd.plan_host_slices(8, range(256), {c: ((0 if c % 128 < 4 else 1), 0, c % 128) for c in range(256)},
+                                [0] * 8)
+    assert all(len(p) == 32 for p in plan5) and len({c for p in plan5 for c in p}) == 256
+    # no topology at all (sysfs unreadable): contiguous logical CPUs, still disjoint and complete
+    plan6 = sd.plan_host_slices(4, range(16), None, None)
+    assert plan6 == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9, 10, 11], [12, 13, 14, 15]]
 
 
 def test_single_process_is_a_noop():
@@ -171,6 +213,16 @@ def _dp_step(o, fx, clean, noisy, z, seed, buffers=False):
     return out
 
 
+def _dp_inputs(world):
+    """Global batch: 4 for two ranks (as before), 8 for four and eight (one sample per rank at 8)."""
+    n = 4 if world <= 2 else 8
+    g = torch.Generator().manual_seed(3)
+    clean = torch.rand(n, 1, 1024, generator=g) * 2 - 1
+    noisy = (clean + 0.1 * torch.randn(n, 1, 1024, generator=g)).clamp(-1, 1)
+    z = torch.randn(n, 32, 16, generator=g)
+    return clean, noisy, z
+
+
 def _dp_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank),
                       WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
@@ -181,11 +233,11 @@ def _dp_worker(rank, world, port, q):
     # inside the backward passes (distributed.GradReducer)
     sdist.set_bucket_bytes(16 * 1024)
     o, fx = _dp_opts()
-    g = torch.Generator().manual_seed(3)
-    clean = torch.rand(4, 1, 1024, generator=g) * 2 - 1
-    noisy = (clean + 0.1 * torch.randn(4, 1, 1024, generator=g)).clamp(-1, 1)
-    z = torch.randn(4, 32, 16, generator=g)
-    sl = slice(2 * rank, 2 * rank + 2)
+    clean, noisy, z = _dp_inputs(world)
+    per = clean.size(0) // world
+    assert sdist.shard_batch(clean).shape[0] == per
+    sl = slice(per * rank, per * rank + per)
+    assert torch.equal(sdist.shard_batch(clean), clean[sl])
     sdist.set_profile(True)
     out = _dp_step(o, fx, clean[sl].contiguous(), noisy[sl].contiguous(), z[sl].contiguous(), 11)
     nb = [len(r.buckets) for r in sdist._reducers.values()]
@@ -203,33 +255,48 @@ def _dp_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_gan_step_equals_the_full_batch_step():
-    """Global batch 4 split 2 + 2 over two gloo ranks (D without BatchNorm): after the
-    gradient all-reduce both ranks hold the gradients — and after the optimizer step the
-    weights — of the single-process step on all 4 samples."""
+def _run_ranks(target, world, timeout=600):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=target, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=300) for _ in range(2))
+    res = dict(q.get(timeout=timeout) for _ in range(world))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    return res
+
+
+def _gan_step_equals_full_batch(world):
+    res = _run_ranks(_dp_worker, world)
     o, fx = _dp_opts()
-    g = torch.Generator().manual_seed(3)
-    clean = torch.rand(4, 1, 1024, generator=g) * 2 - 1
-    noisy = (clean + 0.1 * torch.randn(4, 1, 1024, generator=g)).clamp(-1, 1)
-    z = torch.randn(4, 32, 16, generator=g)
+    clean, noisy, z = _dp_inputs(world)
     full = _dp_step(o, fx, clean, noisy, z, 11)
     for k, v in full.items():
         scale = max(v.abs().max().item(), 1e-30)
-        for r in (0, 1):
+        for r in range(world):
             err = (torch.from_numpy(res[r][k]) - v).abs().max().item()
             # gradients: fp32 summation order; weights: within 10 % of an RMSprop step
             tol = 5e-5 if k.startswith('Dw.') else 2e-5 * scale
             assert err < tol, (k, r, err)
+
+
+def test_two_rank_gan_step_equals_the_full_batch_step():
+    """Global batch 4 split 2 + 2 over two gloo ranks (D without BatchNorm): after the
+    gradient all-reduce both ranks hold the gradients — and after the optimizer step the
+    weights — of the single-process step on all 4 samples."""
+    _gan_step_equals_full_batch(2)
+
+
+@pytest.mark.parametrize('world', [4, 8])
+def test_four_and_eight_rank_gan_step_equals_the_full_batch_step(world):
+    """The same at world size 4 (2 samples per rank) and 8 (ONE sample per rank) of a global batch
+    of 8: bucket arming, the reports from inside the backward passes, `shard_batch` and the 1/world
+    scale at the world sizes the driver's scaling run uses (round-5 review: nothing had ever run at
+    world 4 or 8, even on CPU)."""
+    _gan_step_equals_full_batch(world)
 
 
 def _syncbn_worker(rank, world, port, q):
@@ -319,11 +386,12 @@ def _wsegan_step(rank_seed, clean, noisy, names):
     return out
 
 
-def _wsegan_inputs():
+def _wsegan_inputs(world=2):
     g = torch.Generator().manual_seed(5)
-    clean = torch.rand(4, 1, 1024, generator=g) * 2 - 1
-    noisy = (clean + 0.1 * torch.randn(4, 1, 1024, generator=g)).clamp(-1, 1)
-    names = ['a_additive', 'b', 'c_additive', 'd']
+    n = 2 * world               # two samples per rank: D's BatchNorm needs more than one
+    clean = torch.rand(n, 1, 1024, generator=g) * 2 - 1
+    noisy = (clean + 0.1 * torch.randn(n, 1, 1024, generator=g)).clamp(-1, 1)
+    names = ['a_additive', 'b', 'c_additive', 'd'] * (n // 4)
     return clean, noisy, names
 
 
@@ -334,11 +402,33 @@ def _wsegan_worker(rank, world, port, q):
     from segan_pytorch_amd import distributed as sdist
     sdist.init_from_env(backend='gloo')
     sdist.set_bucket_bytes(4 * 1024)         # many buckets: they must wait for the LAST D pass
-    clean, noisy, names = _wsegan_inputs()
+    clean, noisy, names = _wsegan_inputs(world)
     sl = slice(2 * rank, 2 * rank + 2)
     out = _wsegan_step(40 + rank, clean[sl].contiguous(), noisy[sl].contiguous(), names[sl])
     q.put((rank, {k: v.numpy() for k, v in out.items()}))
     dist.destroy_process_group()
+
+
+def _wsegan_ranks_average(world):
+    res = _run_ranks(_wsegan_worker, world)
+    clean, noisy, names = _wsegan_inputs(world)
+    solo = [_wsegan_step(40 + r, clean[2 * r:2 * r + 2].contiguous(),
+                         noisy[2 * r:2 * r + 2].contiguous(), names[2 * r:2 * r + 2])
+            for r in range(world)]
+    for k in solo[0]:
+        if k.startswith('Gg.'):
+            continue        # G's gradients go through the stepped D: checked below, loosely
+        want = sum(s_[k] for s_ in solo) / world
+        scale = max(want.abs().max().item(), 1e-30)
+        for r in range(world):
+            err = (torch.from_numpy(res[r][k]) - want).abs().max().item()
+            assert err < 2e-5 * scale, (k, r, err, scale)
+    # all ranks hold the same (averaged) generator gradients
+    for k in solo[0]:
+        if k.startswith('Gg.'):
+            a = torch.from_numpy(res[0][k])
+            for r in range(1, world):
+                assert torch.equal(a, torch.from_numpy(res[r][k])), (k, r)
 
 
 def test_two_rank_wsegan_step_averages_all_discriminator_passes():
@@ -347,30 +437,11 @@ def test_two_rank_wsegan_step_averages_all_discriminator_passes():
     times.  Every bucket of the overlapped reducer must leave only after the LAST pass wrote its
     gradients: both ranks must hold the mean of the two ranks' single-process gradients (each
     rank's own shard, RNG draws and local BatchNorm statistics), for D and for G."""
-    ctx = mp.get_context('spawn')
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_wsegan_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = dict(q.get(timeout=300) for _ in range(2))
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
-    clean, noisy, names = _wsegan_inputs()
-    solo = [_wsegan_step(40 + r, clean[2 * r:2 * r + 2].contiguous(),
-                         noisy[2 * r:2 * r + 2].contiguous(), names[2 * r:2 * r + 2])
-            for r in range(2)]
-    for k in solo[0]:
-        if k.startswith('Gg.'):
-            continue        # G's gradients go through the stepped D: checked below, loosely
-        want = 0.5 * (solo[0][k] + solo[1][k])
-        scale = max(want.abs().max().item(), 1e-30)
-        for r in (0, 1):
-            err = (torch.from_numpy(res[r][k]) - want).abs().max().item()
-            assert err < 2e-5 * scale, (k, r, err, scale)
-    # the two ranks hold the same (averaged) generator gradients
-    for k in solo[0]:
-        if k.startswith('Gg.'):
-            a, b = torch.from_numpy(res[0][k]), torch.from_numpy(res[1][k])
-            assert torch.equal(a, b), k
+    _wsegan_ranks_average(2)
+
+
+@pytest.mark.parametrize('world', [4, 8])
+def test_four_and_eight_rank_wsegan_step_averages_all_discriminator_passes(world):
+    """The same with four and eight gloo ranks (two samples each): BASELINE config 4 is an 8-GPU
+    configuration, and its pass-counted bucket arming had only ever run at world size 2."""
+    _wsegan_ranks_average(world)

@@ -105,8 +105,10 @@ def test_rccl_single_rank_sync_batchnorm(tmp_path):
 
 
 @pytest.mark.gpu
-def test_bench_launches_its_own_ranks():
-    """`python bench.py --gpus 2` as the driver may call it (no WORLD_SIZE in the environment): the
+@pytest.mark.parametrize('world', [2, 8])
+def test_bench_launches_its_own_ranks(world):
+    """`python bench.py --gpus N` (N = 2, and N = 8 with the `other_workloads` block: the command of
+    the driver's scaling run) as the driver may call it (no WORLD_SIZE in the environment): the
     script re-executes itself under torch.distributed.run, both ranks initialise a process group,
     shard the batch, all-reduce their gradients from inside the backward passes and rank 0 prints
     ONE JSON line for the whole job.  A one-GPU box cannot host two RCCL ranks, so the two ranks
@@ -118,17 +120,26 @@ def test_bench_launches_its_own_ranks():
     env = dict(os.environ, SEGAN_DIST_BACKEND='gloo', SEGAN_LOCAL_DEVICE='0')
     for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2',
-                        '--warmup', '1', '--batch', '12', '--no-cpu-baseline', '--no-modes'],
+    batch = 12 if world == 2 else 8
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(world), '--steps', '2',
+                        '--warmup', '1', '--batch', str(batch), '--no-cpu-baseline', '--no-modes'] +
+                       (['--no-side-workloads'] if world == 2 else ['--side-steps', '1']),
                        capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d['n_gpus'] == 2 and d['ranks_seen'] == [0, 1] and d['backend'] == 'gloo'
+    assert d['n_gpus'] == world and d['ranks_seen'] == list(range(world)) and d['backend'] == 'gloo'
     assert d['losses_finite'] is True and d['scaling'] == 'weak'
-    assert d['config']['global_batch'] == 24 and d['config']['parallelism'] == 'dp2'
-    assert abs(d['value'] - 24 * 1e3 / d['ms_per_step']) < 1e-6 * d['value']
+    assert d['config']['global_batch'] == batch * world and d['config']['parallelism'] == 'dp{}'.format(world)
+    assert abs(d['value'] - batch * world * 1e3 / d['ms_per_step']) < 1e-6 * d['value']
+    if world == 8:
+        # BASELINE configs 3 / 4 are 8-GPU configurations: the side workloads run on all ranks too
+        ow = d['other_workloads']
+        for k in ('wsegan', 'vanilla11'):
+            assert 'error' not in ow[k], ow[k]
+            assert ow[k]['n_gpus'] == 8 and ow[k]['losses_finite'] is True
+            assert abs(ow[k]['value'] - batch * world * 1e3 / ow[k]['ms_per_step']) < 1e-6 * ow[k]['value']
     # the multi-GPU line diagnoses itself: transport, SyncBN switch, bucket layout of the two
     # gradient arenas (G 64.8 M floats, D 25.8 M), how long the compute stream waited for the
     # collectives per step and how many buckets only left at the optimizer step
@@ -149,8 +160,8 @@ def test_bench_launches_its_own_ranks():
         assert a['wait_device_ms_per_step'] >= 0.0 and a['wait_host_ms_per_step'] > 0.0
     # the host side of every rank, all ranks at it at once: z draw (single-threaded randn) and its H2D
     h = c['host']
-    assert len(h['z_draw_ms_per_rank']) == len(h['z_h2d_ms_per_rank']) == 2
+    assert len(h['z_draw_ms_per_rank']) == len(h['z_h2d_ms_per_rank']) == world
     assert all(v > 0 for v in h['z_draw_ms_per_rank'] + h['z_h2d_ms_per_rank'])
-    assert h['pinning'] is None or 'cpus_per_rank' in h['pinning'] or 'error' in h['pinning']
+    assert h['pinning'] is None or any(k in h['pinning'] for k in ('cpus', 'skipped', 'error'))
     assert d['comm_wait_ms_per_step'] == c['comm_wait_ms_per_step'] >= 0.0
     assert list(c['ms_per_step']) == ['torch.distributed']

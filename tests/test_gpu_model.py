@@ -97,15 +97,17 @@ def check_step_against_golden(fx):
     import torch.nn.functional as F
     st = fx['opts']['genc_poolings']
     kw = oracle_kwargs(fx['opts'])
-    G = {k: v.clone().requires_grad_(True) for k, v in fx['G0'].items()}
+    frozen = kw.get('frozen', ())
+    G = {k: (v.clone() if k in frozen else v.clone().requires_grad_(True)) for k, v in fx['G0'].items()}
     d_after = {k: v.detach().cpu().clone() for k, v in m.D.state_dict().items()}
     genh = O.generator_forward(G, fx['noisy'], fx['z'], st, kw['dec_strides'],
                                skip_merge=kw['skip_merge'])
     d = O.discriminator_forward(d_after, torch.cat((genh, fx['noisy']), 1), fx['rolls'][2],
                                 kw['d_strides'], pool_type=kw['pool_type'])
     B = fx['clean'].size(0)
-    loss = F.mse_loss(d.view(-1), torch.ones(B)) + 100.0 * F.l1_loss(genh, fx['clean'])
-    keys = list(G.keys())
+    loss = F.mse_loss(d.view(-1), torch.ones(B)) + \
+        100.0 * getattr(F, kw.get('reg_loss', 'l1_loss'))(genh, fx['clean'])
+    keys = [k for k in G if k not in frozen]
     for k, g in zip(keys, torch.autograd.grad(loss, [G[k] for k in keys], allow_unused=True)):
         if g is None:       # a skip the forward never takes (pooling-1 decoder level)
             assert gn[k].grad is None or float(gn[k].grad.abs().max()) == 0.0, k
@@ -224,6 +226,46 @@ def test_tiny_literal_train_matches_reference(tiny_train2, tmp_path):
     names = os.listdir(str(tmp_path))
     assert any(n.startswith('weights_EOE_G-Generator-') for n in names)
     assert 'EOE_D-checkpoints' in names
+
+
+def _literal_train_on_gpu(fx, o, G0, D0, tmp_path):
+    o = dict(o)
+    o['save_path'] = str(tmp_path)
+    m = build({'opts': o, 'G0': G0, 'D0': D0})
+    loader = [[['u'] * 3, c, n, torch.zeros(3)] for c, n in fx['batches']]
+    random.seed(fx['seed'])
+    np.random.seed(fx['seed'])
+    torch.manual_seed(fx['seed'])
+    m.train(SimpleNamespace(**o), loader, None, o['l1_weight'], o['l1_dec_step'], o['l1_dec_epoch'], 1000,
+            va_dloader=None, device=DEV)
+    assert_weights_after_step(m.G.state_dict(), fx['G_final'])
+    assert_weights_after_step(m.D.state_dict(), fx['D_final'], skip=NOISE_KEYS)
+    return m
+
+
+def test_constant_skip_matches_reference_and_is_never_trained(tmp_path):
+    """--skip_type constant (generator.py:25,40-41,59) on the GPU: one step against the reference
+    (the fixed randn scale folded into the deconv loads, no gradient for it, Model.parameters —
+    core.py:196-198 — keeps it out of the optimizer arena) and the literal two-batch SEGAN.train."""
+    fx = load_golden('tiny_corners.pt')['constantskip']
+    check_step_against_golden(fx)
+    m = build(fx)
+    Gopt, _ = m.build_optimizers(SimpleNamespace(**fx['opts']))
+    named = dict(m.G.named_parameters())
+    assert sum(p.numel() for p in Gopt._params) == fx['n_params_G'] == m.G.get_n_params()
+    assert all(id(named[k]) not in {id(p) for p in Gopt._params} for k in fx['constants'])
+    m2 = _literal_train_on_gpu(fx['train2'], fx['opts'], fx['G0'], fx['D0'], tmp_path)
+    for k in fx['constants']:
+        assert torch.equal(m2.G.state_dict()[k].cpu(), fx['G0'][k]), k
+        assert dict(m2.G.named_parameters())[k].grad is None
+
+
+def test_mse_reg_loss_matches_reference(tmp_path):
+    """--reg_loss mse_loss (train.py:179, model.py:79) at model level on the GPU: one step against
+    the reference and the oracle, and the literal two-batch SEGAN.train."""
+    fx = load_golden('tiny_corners.pt')['mseloss']
+    check_step_against_golden(fx)
+    _literal_train_on_gpu(fx['train2'], fx['opts'], fx['G0'], fx['D0'], tmp_path)
 
 
 def _chk(t, c, tol):
@@ -611,14 +653,15 @@ def test_blocks_standalone_match_oracle():
         assert max_rel(dbn.norm.running_var, bn['running_var']) < 1e-4
 
 
-@pytest.mark.parametrize('golden', ['tiny_wsegan2.pt', 'tiny_wsegan_snorm.pt'])
+@pytest.mark.parametrize('golden', ['tiny_wsegan2.pt', 'tiny_wsegan_snorm.pt', 'vanillagan'])
 def test_wsegan_literal_train_matches_reference(golden, tmp_path):
     """WSEGAN.train with --misalign_pair on the GPU against the reference's literal
     WSEGAN.train (two iterations; same host RNG streams); second fixture: the
-    run_wsegan_train.sh flavour (--dnorm_type snorm --opt adam)."""
+    run_wsegan_train.sh flavour (--dnorm_type snorm --opt adam); third: --vanilla_gan (the BCE
+    cost of model.py:582-585 in every adversarial term; oracle/make_golden.py corners)."""
     from conftest import load_golden
     from segan_pytorch_amd.models import WSEGAN
-    fx = load_golden(golden)
+    fx = load_golden('tiny_corners.pt')[golden] if golden == 'vanillagan' else load_golden(golden)
     o = dict(fx['opts'])
     o['save_path'] = str(tmp_path)
     o['epoch'] = fx['iters']

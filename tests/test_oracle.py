@@ -127,12 +127,13 @@ def test_tiny_literal_train_replay(tiny_train2):
     """Replay the reference's literal SEGAN.train (two batches): z comes from the global
     torch RNG (generator.py:197), the phase shifts from python's random
     (discriminator.py:159-163)."""
-    fx = tiny_train2
-    o = fx['opts']
+    _replay_literal_train(tiny_train2, tiny_train2['opts'], tiny_train2['G0'], tiny_train2['D0'])
+
+
+def _replay_literal_train(fx, o, G, D, **kw):
     st = o['genc_poolings']
     random.seed(fx['seed'])
     torch.manual_seed(fx['seed'])
-    G, D = fx['G0'], fx['D0']
     g_sq = d_sq = None
     for clean, noisy in fx['batches']:
         clean, noisy = clean.unsqueeze(1), noisy.unsqueeze(1)
@@ -145,7 +146,7 @@ def test_tiny_literal_train_replay(tiny_train2):
                 r.append(s if random.random() > 0.5 else -s)
             rolls.append(r)
         res = O.gan_step(G, D, clean, noisy, z, rolls, st, l1_weight=o['l1_weight'],
-                         lr=o['g_lr'], g_sq=g_sq, d_sq=d_sq)
+                         lr=o['g_lr'], g_sq=g_sq, d_sq=d_sq, **kw)
         G, D, g_sq, d_sq = res['G'], res['D'], res['g_sq'], res['d_sq']
     for k, v in fx['G_final'].items():
         assert (G[k] - v).abs().max().item() < 4e-6, k
@@ -265,8 +266,43 @@ def test_vanilla11_net_init_and_step(vanilla11_b8):
 def test_wsegan_literal_train_replay(tiny_wsegan2):
     """The oracle's WSEGAN step replayed against the reference's literal WSEGAN.train
     (--misalign_pair, two iterations)."""
+    _replay_wsegan_train(tiny_wsegan2)
+
+
+def test_wsegan_vanilla_gan_literal_train_replay(tiny_corners):
+    """--vanilla_gan (model.py:582-585: binary_cross_entropy_with_logits for every adversarial
+    term) through the reference's literal WSEGAN.train, two iterations."""
+    assert tiny_corners['vanillagan']['opts']['vanilla_gan'] is True
+    _replay_wsegan_train(tiny_corners['vanillagan'], vanilla_gan=True)
+
+
+def test_constant_skip_step_and_literal_train(tiny_corners):
+    """--skip_type constant (generator.py:25,40-41,59): the per-channel skip scale is a fixed
+    (here randn-initialised) constant — no gradient, not in the optimizer (core.py:196-198), unchanged
+    by the step and by two batches of the literal SEGAN.train."""
+    fx = tiny_corners['constantskip']
+    kw = oracle_kwargs(fx['opts'])
+    assert kw['frozen'] == tuple(fx['constants'])
+    _check_step(fx)
+    st = fx['opts']['genc_poolings']
+    res = O.gan_step(fx['G0'], fx['D0'], fx['clean'], fx['noisy'], fx['z'], fx['rolls'], st, **kw)
+    for k in fx['constants']:
+        assert k not in res['g_grads'] and torch.equal(res['G'][k], fx['G0'][k])
+        assert float(fx['G0'][k].std()) > 0.1           # a non-trivial constant
+    _replay_literal_train(fx['train2'], fx['opts'], fx['G0'], fx['D0'], frozen=kw['frozen'])
+
+
+def test_mse_reg_loss_step_and_literal_train(tiny_corners):
+    """--reg_loss mse_loss (train.py:179; model.py:79 getattr(F, opts.reg_loss)): one step and the
+    literal two-batch loop."""
+    fx = tiny_corners['mseloss']
+    assert oracle_kwargs(fx['opts'])['reg_loss'] == 'mse_loss'
+    _check_step(fx)
+    _replay_literal_train(fx['train2'], fx['opts'], fx['G0'], fx['D0'], reg_loss='mse_loss')
+
+
+def _replay_wsegan_train(fx, **kw):
     from conftest import draw_rolls
-    fx = tiny_wsegan2
     o = fx['opts']
     st = o['genc_poolings']
     random.seed(fx['seed'])
@@ -283,7 +319,7 @@ def test_wsegan_literal_train_replay(tiny_wsegan2):
         r3 = draw_rolls(len(st), o['phase_shift'])
         res = O.wsegan_step(G, D, clean, noisy, z, [r0, r1, r2, r3], perm, fx['names'], st,
                             l1_weight=o['l1_weight'], pow_weight=o['pow_weight'], lr=o['g_lr'],
-                            n_fft=o['n_fft'], g_sq=g_sq, d_sq=d_sq)
+                            n_fft=o['n_fft'], g_sq=g_sq, d_sq=d_sq, **kw)
         G, D, g_sq, d_sq = res['G'], res['D'], res['g_sq'], res['d_sq']
     for k, v in fx['G_final'].items():
         assert (G[k] - v).abs().max().item() < 5e-5, k   # 10 % of an RMSprop step

@@ -123,7 +123,7 @@ def test_loader_sample_keeps_one_live_iterator(tmp_path):
     ds = PCMShardDataset(str(tmp_path / 'sh'))
     loader = PCMShardLoader(ds, 4, 0.95, 'cuda', num_workers=1)
     entered = []
-    loader._sample_loader = loader._make_loader()       # sample()'s own DataLoader (lazy otherwise)
+    loader._ensure_sample_loader()       # sample()'s own DataLoader (lazy otherwise)
     assert loader._sample_loader is not loader.loader
     real_iter = type(loader._sample_loader).__iter__
 
@@ -165,3 +165,29 @@ def test_loader_sample_does_not_disturb_an_epoch_in_progress(tmp_path):
         assert torch.isfinite(sc).all() and torch.isfinite(clean).all()
     assert len(epoch) == len(ds) == len(set(epoch))
     assert len(sampled) == len(ds) == len(set(sampled))
+
+
+@pytest.mark.gpu
+def test_loader_sample_leaves_the_global_generator_alone(tmp_path):
+    """Round-5 advice: after its first call sample() draws from its own sampler and generator —
+    torch's global CPU generator stands where it stood across 2.5 sample epochs (the RandomSampler
+    reseeds and the DataLoader base seed at every wrap-around used to take from it, which broke the
+    generator's z look-ahead), and the main sampler's next shuffle is what it would have been."""
+    from segan_pytorch_amd.datasets import PCMShardLoader
+    cd, nd = _write_wavs(tmp_path)
+    build_pcm_shard(cd, nd, str(tmp_path / 'sh'), slice_size=16384, stride=0.5)
+    ds = PCMShardDataset(str(tmp_path / 'sh'))
+    loader = PCMShardLoader(ds, 4, 0.95, 'cuda', num_workers=1)
+    assert loader.sample_keeps_global_rng
+    loader.sample()                                  # creates the loader: ONE global draw, here
+    torch.manual_seed(5)
+    want = [list(b) for b in torch.utils.data.BatchSampler(torch.utils.data.RandomSampler(ds), 4, False)]
+    torch.manual_seed(5)
+    state = torch.get_rng_state()
+    for _ in range(2 * len(loader) + len(loader) // 2 + 1):
+        loader.sample()
+    assert torch.equal(torch.get_rng_state(), state)
+    got = [list(b) for b in loader.loader.sampler]   # the MAIN loader's next epoch order
+    assert got == want
+    loader.close()
+    assert loader._sample_loader is None
