@@ -2,6 +2,7 @@
 #include "segan_common.h"
 #include <string.h>
 #include <stdlib.h>
+#include <atomic>
 
 static thread_local char g_err[512] = "";
 
@@ -21,18 +22,28 @@ int segan_check_launch(const char* what) {
   return SEGAN_OK;
 }
 
-static int g_reserved_slots = -1;      // -1: not set yet (environment default)
+// Process-wide, read by the launch planners of every thread while segan_set_reserved_slots may be
+// writing it from another one (the header advertises the setter for hosts with concurrent streams
+// and threads): an atomic, initialised from the environment exactly once (round-5 advice).
+static std::atomic<int> g_reserved_slots{-1};      // -1: not set yet (environment default)
+static int reserved_slots_env(void) {
+  const char* e = getenv("SEGAN_RESERVED_SLOTS");
+  const int v = e ? atoi(e) : 0;
+  return v < 0 ? 0 : (v > 512 ? 512 : v);
+}
 int segan_reserved_slots_value(void) {
-  if (g_reserved_slots < 0) {
-    const char* e = getenv("SEGAN_RESERVED_SLOTS");
-    const int v = e ? atoi(e) : 0;
-    g_reserved_slots = v < 0 ? 0 : (v > 512 ? 512 : v);
+  int v = g_reserved_slots.load(std::memory_order_relaxed);
+  if (v < 0) {
+    int expected = -1;
+    const int env = reserved_slots_env();
+    // the first reader publishes the environment default; a concurrent setter's value wins
+    v = g_reserved_slots.compare_exchange_strong(expected, env, std::memory_order_relaxed) ? env : expected;
   }
-  return g_reserved_slots;
+  return v;
 }
 extern "C" int segan_set_reserved_slots(int n) {
   const int prev = segan_reserved_slots_value();
-  g_reserved_slots = n < 0 ? 0 : (n > 512 ? 512 : n);
+  g_reserved_slots.store(n < 0 ? 0 : (n > 512 ? 512 : n), std::memory_order_relaxed);
   return prev;
 }
 

@@ -1274,7 +1274,7 @@ static int resident_per_cu(K kern, size_t lds, int (&occ)[16], size_t (&occ_lds)
 // last partial round are cut along the contraction across all workgroups (slabs in the
 // caller's scratch + corr_fixup_kernel; without enough scratch the launch stays classic).
 static unsigned plan_streamk(CorrArgs& a, int ntiles, int nch, int occ, size_t slab_floats,
-                             bool allow) {
+                             bool allow, bool pair_cuts = false) {
   a.sk_nfull = ntiles;
   a.sk_units = 1;
   a.sk_total = 0;
@@ -1294,9 +1294,11 @@ static unsigned plan_streamk(CorrArgs& a, int ntiles, int nch, int occ, size_t s
   if (rem == 0) return (unsigned)ntiles;
   a.sk_total = (long)rem * nch;
   a.sk_units = (int)((a.sk_total + G - 1) / G);
-  // paired channels (f_pair: nch = the even channel count): cuts on even chunks only, so that
-  // every piece is whole (A, B) pairs
-  if (a.f_pair) a.sk_units += a.sk_units & 1;
+  // paired channels (corr2_kernel with f_pair: a chunk is ONE channel, nch = the even channel
+  // count): cuts on even chunks only, so that every piece is whole (A, B) pairs.  corr_kernel does
+  // not pair (it zeroes the borrowed row while staging and runs the plain 16 steps), its pieces may
+  // be odd (round-5 advice)
+  if (pair_cuts) a.sk_units += a.sk_units & 1;
   return (unsigned)G;
 }
 
@@ -1352,7 +1354,11 @@ static int launch_corr2_x(CorrArgs a, hipStream_t st, bool allow_sk) {
   const int ntiles = (nrowtiles - a.rt0) * a.ncoltiles;
   const int nch = ceil_div(a.Ktot, KC);
   const unsigned grid = plan_streamk(a, ntiles, nch, resident_per_cu(kern, lds, occ, occ_lds),
-                                     (size_t)MB * NB, allow_sk);
+                                     (size_t)MB * NB, allow_sk, a.f_pair != 0);
+  // the pair loop of corr2_kernel runs one_chunk(ch) and one_chunk(ch + 1) unconditionally: every
+  // piece it is handed must start and end on an even chunk
+  SEGAN_REQUIRE(!a.f_pair || ((nch & 1) == 0 && (a.sk_total == 0 || (a.sk_units & 1) == 0)),
+                "corr2: paired channels need even pieces (nch=%d, sk_units=%d)", nch, a.sk_units);
   segan_note_corr_launch(2, grid, a, ntiles);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
   if (int e = segan_check_launch("corr2_kernel")) return e;
