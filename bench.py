@@ -567,9 +567,10 @@ def measure_host(one_step, reps=5):
       after: python + ctypes + the caching allocator + the HIP launches of one step, no GPU in the way
       (median of `reps`; any hidden device sync inside the step would show up here as a step time);
     * gpu_ms_per_step_unstarved — HIP-event time of one step whose launches were ALL enqueued while the
-      device was still busy with a blocker (torch.cuda._sleep, sized above the enqueue time): the step as
-      the GPU executes it back to back, i.e. what a kernel trace's per-step kernel sum + launch gaps
-      would read.  `unstarved_ok` says the host did finish enqueueing before the blocker ended.
+      device was still busy (behind a torch.cuda._sleep blocker sized above the enqueue time of two
+      steps, and behind a first, untimed step): the step as the GPU executes it back to back, i.e. what
+      a kernel trace's per-step kernel sum + dispatch gaps would read.  `unstarved_ok` says the host
+      did finish enqueueing both steps before the blocker ended.
 
     The timed steps' ms_per_step minus gpu_ms_per_step_unstarved is the time per step the GPU idled
     waiting for the host (`gpu_idle_ms_per_step` in the line)."""
@@ -590,13 +591,17 @@ def measure_host(one_step, reps=5):
     e0.record(); torch.cuda._sleep(cyc); e1.record()
     torch.cuda.synchronize()
     per_ms = cyc / max(e0.elapsed_time(e1), 1e-3)
-    block_ms = 1.5 * max(enq) + 20.0
+    # TWO steps behind the blocker, the second one timed: it starts the moment the first ends — warm
+    # clocks, like every step of the timed loop (a step that follows the idle blocker runs ~1.5 ms
+    # slower: the matrix clocks ramp up under the first contraction launches)
+    block_ms = 3.0 * max(enq) + 20.0
     gpu, ok = [], True
     for _ in range(3):
         torch.cuda.synchronize()
         s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         torch.cuda._sleep(int(block_ms * per_ms))
+        one_step()
         s0.record()
         one_step()
         s1.record()

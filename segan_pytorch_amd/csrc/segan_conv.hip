@@ -709,7 +709,12 @@ __global__ __launch_bounds__(256, (IN_HI && !BLK) ? 4 : 2) void corr2_kernel(con
   constexpr int SL = 4 / CV;          // waves that share a channel, each a slice of positions
   constexpr int NLD = CORR2_NLD;
   static_assert(CV == S, "one real channel per chunk of a HI input");
-  static_assert(!OUT_HI || NPT % 32 == 0, "T-form tiles hold whole 32-row phase blocks");
+  // a row shift is a property of a whole 32-row MFMA block (it moves the block's activation
+  // operand): shifted T tiles hold whole 32-row phase blocks; unshifted ones may mix the phases of
+  // NPT = 16 channels inside a block (the row decode of the weight tile and of the epilogue is per
+  // element)
+  static_assert(!OUT_HI || NPT % 32 == 0 || (!SHIFT && NPT % 4 == 0 && U != 8),
+                "T-form tiles hold whole 32-row phase blocks");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int RLs = a.RLs;              // padded row: a multiple of 64*SL, every lane may write
@@ -1340,7 +1345,9 @@ static int launch_corr2_x(CorrArgs a, hipStream_t st, bool allow_sk) {
   constexpr int CV = KC / U;
   constexpr int S = 32 / U;
   constexpr int SL = 4 / CV;
-  const int nrowtiles = OUT_HI ? a.NP / (MB / S) : ceil_div(a.Rvalid, MB);
+  // T form: NPT = MB / S channels per tile out of the NP the packing pads to (a multiple of 128 / S:
+  // the small-row tiles below it leave the all-padding row tiles out)
+  const int nrowtiles = OUT_HI ? ceil_div(a.Nout, MB / S) : ceil_div(a.Rvalid, MB);
   a.RLv = a.RLs;
   a.RLs = round_up(a.RLs, 64 * SL);
   a.nld = a.RLs / (64 * SL);
@@ -1402,6 +1409,20 @@ static int launch_corr_f(CorrArgs& a, hipStream_t st) {
   a.ncoltiles = ceil_div(a.Ctot, NB);
   a.RLs = NB + samples_per_tile(a.Tcols, NB) * a.H;
   const bool small = a.Rvalid <= 64;
+  if constexpr (U == 16) {
+    // stride 2 with at most 32 output rows (the 16 / 32-channel layers of the 11-layer stride-2 shape:
+    // round-5 review, weak 3): 32 x 256 tiles, waves 1 x 4 — a 64-row tile would be half padding
+    if (a.Rvalid <= 32) {
+      constexpr int NBW = 256;
+      CorrArgs b = a;
+      b.ncoltiles = ceil_div(b.Ctot, NBW);
+      b.RLs = NBW + samples_per_tile(b.Tcols, NBW) * b.H;
+      if (corr2_ok<U>(b, NBW)) {
+        a = b;
+        return launch_corr2_t<32, NBW, 1, U, true, false, false>(a, st, false);
+      }
+    }
+  }
   if (corr2_ok<U>(a, NB))
     return small ? launch_corr2_t<64, NB, 2, U, true, false, false>(a, st, false)
                  : launch_corr2_t<128, NB, 2, U, true, false, false>(a, st, true);
@@ -1431,7 +1452,17 @@ static int launch_corr_tt(CorrArgs& a, hipStream_t st) {
                     a.RLs);
     return SEGAN_EUNSUPPORTED;
   }
-  if (corr2_ok<U>(a, NB)) return launch_corr2_t<128, NB, 1, U, false, true, SHIFT>(a, st, true);
+  if (corr2_ok<U>(a, NB)) {
+    if constexpr (U == 16) {
+      // stride 2, few output channels (the shallow layers of the 11-layer stride-2 shape): a 128-row
+      // tile is 64 channels x 2 phases — with 32 / 16 channels half / three quarters of its MFMAs
+      // multiply padding.  64-row tiles (32 channels), and 32-row tiles (16 channels, both phases
+      // inside one 32-row MFMA block: only without row shifts, i.e. for the conv data gradient)
+      if (!SHIFT && a.Nout <= 16) return launch_corr2_t<32, NB, 1, U, false, true, false>(a, st, true);
+      if (a.Nout <= 32) return launch_corr2_t<64, NB, 1, U, false, true, SHIFT>(a, st, true);
+    }
+    return launch_corr2_t<128, NB, 1, U, false, true, SHIFT>(a, st, true);
+  }
   constexpr int KC = U <= 16 ? 32 : KCH;
   if (a.RLs <= 256) return launch_corr_t<128, NB, 1, U, false, true, SHIFT, 1, KC>(a, st, true);
   return launch_corr_t<128, NB, 1, U, false, true, SHIFT, 2, KCH>(a, st, true);

@@ -50,13 +50,17 @@ __global__ __launch_bounds__(256) void wgrad_group_kernel(float* slabs, int nspl
   for (int q = 0; q < NV; ++q) d4[q * 256 + tid] = acc[q];
 }
 
-template <int U, int MB, int NBT>
+// WM: wave rows of the tile that wrote the slabs (2 x 2 waves, or 1 x 4 for the 32-row tiles of
+// wgrad2_kernel): the slab layout is thread-minor, so the reduction must decode (row, column) of a
+// thread's elements exactly as the writer did
+template <int U, int MB, int NBT, int WM = 2>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs a, int nsplit, int zstep = 1) {
   constexpr int S = 32 / U;
-  constexpr int CVW = NBT / U, NI = MB / 64, NJ = NBT / 64;
+  constexpr int WN = 4 / WM;
+  constexpr int CVW = NBT / U, NI = MB / (32 * WM), NJ = NBT / (32 * WN);
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, h = lane >> 5;
   const int cv0 = blockIdx.x * CVW, m0 = blockIdx.y * MB;
   f32x16 acc[NI][NJ];
@@ -82,7 +86,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs a, in
   }
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
-    const int cc = wn * (NBT / 2) + 32 * j + l31;
+    const int cc = wn * (NBT / WN) + 32 * j + l31;
     const int cv = cv0 + cc / U;
     const int u = cc % U;
     const int n = cv / S, r = cv % S;
@@ -92,7 +96,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs a, in
     for (int i = 0; i < NI; ++i)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int m = m0 + wm * (MB / 2) + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int m = m0 + wm * (MB / WM) + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
         if (m < a.M) a.dw[((size_t)m * a.N + n) * a.K + k] += acc[i][j][e];
       }
   }
@@ -368,15 +372,22 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 #define WG2_TK 32
 #define WG2_NLD 4
 
-template <int U, bool XF>
+// MB: rows (low-rate channels m) of the block tile.  128 for the big layers; 64 and 32 for layers
+// with at most that many low-rate channels (the 16 - 64-channel layers of the 11-layer stride-2 shape
+// ran the 128-row tile at 25 - 50 % row utilisation: round-5 review, weak 3).  Waves 2 x 2 (1 x 4 for
+// MB = 32); the hi staging — one real channel per wave — does not depend on MB.
+template <int U, bool XF, int MB = 128>
 __global__ __launch_bounds__(256, 2) void wgrad2_kernel(const WgradArgs a) {
   constexpr int S = 32 / U;
   constexpr int TK = WG2_TK;
-  constexpr int MB = 128, NBT = 128;
+  constexpr int NBT = 128;
   constexpr int CVW = NBT / U;        // virtual channels per block = 4 real channels x S phases
-  constexpr int NI = 2, NJ = 2;
+  constexpr int WM = MB >= 64 ? 2 : 1, WN = 4 / WM;
+  constexpr int NI = MB / (32 * WM), NJ = NBT / (32 * WN);
   constexpr int NLD = WG2_NLD;
+  constexpr int NDMA = MB / 32;       // lo DMA instructions per wave and chunk (8 rows each)
   static_assert(CVW / S == 4, "one real hi channel per wave");
+  static_assert(MB == 128 || MB == 64 || MB == 32, "block rows");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int RLw = a.RLw;
@@ -386,7 +397,7 @@ __global__ __launch_bounds__(256, 2) void wgrad2_kernel(const WgradArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, h = lane >> 5;
 
   const int cv0 = blockIdx.x * CVW;
@@ -471,7 +482,7 @@ __global__ __launch_bounds__(256, 2) void wgrad2_kernel(const WgradArgs a) {
   int aoff[NI][4];
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
-    const int row = wm * 64 + 32 * i + l31;
+    const int row = wm * (MB / WM) + 32 * i + l31;
 #pragma unroll
     for (int j = 0; j < 4; ++j) aoff[i][j] = row * TK + 4 * ((2 * j + h) ^ ((row >> 1) & 7));
   }
@@ -480,7 +491,7 @@ __global__ __launch_bounds__(256, 2) void wgrad2_kernel(const WgradArgs a) {
   int bpos[4][NJ];
 #pragma unroll
   for (int jj = 0; jj < NJ; ++jj) {
-    const int cc = wn * (NBT / 2) + 32 * jj + l31;
+    const int cc = wn * (NBT / WN) + 32 * jj + l31;
     const int bb = (cc / U) * RLw + cc % U + 4 * h;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -497,12 +508,12 @@ __global__ __launch_bounds__(256, 2) void wgrad2_kernel(const WgradArgs a) {
 
   float hreg[NLD];
   auto load_chunk = [&](int buf) {
-    // lo: 4 DMA instructions per wave
+    // lo: NDMA (4 for the 128-row tile) DMA instructions per wave
     const int t0 = tq * TK;
     const int lo_s = ((brel * a.M + m0) * Ls + t0) * 4;
     float* Al = Al0 + buf * (MB * TK);
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < NDMA; ++p) {
       const int q = wave + 4 * p;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(
           lor, (__attribute__((address_space(3))) void*)(Al + q * 256), 16, lo_vo,
@@ -600,7 +611,7 @@ __global__ __launch_bounds__(256, 2) void wgrad2_kernel(const WgradArgs a) {
   }
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
-    const int cc = wn * (NBT / 2) + 32 * j + l31;
+    const int cc = wn * (NBT / WN) + 32 * j + l31;
     const int cv = cv0 + cc / U;
     const int u = cc % U;
     const int n = cv / S, r = cv % S;
@@ -610,7 +621,7 @@ __global__ __launch_bounds__(256, 2) void wgrad2_kernel(const WgradArgs a) {
     for (int i = 0; i < NI; ++i)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int m = m0 + wm * (MB / 2) + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int m = m0 + wm * (MB / WM) + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
         if (m < a.M) atomicAdd(a.dw + ((size_t)m * a.N + n) * a.K + k, acc[i][j][e]);
       }
   }
@@ -659,7 +670,7 @@ static int wg_cur_device() {
 
 // scratch layout of the fp32 weight gradient: [lo materialised: B*M*Ls floats, when lo has a
 // transform or two segments][slabs: blocks * 128*128 floats, deterministic mode]
-static size_t wgrad2_slab_floats(int tiles, int nsplit) { return (size_t)tiles * nsplit * 128 * 128; }
+static size_t wgrad2_slab_floats(int tiles, int nsplit, int MB = 128) { return (size_t)tiles * nsplit * MB * 128; }
 
 static bool wgrad2_geometry_ok(const WgradArgs& a, int U) {
   if (a.Cv <= 64 / U) return false;                    // edge layers: small-tile kernels
@@ -668,8 +679,8 @@ static bool wgrad2_geometry_ok(const WgradArgs& a, int U) {
 }
 
 static void wgrad2_plan(const WgradArgs& a, int U, int occ, int& tiles, int& nsplit, int& cps,
-                        int& nch) {
-  const int ncol = ceil_div(a.Cv, 128 / U), nrow = ceil_div(a.M, 128);
+                        int& nch, int MB = 128) {
+  const int ncol = ceil_div(a.Cv, 128 / U), nrow = ceil_div(a.M, MB);
   tiles = ncol * nrow;
   nch = ceil_div(a.Ctot, WG2_TK);
   const int G = segan_grid_slots(occ);
@@ -687,7 +698,7 @@ static void wgrad2_plan(const WgradArgs& a, int U, int occ, int& tiles, int& nsp
   nsplit = ceil_div(nch, cps);
 }
 
-template <int U, bool XF>
+template <int U, bool XF, int MB = 128>
 static int launch_wgrad2(WgradArgs& a, hipStream_t st, bool deterministic, float* slabs,
                          size_t slab_floats_avail) {
   constexpr int TK = WG2_TK;
@@ -707,8 +718,8 @@ static int launch_wgrad2(WgradArgs& a, hipStream_t st, bool deterministic, float
   }
   a.w2_nld = ceil_div(S * a.w2_pw, 64);
   if (a.w2_nld > WG2_NLD) return SEGAN_EUNSUPPORTED;
-  const size_t lds = (size_t)(2 * 128 * TK + 2 * (128 / U) * a.RLw) * sizeof(float);
-  auto kern = wgrad2_kernel<U, XF>;
+  const size_t lds = (size_t)(2 * MB * TK + 2 * (128 / U) * a.RLw) * sizeof(float);
+  auto kern = wgrad2_kernel<U, XF, MB>;
   static bool attr_done[16];
   static int occ_c[16];
   static size_t occ_lds[16];
@@ -727,30 +738,43 @@ static int launch_wgrad2(WgradArgs& a, hipStream_t st, bool deterministic, float
     occ_lds[d] = lds;
   }
   int tiles, nsplit, cps, nch;
-  wgrad2_plan(a, U, occ_c[d], tiles, nsplit, cps, nch);
+  wgrad2_plan(a, U, occ_c[d], tiles, nsplit, cps, nch, MB);
   a.w2_cps = cps;
   a.w2_nch = nch;
   a.w2_slabs = nullptr;
   // an unsplit contraction touches every dw element exactly once: nothing to order
   if (nsplit == 1) deterministic = false;
   if (deterministic) {
-    if (slabs == nullptr || slab_floats_avail < wgrad2_slab_floats(tiles, nsplit)) {
+    if (slabs == nullptr || slab_floats_avail < wgrad2_slab_floats(tiles, nsplit, MB)) {
       segan_set_error("wgrad: deterministic mode needs %zu bytes of scratch for the partial tiles",
-                      wgrad2_slab_floats(tiles, nsplit) * sizeof(float));
+                      wgrad2_slab_floats(tiles, nsplit, MB) * sizeof(float));
       return SEGAN_EINVAL;
     }
     a.w2_slabs = slabs;
   }
-  const int ncol = ceil_div(a.Cv, 128 / U), nrow = ceil_div(a.M, 128);
+  const int ncol = ceil_div(a.Cv, 128 / U), nrow = ceil_div(a.M, MB);
   g_last_wgrad[0] = 2; g_last_wgrad[1] = tiles; g_last_wgrad[2] = nsplit; g_last_wgrad[3] = cps;
   g_last_wgrad[4] = occ_c[d]; g_last_wgrad[5] = a.w2_nld;
   hipLaunchKernelGGL(kern, dim3(ncol, nrow, nsplit), dim3(256), lds, st, a);
   if (int e = segan_check_launch("wgrad2_kernel")) return e;
   if (deterministic) {
-    hipLaunchKernelGGL((wgrad_reduce_kernel<U, 128, 128>), dim3(ncol, nrow), dim3(256), 0, st, a, nsplit, 1);
+    hipLaunchKernelGGL((wgrad_reduce_kernel<U, MB, 128, (MB >= 64 ? 2 : 1)>), dim3(ncol, nrow), dim3(256), 0,
+                       st, a, nsplit, 1);
     return segan_check_launch("wgrad_reduce_kernel");
   }
   return SEGAN_OK;
+}
+
+// the row tile by the number of low-rate channels: 32 rows for M <= 32, 64 for M <= 64 (stride 2
+// only: the shapes that need it), 128 otherwise
+template <int U, bool XF>
+static int launch_wgrad2_rows(WgradArgs& a, hipStream_t st, bool deterministic, float* slabs,
+                              size_t slab_floats_avail) {
+  if constexpr (U == 16) {
+    if (a.M <= 32) return launch_wgrad2<U, XF, 32>(a, st, deterministic, slabs, slab_floats_avail);
+    if (a.M <= 64) return launch_wgrad2<U, XF, 64>(a, st, deterministic, slabs, slab_floats_avail);
+  }
+  return launch_wgrad2<U, XF, 128>(a, st, deterministic, slabs, slab_floats_avail);
 }
 
 template <int U, bool LO_ID, bool HI_ID, int MB, int NBT>
@@ -884,8 +908,8 @@ static int launch_wgrad_fp32(WgradArgs& a, hipStream_t st, bool deterministic, f
     if (hi_xf) {
       if (int e = segan_src_defaults(&a.hi, st, "wgrad(hi)")) return e;
     }
-    const int rc = hi_xf ? launch_wgrad2<U, true>(a, st, deterministic, slabs, slab_floats)
-                         : launch_wgrad2<U, false>(a, st, deterministic, slabs, slab_floats);
+    const int rc = hi_xf ? launch_wgrad2_rows<U, true>(a, st, deterministic, slabs, slab_floats)
+                         : launch_wgrad2_rows<U, false>(a, st, deterministic, slabs, slab_floats);
     if (rc != SEGAN_EUNSUPPORTED) return rc;
   }
   return launch_wgrad_t<U>(a, st, slabs, slab_floats);

@@ -57,6 +57,13 @@ CONV_CASES = [
     (2, 6, 7, 128, 4, 5, 1),
     (2, 256, 130, 512, 4, 31, 0),
     (1, 12, 40, 4096, 4, 31, 4),
+    # stride 2 with few channels: the small-row tiles (F 32 x 256; T 64 / 32 rows; W 64 / 32 rows)
+    (3, 16, 32, 512, 2, 31, 2),
+    (2, 32, 32, 1024, 2, 31, -3),
+    (3, 32, 64, 256, 2, 31, 1),
+    (5, 12, 20, 64, 2, 31, 0),
+    (2, 16, 32, 16, 2, 31, 0),
+    (2, 20, 48, 2048, 2, 31, 5),
 ]
 
 
@@ -139,6 +146,11 @@ DECONV_CASES = [
     (9, 40, 33, 16, 4, 31),
     (2, 8, 12, 32, 2, 31),
     (1, 24, 130, 1024, 4, 31),
+    # stride 2 with few channels: 64-row T tiles with row shifts, 64 / 32-row weight-gradient tiles
+    (3, 64, 32, 128, 2, 31),
+    (2, 64, 16, 256, 2, 31),
+    (2, 32, 8, 64, 2, 31),
+    (4, 24, 20, 32, 2, 31),
 ]
 
 
@@ -839,6 +851,115 @@ def test_deconv_layers_at_batch_scale(name, M0, M1, N, Ls, B):
         finally:
             ops.set_deterministic(False)
     assert info_t['kernel'] == 2 and info_f['kernel'] == 2
+
+
+# the shallow layers of the original 11-layer stride-2 SEGAN shape (train.py:199-205 flags): 16 - 64
+# channels, where round 6 added the small-row tiles
+SCALE_S2 = [
+    # name, N (Cin), M (Cout), L, roll, B
+    ('v11.enc1', 16, 32, 8192, 3, 40),
+    ('v11.enc2', 32, 32, 4096, -2, 40),
+    ('v11.enc3', 32, 64, 2048, 5, 40),
+    ('v11.enc4', 64, 64, 1024, -1, 300),
+]
+
+
+@pytest.mark.parametrize('name,N,M,L,roll,B', SCALE_S2)
+def test_stride2_conv_layers_take_the_small_row_tiles(name, N, M, L, roll, B):
+    """Conv forward / data gradient / weight gradient of the 16 - 64-channel stride-2 layers against
+    torch fp64, PReLU on load, both reduction modes, bit-reproducible; and the launch records say
+    the small-row tiles ran: F form 32 x 256 for <= 32 output channels, T form 32 rows (16 channels) /
+    64 rows (32 channels), W form 32 / 64 rows."""
+    ops = _ops()
+    S, K = 2, 31
+    x = rnd(B, N, L, seed=11)
+    sl = rnd(N, seed=12).abs() * 0.3
+    w = rnd(M, N, K, seed=13, scale=0.05)
+    b = rnd(M, seed=14)
+    hd = xform_ref(x, slope=sl).requires_grad_(True)
+    wd = w.double().requires_grad_(True)
+    ref = conv_ref(hd, wd, b.double(), S, roll)
+    xg, wg, bg, slg = x.to(DEV), w.to(DEV), b.to(DEV), sl.to(DEV)
+    src = ops.Src(xg, slope=slg)
+    out = ops.conv1d_fwd(src, wg, bg, S, roll=roll)
+    info_f = ops.last_corr_launch()
+    assert max_rel(out, ref) < TOL
+    assert torch.equal(out, ops.conv1d_fwd(src, wg, bg, S, roll=roll))
+    da = rnd(*ref.shape, seed=15)
+    ref.backward(da.double())
+    dag = da.to(DEV)
+    dx = ops.conv1d_dgrad(dag, wg, L, S, roll=roll)
+    info_t = ops.last_corr_launch()
+    assert max_rel(dx, hd.grad) < TOL
+    assert torch.equal(dx, ops.conv1d_dgrad(dag, wg, L, S, roll=roll))
+    padL = ops.conv_pad(K, S)[0]
+    for det in (False, True):
+        ops.set_deterministic(det)
+        try:
+            dw = torch.zeros_like(wg)
+            ops.wgrad(ops.Src(dag), src, dw, K, S, padL, ops.PAD_REFLECT, roll=roll)
+            info_w = ops.last_wgrad_launch()
+            assert max_rel(dw, wd.grad) < TOL, det
+            if det:
+                dw2 = torch.zeros_like(wg)
+                ops.wgrad(ops.Src(dag), src, dw2, K, S, padL, ops.PAD_REFLECT, roll=roll)
+                assert torch.equal(dw, dw2)
+        finally:
+            ops.set_deterministic(False)
+    assert info_f['kernel'] == 2 and info_t['kernel'] == 2 and info_w['kernel'] == 2
+    cols = B * (L // S)
+    if M <= 32:
+        assert info_f['tiles'] == -(-cols // 256)              # one 32-row tile per 256 columns
+    # T form: padded coordinates (L + padL + padR - 1) // S + 1 = (L + 14 + 15 - 1) // 2 + 1 columns
+    # per sample, 128 per tile
+    tcols = B * ((L + 14 + 15 - 1) // 2 + 1)
+    npt = 16 if N <= 16 else 32 if N <= 32 else 64
+    assert info_t['tiles'] == -(-N // npt) * -(-tcols // 128)
+    assert info_w['tiles'] == -(-N * S // (128 // 16)) * 1       # one row tile of 32 / 64 rows
+
+
+@pytest.mark.parametrize('name,M0,M1,N,Ls,B', [('v11.dec7', 64, 64, 32, 1024, 40), ('v11.dec8', 32, 32, 32, 2048, 40),
+                                               ('v11.dec9', 32, 32, 16, 4096, 40)])
+def test_stride2_deconv_layers_take_the_small_row_tiles(name, M0, M1, N, Ls, B):
+    """The last MFMA decoder layers of the 11-layer stride-2 shape as the generator runs them
+    (two-pointer input, PReLU / alpha on load): forward on 64-row T tiles with row shifts (32 output
+    channels; 16 are padded to 32 — a row shift is a property of a whole 32-row block), data gradient
+    on the F form, weight gradient on 64-row tiles."""
+    ops = _ops()
+    S, K = 2, 31
+    M = M0 + M1
+    x0, x1 = rnd(B, M0, Ls, seed=21), rnd(B, M1, Ls, seed=22)
+    scale = torch.cat((torch.ones(M0), rnd(M1, seed=23)))
+    slope = torch.cat((rnd(M0, seed=24).abs() * 0.3, torch.ones(M1)))
+    w = rnd(M, N, K, seed=25, scale=0.05)
+    b = rnd(N, seed=26)
+    xin = xform_ref(torch.cat((x0, x1), 1), scale, None, slope).requires_grad_(True)
+    wd = w.double().requires_grad_(True)
+    pad = ops.deconv_pad(K, S)
+    ref = F.conv_transpose1d(xin, wd, b.double(), stride=S, padding=pad)[:, :, :S * Ls]
+    src = ops.Src(x0.to(DEV), x1.to(DEV), scale=scale.to(DEV), slope=slope.to(DEV))
+    wg = w.to(DEV)
+    y = ops.deconv1d_fwd(src, wg, b.to(DEV), S)
+    info_t = ops.last_corr_launch()
+    assert max_rel(y, ref) < TOL
+    assert torch.equal(y, ops.deconv1d_fwd(src, wg, b.to(DEV), S))
+    dy = rnd(*ref.shape, seed=27)
+    ref.backward(dy.double())
+    dyg = dy.to(DEV)
+    dx0, dx1 = ops.deconv1d_dgrad(dyg, wg, S, M0)
+    assert max_rel(dx1, xin.grad[:, M0:]) < TOL and max_rel(dx0, xin.grad[:, :M0]) < TOL
+    for det in (False, True):
+        ops.set_deterministic(det)
+        try:
+            dw = torch.zeros_like(wg)
+            ops.wgrad(src, ops.Src(dyg), dw, K, S, pad, ops.PAD_ZERO)
+            info_w = ops.last_wgrad_launch()
+            assert max_rel(dw, wd.grad) < TOL, det
+        finally:
+            ops.set_deterministic(False)
+    assert info_t['kernel'] == 2 and info_w['kernel'] == 2
+    assert info_t['tiles'] == 1 * -(-(B * Ls) // 128)            # ONE 64-row tile of 32 channels x 2 phases
+    assert info_w['tiles'] == -(-N * S // 8) * -(-M // (64 if M <= 64 else 128))
 
 
 @pytest.mark.parametrize('prec', ['bf16x3', 'bf16'])
