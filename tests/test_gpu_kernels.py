@@ -922,9 +922,9 @@ def test_stride2_conv_layers_take_the_small_row_tiles(name, N, M, L, roll, B):
                                                ('v11.dec9', 32, 32, 16, 4096, 40)])
 def test_stride2_deconv_layers_take_the_small_row_tiles(name, M0, M1, N, Ls, B):
     """The last MFMA decoder layers of the 11-layer stride-2 shape as the generator runs them
-    (two-pointer input, PReLU / alpha on load): forward on 64-row T tiles with row shifts (32 output
-    channels; 16 are padded to 32 — a row shift is a property of a whole 32-row block), data gradient
-    on the F form, weight gradient on 64-row tiles."""
+    (two-pointer input, PReLU / alpha on load): forward on 64-row T tiles (32 output channels) or
+    32-row tiles (16 channels: both phases inside one MFMA block — the stride-2 transposed conv with
+    padding 14 has no row shifts), data gradient on the F form, weight gradient on 64-row tiles."""
     ops = _ops()
     S, K = 2, 31
     M = M0 + M1
@@ -958,7 +958,7 @@ def test_stride2_deconv_layers_take_the_small_row_tiles(name, M0, M1, N, Ls, B):
         finally:
             ops.set_deterministic(False)
     assert info_t['kernel'] == 2 and info_w['kernel'] == 2
-    assert info_t['tiles'] == 1 * -(-(B * Ls) // 128)            # ONE 64-row tile of 32 channels x 2 phases
+    assert info_t['tiles'] == 1 * -(-(B * Ls) // 128)            # ONE row tile: 32 (or 16) channels x 2 phases
     assert info_w['tiles'] == -(-N * S // 8) * -(-M // (64 if M <= 64 else 128))
 
 
