@@ -292,6 +292,54 @@ __device__ __forceinline__ void corr_store_tile(
       for (int j = 0; j < NJ; ++j) left = left || cb[j] >= 0;
       if (!left) return;
     }
+    // Stride 2 (round 6): a lane holds BOTH phases of its channels — in row blocks ib and ib + NI/2
+    // (64 / 32 channels per tile), or in elements e and e + 8 of the one block of a 16-channel tile —
+    // i.e. two consecutive output samples: one 8-byte store per (channel, column) for the deconv
+    // forward and the interior columns of the conv data gradient, offsets once per column as in the
+    // stride-4 form above.  The stride-2 T form used to take the generic per-element path below
+    // (~30 VALU per stored value).
+    constexpr bool PAIR = (S == 2 && WM == 1 && (NI == 4 || NI == 2 || NI == 1));
+    if (PAIR && qfast && a.act == SEGAN_ACT_NONE && n0 + NPT <= a.Nout) {
+      int ovo[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        ovo[j] = (int)0x80000000u;
+        if (col_b[j] >= 0) {
+          const int i0 = 2 * col_t[j] - a.o_padL;
+          int ib = i0 - a.o_roll;
+          if (ib < 0) ib += a.Lout;
+          if (ib >= a.Lout) ib -= a.Lout;
+          if (i0 >= 0 && i0 + 1 < a.Lout && ib + 1 < a.Lout) {
+            ovo[j] = ((col_b[j] * a.Nout + n0 + 4 * h) * a.Lout + ib) * 4;
+            cb[j] = -1;
+          }
+        }
+      }
+      const int rowstep = a.Lout * 4;
+      constexpr int NBLK = NI >= 2 ? NI / 2 : 1;      // 32-channel blocks of the tile
+      constexpr int NE = NI >= 2 ? 16 : 8;            // channel slots per block and lane
+#pragma unroll
+      for (int bk = 0; bk < NBLK; ++bk) {
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+          const int nl = 32 * bk + (e & 3) + 8 * (e >> 2);
+          float bs = 0.0f;
+          if (a.bias) bs = a.bias[n0 + 4 * h + nl];
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            typedef unsigned u32x2s __attribute__((ext_vector_type(2)));
+            const float p0 = acc[bk][j][e];
+            const float p1 = NI >= 2 ? acc[(bk + NI / 2) % NI][j][e] : acc[0][j][(e + 8) % 16];
+            const u32x2s o = {__builtin_bit_cast(unsigned, p0 + bs), __builtin_bit_cast(unsigned, p1 + bs)};
+            __builtin_amdgcn_raw_buffer_store_b64(o, qrs, ovo[j] + nl * rowstep, 0, 0);   // (*)
+          }
+        }
+      }
+      bool left = false;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) left = left || cb[j] >= 0;
+      if (!left) return;
+    }
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
 #pragma unroll
