@@ -36,13 +36,65 @@ def _gb(p, needed=True):
     return grad_buf(p)
 
 
-def _bn_train_stats(c, bn):
-    """BatchNorm training statistics of pre-activation c: over this rank's batch, or over the
-    global batch when synchronised BatchNorm is on (distributed.sync_bn_enabled)."""
+def _bn_batch_stats(bn, training):
+    """nn.BatchNorm1d.forward's rule: batch statistics in training mode — and in eval mode too when
+    the module tracks no running statistics (track_running_stats=False: the buffers are None)."""
+    return training or bn.running_mean is None or bn.running_var is None
+
+
+def _bn_train_stats(c, bn, training=True):
+    """BatchNorm batch statistics of pre-activation c: over this rank's batch, or over the
+    global batch when synchronised BatchNorm is on (distributed.sync_bn_enabled).  In training
+    mode with tracked statistics the batch counter is bumped FIRST and the running statistics move
+    by torch's exponential_average_factor: bn.momentum, or — momentum=None — the cumulative average
+    1 / num_batches_tracked (one host read of the counter: a corner no train.py flag reaches).
+    Without tracked statistics (or in eval mode without them) nothing but the batch statistics is
+    touched."""
     from . import distributed as sdist
     fn = sdist.bn_stats_sync if sdist.sync_bn_enabled() else ops.bn_stats
-    return fn(c, bn.weight, bn.bias, bn.eps, bn.momentum if bn.momentum is not None else 0.1,
-              bn.running_mean, bn.running_var)
+    track = training and bn.running_mean is not None and bn.running_var is not None
+    momentum = 0.0
+    if track:
+        if bn.num_batches_tracked is not None:
+            bn.num_batches_tracked += 1
+        if bn.momentum is not None:
+            momentum = bn.momentum
+        else:
+            momentum = 1.0 / float(bn.num_batches_tracked) if bn.num_batches_tracked is not None else 0.0
+    return fn(c, bn.weight, bn.bias, bn.eps, momentum, bn.running_mean if track else None,
+              bn.running_var if track else None)
+
+
+def _bn_eval_affine(bn):
+    """(scale, shift, rstd) of an eval-mode BatchNorm with tracked statistics: a fixed per-channel
+    affine map of the running statistics."""
+    rstd = torch.rsqrt(bn.running_var + bn.eps)
+    gamma = bn.weight.detach() if bn.weight is not None else torch.ones_like(rstd)
+    beta = bn.bias.detach() if bn.bias is not None else torch.zeros_like(rstd)
+    scale = (gamma * rstd).contiguous()
+    shift = (beta - bn.running_mean * scale).contiguous()
+    return scale, shift, rstd.contiguous()
+
+
+def _eval_bn_act_bwd(c, bn, scale, shift, rstd, dh, slope, dslope, y_tanh=None, dbias=None):
+    """Backward through act(bn_eval(c)) of a stand-alone block whose BatchNorm is in eval() — a fixed
+    affine map, which autograd differentiates like any other (fine-tuning with frozen statistics;
+    round-5 advice: this used to raise).  g = dL/d bn(c) through the PReLU (or the Tanh, from its
+    output `y_tanh`), dbeta += sum g, dgamma += sum g * xhat with xhat = (c - mean) * rstd of the
+    RUNNING statistics, dL/dc = g * scale, and the conv bias takes sum dL/dc.  The two per-channel
+    sums for gamma run on ATen reductions: a path the reference's training never takes."""
+    if y_tanh is not None:
+        g = ops.tanh_bwd(y_tanh, dh, dbias=_gb(bn.bias))
+    else:
+        v = ops.affine_prelu(c, scale, shift, None)
+        g = ops.act_bwd(v, dh, slope=slope, dslope=dslope, dbias=_gb(bn.bias))
+    if bn.weight is not None and bn.weight.requires_grad:
+        xhat = ops.affine_prelu(c, rstd, (-bn.running_mean * rstd).contiguous(), None)
+        grad_buf(bn.weight).add_((g * xhat).sum((0, 2)))
+    dc = ops.affine_prelu(g, scale, None, None)
+    if dbias is not None:
+        ops.act_bwd(dc, dc, dbias=dbias)          # += sum over (b, t)
+    return dc
 
 
 def _act_bwd_bn(a, dh, slope, bn, dslope, dgamma, dbeta, dbias):
@@ -244,14 +296,10 @@ def _block_norm(blk, c, training):
     bn = getattr(blk, 'norm', None)
     if bn is None:
         return None, None, None
-    if training:
-        mean, rstd, scale, shift = _bn_train_stats(c, bn)
-        if bn.num_batches_tracked is not None:
-            bn.num_batches_tracked += 1
+    if _bn_batch_stats(bn, training):
+        mean, rstd, scale, shift = _bn_train_stats(c, bn, training)
         return scale, shift, (mean, rstd, bn.weight, bn.bias)
-    rstd = torch.rsqrt(bn.running_var + bn.eps)
-    scale = (bn.weight.detach() * rstd).contiguous()
-    shift = (bn.bias.detach() - bn.running_mean * scale).contiguous()
+    scale, shift, _rstd = _bn_eval_affine(bn)
     return scale, shift, 'eval'
 
 
@@ -569,15 +617,11 @@ class DiscriminatorFn(torch.autograd.Function):
             cs.append(c)
             if blk.norm is not None:
                 bn = blk.norm
-                if training:
-                    mean, rstd, scale, shift = _bn_train_stats(c, bn)
-                    if bn.num_batches_tracked is not None:
-                        bn.num_batches_tracked += 1
+                if _bn_batch_stats(bn, training):
+                    mean, rstd, scale, shift = _bn_train_stats(c, bn, training)
                     bns.append((mean, rstd, bn.weight, bn.bias))
                 else:
-                    rstd = torch.rsqrt(bn.running_var + bn.eps)
-                    scale = (bn.weight.detach() * rstd).contiguous()
-                    shift = (bn.bias.detach() - bn.running_mean * scale).contiguous()
+                    scale, shift, _rstd = _bn_eval_affine(bn)
                     bns.append('eval')
                 xfs.append((scale, shift))
                 src = Src(c, scale=scale, shift=shift, slope=blk.act.weight)
@@ -727,16 +771,12 @@ class ConvBlockFn(torch.autograd.Function):
         scale = shift = None
         if blk.norm is not None:
             bn = blk.norm
-            if blk.training:
-                mean, rstd, scale, shift = _bn_train_stats(c, bn)
-                if bn.num_batches_tracked is not None:
-                    bn.num_batches_tracked += 1
+            if _bn_batch_stats(bn, blk.training):
+                mean, rstd, scale, shift = _bn_train_stats(c, bn, blk.training)
                 bn_saved = (mean, rstd, bn.weight, bn.bias)
             else:
-                rstd = torch.rsqrt(bn.running_var + bn.eps)
-                scale = (bn.weight.detach() * rstd).contiguous()
-                shift = (bn.bias.detach() - bn.running_mean * scale).contiguous()
-                bn_saved = 'eval'
+                scale, shift, rstd = _bn_eval_affine(bn)
+                bn_saved = ('eval', scale, shift, rstd)
         h = ops.affine_prelu(c, scale, shift, blk.act.weight)
         a = c if blk.norm is None else ops.affine_prelu(c, scale, shift, None)
         ctx.blk = blk
@@ -760,13 +800,15 @@ class ConvBlockFn(torch.autograd.Function):
                              alpha=_ones(c.shape[1], c) if lin is not None else None,
                              dslope=_gb(blk.act.weight), dbias=_gb(blk.conv.bias))
         else:
-            if bn == 'eval':
-                raise RuntimeError('GConv1DBlock backward with BatchNorm in eval() is unsupported')
             if da_lin is not None or dh is None:
                 raise RuntimeError('gradient through the linear output of a normalised '
                                    'GConv1DBlock is unsupported')
-            dc = _act_bwd_bn(c, dh, blk.act.weight, bn, _gb(blk.act.weight), _gb(bn[2]), _gb(bn[3]),
-                             _gb(blk.conv.bias))
+            if isinstance(bn[0], str):      # ('eval', ...): frozen statistics, a fixed affine map
+                dc = _eval_bn_act_bwd(c, blk.norm, bn[1], bn[2], bn[3], dh, blk.act.weight,
+                                      _gb(blk.act.weight), dbias=_gb(blk.conv.bias))
+            else:
+                dc = _act_bwd_bn(c, dh, blk.act.weight, bn, _gb(blk.act.weight), _gb(bn[2]), _gb(bn[3]),
+                                 _gb(blk.conv.bias))
         padL = ops.conv_pad(K, S)[0]
         if W.needs_grad(blk.conv):
             gw = W.grad_target(blk.conv)
@@ -796,16 +838,12 @@ class DeconvBlockFn(torch.autograd.Function):
         if bn is None:
             h = c if blk.is_tanh else ops.affine_prelu(c, slope=blk.act.weight)
         else:
-            if blk.training:
-                mean, rstd, scale, shift = _bn_train_stats(c, bn)
-                if bn.num_batches_tracked is not None:
-                    bn.num_batches_tracked += 1
+            if _bn_batch_stats(bn, blk.training):
+                mean, rstd, scale, shift = _bn_train_stats(c, bn, blk.training)
                 bn_saved = (mean, rstd, bn.weight, bn.bias)
             else:
-                rstd = torch.rsqrt(bn.running_var + bn.eps)
-                scale = (bn.weight.detach() * rstd).contiguous()
-                shift = (bn.bias.detach() - bn.running_mean * scale).contiguous()
-                bn_saved = 'eval'
+                scale, shift, rstd = _bn_eval_affine(bn)
+                bn_saved = ('eval', scale, shift, rstd)
             h = ops.affine_tanh(c, scale, shift) if blk.is_tanh else \
                 ops.affine_prelu(c, scale, shift, blk.act.weight)
         ctx.blk = blk
@@ -820,10 +858,14 @@ class DeconvBlockFn(torch.autograd.Function):
         K, S = blk.kwidth, blk.stride
         w = W.get(blk.deconv)
         dh = dh.contiguous()
-        if bn == 'eval':
-            raise RuntimeError('GDeconv1DBlock backward with BatchNorm in eval() is unsupported')
         bnm = blk.norm if bn is not None else None
-        if blk.is_tanh:
+        if bn is not None and isinstance(bn[0], str):
+            # frozen statistics (fine-tuning in eval()): the BatchNorm is a fixed affine map
+            da = _eval_bn_act_bwd(c, bnm, bn[1], bn[2], bn[3], dh,
+                                  None if blk.is_tanh else blk.act.weight,
+                                  None if blk.is_tanh else _gb(blk.act.weight),
+                                  y_tanh=y if blk.is_tanh else None, dbias=_gb(blk.deconv.bias))
+        elif blk.is_tanh:
             if bn is None:
                 da = ops.tanh_bwd(c, dh, dbias=_gb(blk.deconv.bias))
             else:       # y = tanh(bn(c)): through the Tanh, then through the BatchNorm

@@ -260,6 +260,92 @@ def test_blocks_standalone(tiny_step):
         assert max_rel(dbn.norm.running_var, bn['running_var']) < 1e-4
 
 
+def _torch_block(kind, blk, x, act_tanh=False):
+    """The same block composed from torch.nn.functional ops on the block's own parameters."""
+    import torch.nn.functional as F
+    K, S = blk.kwidth, blk.stride
+    if kind == 'conv':
+        c = F.conv1d(F.pad(x, (K // 2 - 1, K // 2), mode='reflect'), blk.conv.weight, blk.conv.bias, stride=S)
+    else:
+        pad = max(0, (S - K) // -2)
+        c = F.conv_transpose1d(x, blk.deconv.weight, blk.deconv.bias, stride=S, padding=pad)
+        c = c[:, :, :-1] if K % 2 else c
+    bn = blk.norm
+    c = F.batch_norm(c, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.training or
+                     bn.running_mean is None, bn.momentum if bn.momentum is not None else 0.0, bn.eps)
+    return torch.tanh(c) if act_tanh else F.prelu(c, blk.act.weight)
+
+
+@pytest.mark.parametrize('kind,act', [('conv', None), ('deconv', None), ('deconv', 'Tanh')])
+def test_standalone_block_backward_with_batchnorm_in_eval(kind, act):
+    """Round-5 advice: a stand-alone block whose BatchNorm is in eval() — fine-tuning with frozen
+    statistics — is differentiable in the reference (autograd goes through the fixed affine map);
+    here it used to raise.  Output, input gradient and every parameter gradient (gamma and beta
+    included) against plain torch autograd of the same composition."""
+    import copy
+    from segan_pytorch_amd.models import GConv1DBlock, GDeconv1DBlock
+    torch.manual_seed(3)
+    if kind == 'conv':
+        blk = GConv1DBlock(6, 10, 31, stride=4, bias=True, norm_type='bnorm')
+        x = torch.randn(3, 6, 128)
+    else:
+        blk = GDeconv1DBlock(10, 4, 31, stride=4, norm_type='bnorm', act=act)
+        x = torch.randn(2, 10, 32)
+    if act is None:
+        blk.act.weight.data.uniform_(0.1, 0.3)
+    blk.norm.weight.data.uniform_(0.5, 1.5)
+    blk.norm.bias.data.uniform_(-0.2, 0.2)
+    blk.norm.running_mean.uniform_(-0.3, 0.3)
+    blk.norm.running_var.uniform_(0.5, 2.0)
+    ref = copy.deepcopy(blk)
+    blk.eval()
+    ref.eval()
+    xg, xr = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    w = torch.randn(1)
+    h = blk(xg)
+    h = h[0] if isinstance(h, tuple) else h
+    hr = _torch_block(kind, ref, xr, act_tanh=act == 'Tanh')
+    assert max_rel(h, hr) < 2e-5
+    c = torch.randn_like(hr)
+    (h * c).sum().backward()
+    (hr * c).sum().backward()
+    assert max_rel(xg.grad, xr.grad) < 1e-4
+    for (k, p), (_k, q) in zip(blk.named_parameters(), ref.named_parameters()):
+        assert p.grad is not None and max_rel(p.grad, q.grad) < 1e-4, k
+    # the running statistics did not move
+    assert torch.equal(blk.norm.running_mean, ref.norm.running_mean)
+    assert int(blk.norm.num_batches_tracked) == 0
+
+
+def test_batchnorm_without_tracked_statistics_and_cumulative_momentum():
+    """nn.BatchNorm1d corners the blocks inherit from torch: track_running_stats=False (no buffers:
+    batch statistics also in eval mode — this used to dereference running_var) and momentum=None (the
+    running statistics are the cumulative average 1 / num_batches_tracked, not a 0.1 EMA)."""
+    from segan_pytorch_amd.models import GDeconv1DBlock
+    torch.manual_seed(4)
+    blk = GDeconv1DBlock(10, 4, 31, stride=4, norm_type='bnorm')
+    blk.act.weight.data.uniform_(0.1, 0.3)
+    blk.norm = torch.nn.BatchNorm1d(4, track_running_stats=False)
+    x = torch.randn(3, 10, 32)
+    for mode in (True, False):
+        blk.train(mode)
+        h = blk(x)
+        assert max_rel(h, _torch_block('deconv', blk, x)) < 2e-5
+    blk.norm = torch.nn.BatchNorm1d(4, momentum=None)
+    ref = torch.nn.BatchNorm1d(4, momentum=None)
+    blk.train()
+    ref.train()
+    import torch.nn.functional as F
+    for i in range(3):
+        xi = torch.randn(3, 10, 32)
+        blk(xi)
+        c = F.conv_transpose1d(xi, blk.deconv.weight, blk.deconv.bias, stride=4, padding=13)[:, :, :-1]
+        ref(c.detach())
+    assert int(blk.norm.num_batches_tracked) == 3
+    assert max_rel(blk.norm.running_mean, ref.running_mean) < 1e-5
+    assert max_rel(blk.norm.running_var, ref.running_var) < 1e-5
+
+
 @pytest.mark.parametrize('golden', ['tiny_wsegan2.pt', 'tiny_wsegan_snorm.pt', 'vanillagan'])
 def test_wsegan_literal_train(golden, tmp_path):
     """WSEGAN.train (misalign pair, STFT power loss, masked L1) against the reference's
