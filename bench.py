@@ -700,6 +700,8 @@ def main():
                     help='skip the `other_workloads` block (WSEGAN = BASELINE config 4, the 11-layer stride-2 '
                          'shape = config 2 as worded) that the default fp32 SEGAN+ run carries')
     ap.add_argument('--side-steps', type=int, default=10, help='timed steps per side workload')
+    ap.add_argument('--no-host-measure', action='store_true',
+                    help='skip measure_host (host enqueue time per step, GPU time of an unstarved step)')
     ap.add_argument('--comm-ab', action='store_true',
                     help='world > 1: also time the steps with the OTHER gradient transport (libsegan_hip\'s '
                          'own RCCL communicators vs torch.distributed); opt-in — the native transport has '
@@ -799,7 +801,7 @@ def main():
         # and the first layers' data gradients)
         gflop_exec = timer.booked_flops() / (B * args.steps) / 1e9
     host = None
-    if world == 1 and not args.no_modes:
+    if world == 1 and not args.no_host_measure:
         try:
             host = measure_host(one_step)
         except Exception as e:      # a side measurement must never cost the headline line

@@ -121,7 +121,7 @@ def test_loader_sample_keeps_one_live_iterator(tmp_path):
     ref = SEDataset(cd, nd, preemph=0.95, slice_size=16384, stride=0.5)
     want = {(ref[i][0], ref[i][3]): (ref[i][1], ref[i][2]) for i in range(len(ref))}
     ds = PCMShardDataset(str(tmp_path / 'sh'))
-    loader = PCMShardLoader(ds, 4, 0.95, 'cuda', num_workers=1)
+    loader = PCMShardLoader(ds, 4, 0.95, 'cuda', num_workers=0)      # in-process: the iterator logic is the same, no worker start-up
     entered = []
     loader._ensure_sample_loader()       # sample()'s own DataLoader (lazy otherwise)
     assert loader._sample_loader is not loader.loader
@@ -177,7 +177,7 @@ def test_loader_sample_leaves_the_global_generator_alone(tmp_path):
     cd, nd = _write_wavs(tmp_path)
     build_pcm_shard(cd, nd, str(tmp_path / 'sh'), slice_size=16384, stride=0.5)
     ds = PCMShardDataset(str(tmp_path / 'sh'))
-    loader = PCMShardLoader(ds, 4, 0.95, 'cuda', num_workers=1)
+    loader = PCMShardLoader(ds, 4, 0.95, 'cuda', num_workers=0)
     assert loader.sample_keeps_global_rng
     loader.sample()                                  # creates the loader: ONE global draw, here
     torch.manual_seed(5)
