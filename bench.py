@@ -16,8 +16,9 @@ Prints ONE JSON line (rank 0):
   value       whole-job 16384-sample chunks/s
   roofline    the dominant kernel family (corr_kernel: every conv/deconv forward and data
               gradient): ALGORITHMIC flops of its launches / their summed duration,
-              measured live with HIP events on the launch stream, vs the 157.3 TF/s
-              fp32-MFMA peak (guides/MI355X_MICROARCH.md)
+              measured live with HIP events on the launch stream in three of the K timed steps
+              (KernelTimer: every launch of those steps), vs the 157.3 TF/s fp32-MFMA peak
+              (guides/MI355X_MICROARCH.md)
   cpu_baseline  the CPU oracle (oracle/segan_oracle.py, a port of the reference's path)
               timed on this host's cores at the metric's batch (300), rank 0 at N=1 only
   parity      BASELINE's second metric: the HIP step against that same oracle step (same
@@ -103,16 +104,60 @@ def z_lookahead_ok(wsegan):
     return True
 
 
+def sample_steps(steps):
+    """The timed steps whose contraction launches are bracketed with HIP events: the first, the middle
+    and the last one."""
+    return sorted({0, steps // 2, steps - 1}) if steps > 0 else []
+
+
 class KernelTimer(object):
-    """Brackets every launch of the contraction entry points with HIP events on torch's
+    """Brackets the launches of the contraction entry points with HIP events on torch's
     current stream (the stream the kernels are launched on) and books the algorithmic
-    FLOPs of the call."""
+    FLOPs of the call.
+
+    The instrumentation must not change what it measures (round 6: with two freshly created timing
+    events around EVERY contraction call the 11-layer shape — 151 calls per step — ran 78.6 instead
+    of 68.1 ms per step in a fresh process, the SEGAN+ step 86.0 instead of 85.4; on a slower host
+    more: the "host-bound on some boxes" of the round-5 review was this).  So: (1) only the steps of
+    `sample_steps` are instrumented — three of the K timed steps, every launch of those —, the others
+    run the plain entry points; (2) the events are created BEFORE the timed region (`prepare`: the
+    last warm-up step runs instrumented, which creates one step's worth of HIP events; two more
+    steps' worth are created and recorded once) and taken from that pool inside it."""
 
     CORR = ('conv1d_fwd', 'conv1d_dgrad', 'deconv1d_fwd', 'deconv1d_dgrad')
 
     def __init__(self):
         self.records = []     # (family, flops, ev0, ev1)
         self._saved = {}
+        self.active = True
+        self.sampled = 0      # instrumented steps so far
+        self._pool, self._next = [], 0
+
+    def _event(self):
+        if self._next < len(self._pool):
+            e = self._pool[self._next]
+        else:
+            e = torch.cuda.Event(enable_timing=True)
+            self._pool.append(e)
+        self._next += 1
+        return e
+
+    def begin_step(self, sampled):
+        self.active = bool(sampled)
+        if sampled:
+            self.sampled += 1
+
+    def prepare(self, one_step, nsteps):
+        """Run ONE instrumented (untimed) step to learn how many events a step takes and to create
+        them, create the events of `nsteps` - 1 further steps (torch creates the HIP event on the first
+        record), then forget the dry step's records."""
+        self.begin_step(True)
+        one_step()
+        per_step = self._next
+        for _ in range(per_step * max(nsteps - 1, 0)):
+            self._event().record()
+        self.records, self._next, self.sampled, self.active = [], 0, 0, False
+        return per_step
 
     @staticmethod
     def _flops(name, args, kwargs, out):
@@ -146,8 +191,9 @@ class KernelTimer(object):
             fam = name if name in ('wgrad', 'gemm') else 'corr'
 
             def wrapped(*a, _fn=fn, _name=name, _fam=fam, **k):
-                e0 = torch.cuda.Event(enable_timing=True)
-                e1 = torch.cuda.Event(enable_timing=True)
+                if not self.active:
+                    return _fn(*a, **k)
+                e0, e1 = self._event(), self._event()
                 e0.record()
                 out = _fn(*a, **k)
                 e1.record()
@@ -161,10 +207,11 @@ class KernelTimer(object):
             setattr(ops, name, fn)
         self._saved = {}
 
-    def booked_flops(self):
-        """All FLOPs the timed launches were booked with: the matrix work the engine EXECUTED (conv /
-        deconv forward, data and weight gradients, the dense-head and STFT GEMMs)."""
-        return sum(r[1] for r in self.records)
+    def booked_flops_per_step(self):
+        """FLOPs the launches of one instrumented step were booked with: the matrix work the engine
+        EXECUTES per step (conv / deconv forward, data and weight gradients, the dense-head and STFT
+        GEMMs)."""
+        return sum(r[1] for r in self.records) / max(self.sampled, 1)
 
     def summary(self):
         out = {}
@@ -174,10 +221,36 @@ class KernelTimer(object):
                 continue
             ms = sum(r[2].elapsed_time(r[3]) for r in rs)
             fl = sum(r[1] for r in rs)
-            out[fam] = dict(launches=len(rs), total_ms=ms, avg_us=1e3 * ms / len(rs),
+            n = max(self.sampled, 1)
+            out[fam] = dict(launches=len(rs), launches_per_step=len(rs) / n, sampled_steps=self.sampled,
+                            total_ms=ms, ms_per_step=ms / n, avg_us=1e3 * ms / len(rs),
                             tflops=fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
                             flops_per_launch=fl / len(rs))
         return out
+
+
+def run_timed(one_step, steps, warmup, barrier, timer=None):
+    """`warmup` untimed steps, then EXACTLY `steps` steps timed between two barriers (barrier +
+    device synchronisation on both sides).  With a KernelTimer the last warm-up step creates its
+    events and the steps of `sample_steps` are instrumented.  Returns (seconds, last step's output)."""
+    samp = sample_steps(steps) if timer is not None else []
+    for i in range(warmup):
+        if timer is not None and i == warmup - 1:
+            timer.prepare(one_step, len(samp))
+        else:
+            one_step()
+    barrier()
+    t0 = time.perf_counter()
+    out = None
+    for i in range(steps):
+        if timer is not None:
+            timer.begin_step(i in samp)
+        out = one_step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if timer is not None:
+        timer.active = False
+    return dt, out
 
 
 def _rel(a, b):
@@ -614,7 +687,7 @@ def measure_host(one_step, reps=5):
             'gpu_ms_unstarved_all': [round(g, 3) for g in gpu], 'blocker_ms': block_ms, 'unstarved_ok': ok}
 
 
-def roofline_blocks(summary, peak_tf, wall_ms_total, fp32_run=True):
+def roofline_blocks(summary, peak_tf, ms_per_step, fp32_run=True):
     """`roofline` / `roofline_wgrad` sub-blocks of a workload from the live KernelTimer summary."""
     out = {}
     for fam, key, what in (('corr', 'roofline', 'conv/deconv forward + data gradient'),
@@ -624,8 +697,9 @@ def roofline_blocks(summary, peak_tf, wall_ms_total, fp32_run=True):
             out[key] = {'bound': 'mfma', 'kernel': what + (' (fp32 MFMA)' if fp32_run else ' (bf16 MFMA)'),
                         'achieved': r['tflops'], 'peak': peak_tf, 'unit': 'TFLOP/s',
                         'frac': r['tflops'] / peak_tf, 'avg_launch_us': r['avg_us'], 'launches': r['launches'],
+                        'launches_per_step': r['launches_per_step'], 'sampled_steps': r['sampled_steps'],
                         'gflop_per_launch': r['flops_per_launch'] / 1e9,
-                        'share_of_step_time': r['total_ms'] / wall_ms_total, 'traffic': None}
+                        'share_of_step_time': r['ms_per_step'] / ms_per_step, 'traffic': None}
     return out
 
 
@@ -635,16 +709,10 @@ def side_workload(shape, wsegan, dev, rank, world, B, steps, warmup, barrier, de
     (WSEGAN --misalign_pair) and the literal 11-layer stride-2 shape of config 2."""
     w = make_workload(shape, wsegan, dev, rank, B, device_z)
     try:
-        for _ in range(warmup):
-            w.one_step()
         timer = KernelTimer()
         timer.install()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            lo = w.one_step()
-        barrier()
-        dt = time.perf_counter() - t0
+        timer.active = False
+        dt, lo = run_timed(w.one_step, steps, warmup, barrier, timer)
         timer.uninstall()
         if world > 1:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -652,7 +720,7 @@ def side_workload(shape, wsegan, dev, rank, world, B, steps, warmup, barrier, de
             dt = float(t.item())
         ms = 1e3 * dt / steps
         value = B * world * steps / dt
-        booked = timer.booked_flops() / (B * steps) / 1e9
+        booked = timer.booked_flops_per_step() / B / 1e9
         out = {'workload': ('WSEGAN step with --misalign_pair (model.py:577-669; BASELINE config 4)' if wsegan
                             else 'original SEGAN shape: 11+11 layers of stride 2, k31 (train.py:199-205 flags; '
                                  'the shape BASELINE config 2 words as "11-layer enc/dec")' if shape == 'vanilla11'
@@ -665,7 +733,7 @@ def side_workload(shape, wsegan, dev, rank, world, B, steps, warmup, barrier, de
                'step_frac_executed': booked * value / 1e3 / PEAK_F32_MFMA_TF / world,
                'losses_finite': all(bool(torch.isfinite(x)) for x in lo),
                'z': 'device generator' if device_z else 'host randn one step ahead on a host thread + H2D'}
-        out.update(roofline_blocks(timer.summary(), PEAK_F32_MFMA_TF, 1e3 * dt))
+        out.update(roofline_blocks(timer.summary(), PEAK_F32_MFMA_TF, ms))
         if world == 1:
             h = measure_host(w.one_step)
             out['host'] = h
@@ -774,20 +842,14 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        one_step()
     timer = None
     if not args.no_kernel_timer:
         timer = KernelTimer()
         timer.install()
+        timer.active = False
     if world > 1:
         sdist.set_profile(True)         # two event records per optimizer step: comm_stats below
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        losses_out = one_step()
-    barrier()
-    dt = time.perf_counter() - t0
+    dt, losses_out = run_timed(one_step, args.steps, args.warmup, barrier, timer)
     if timer is not None:
         timer.uninstall()
     if world > 1:
@@ -799,7 +861,7 @@ def main():
         # what the engine EXECUTED, from the FLOPs the timed launches were booked with (round-5 review,
         # weak 7: the formula's "one D forward less" missed the skipped z half of dec0's data gradient
         # and the first layers' data gradients)
-        gflop_exec = timer.booked_flops() / (B * args.steps) / 1e9
+        gflop_exec = timer.booked_flops_per_step() / B / 1e9
     host = None
     if world == 1 and not args.no_host_measure:
         try:
@@ -912,18 +974,12 @@ def main():
                     model.G.z_prefetch = False
                     host_gen = True
                     model.G.z_generator = torch.Generator(device=dev).manual_seed(rank)
-                for _ in range(2):
-                    one_step()
                 mt = None
                 if not args.no_kernel_timer:
                     mt = KernelTimer()
                     mt.install()
-                barrier()
-                t1 = time.perf_counter()
-                for _ in range(args.steps):
-                    lo = one_step()
-                barrier()
-                dm = time.perf_counter() - t1
+                    mt.active = False
+                dm, lo = run_timed(one_step, args.steps, 2, barrier, mt)
                 if mt is not None:
                     mt.uninstall()
                 if world > 1:
@@ -945,8 +1001,8 @@ def main():
                             modes[prec][key] = {
                                 'bound': 'mfma', 'achieved': r['tflops'], 'peak': peak, 'unit': 'TFLOP/s',
                                 'frac': r['tflops'] / peak, 'avg_launch_us': r['avg_us'],
-                                'launches': r['launches'],
-                                'share_of_step_time': r['total_ms'] / (1e3 * dm),
+                                'launches': r['launches'], 'launches_per_step': r['launches_per_step'],
+                                'share_of_step_time': r['ms_per_step'] / (1e3 * dm / args.steps),
                                 'kernel': ('conv/deconv forward + data gradient' if fam == 'corr'
                                            else 'weight gradients') + ' on v_mfma_f32_32x32x16_bf16'}
             except Exception as e:      # a side measurement must never cost the headline line
@@ -1063,7 +1119,8 @@ def main():
                     'traffic_source': traffic_prov,
                     'avg_launch_us': c['avg_us'], 'launches': c['launches'],
                     'gflop_per_launch': c['flops_per_launch'] / 1e9,
-                    'share_of_step_time': c['total_ms'] / (1e3 * dt),
+                    'launches_per_step': c['launches_per_step'], 'sampled_steps': c['sampled_steps'],
+                    'share_of_step_time': c['ms_per_step'] / ms,
                     'mfma_pipe_busy_pmc': (pmc_mfma_busy('corr2', wl) if fp32_run else
                                            pmc_mfma_busy('corr_bf2', '_bf16' + wl) if args.precision == 'bf16'
                                            else None)}
@@ -1076,7 +1133,8 @@ def main():
                                           'achieved': w['tflops'], 'peak': peak_tf,
                                           'unit': 'TFLOP/s', 'frac': w['tflops'] / peak_tf,
                                           'avg_launch_us': w['avg_us'], 'launches': w['launches'],
-                                          'share_of_step_time': w['total_ms'] / (1e3 * dt),
+                                          'launches_per_step': w['launches_per_step'],
+                                          'share_of_step_time': w['ms_per_step'] / ms,
                                           'mfma_pipe_busy_pmc': (
                                               pmc_mfma_busy('wgrad2', wl) if fp32_run else
                                               pmc_mfma_busy('wgrad_bf2', '_bf16' + wl) if args.precision == 'bf16'

@@ -79,8 +79,10 @@ def test_bench_line_assembly_runs_without_a_gpu(prec, wsegan, shape):
 
     class Timer(object):
         def summary(self):
-            return {'corr': dict(tflops=100.0, avg_us=100.0, launches=10, flops_per_launch=1e12, total_ms=10.0),
-                    'wgrad': dict(tflops=90.0, avg_us=100.0, launches=5, total_ms=5.0)}
+            return {'corr': dict(tflops=100.0, avg_us=100.0, launches=10, flops_per_launch=1e12, total_ms=10.0,
+                                 ms_per_step=3.3, launches_per_step=3.3, sampled_steps=3),
+                    'wgrad': dict(tflops=90.0, avg_us=100.0, launches=5, total_ms=5.0, ms_per_step=1.7,
+                                  launches_per_step=1.7, sampled_steps=3)}
 
     ns = dict(vars(bench))
     ns.update(B=300, world=1, dt=0.9, ranks_seen=[0], devices_seen=[0], backend=None, finite=True, comm=None,
