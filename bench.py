@@ -211,9 +211,23 @@ class KernelTimer(object):
         """FLOPs the launches of one instrumented step were booked with: the matrix work the engine
         EXECUTES per step (conv / deconv forward, data and weight gradients, the dense-head and STFT
         GEMMs)."""
+        if self._done is not None:
+            return self._done[1]
         return sum(r[1] for r in self.records) / max(self.sampled, 1)
 
+    _done = None
+
+    def finish(self):
+        """Read the events (the device must be idle: call after the closing barrier), keep the figures
+        and DROP the events: hundreds of live timing events are destroyed here, outside any timed
+        region, not whenever the collector finds the timer."""
+        self._done = (self.summary(), self.booked_flops_per_step())
+        self.records, self._pool, self._next = [], [], 0
+        return self._done[0]
+
     def summary(self):
+        if self._done is not None:
+            return self._done[0]
         out = {}
         for fam in ('corr', 'wgrad', 'gemm'):
             rs = [r for r in self.records if r[0] == fam]
@@ -233,23 +247,34 @@ def run_timed(one_step, steps, warmup, barrier, timer=None):
     """`warmup` untimed steps, then EXACTLY `steps` steps timed between two barriers (barrier +
     device synchronisation on both sides).  With a KernelTimer the last warm-up step creates its
     events and the steps of `sample_steps` are instrumented.  Returns (seconds, last step's output)."""
+    import gc
     samp = sample_steps(steps) if timer is not None else []
     for i in range(warmup):
         if timer is not None and i == warmup - 1:
             timer.prepare(one_step, len(samp))
         else:
             one_step()
-    barrier()
-    t0 = time.perf_counter()
-    out = None
-    for i in range(steps):
-        if timer is not None:
-            timer.begin_step(i in samp)
-        out = one_step()
-    barrier()
-    dt = time.perf_counter() - t0
+    # no cyclic collection inside the timed region (a generation-2 pass over a process that holds two
+    # networks and thousands of tensors is tens of milliseconds of host time at a random launch)
+    gc.collect()
+    gc_was = gc.isenabled()
+    gc.disable()
+    try:
+        barrier()
+        t0 = time.perf_counter()
+        out = None
+        for i in range(steps):
+            if timer is not None:
+                timer.begin_step(i in samp)
+            out = one_step()
+        barrier()
+        dt = time.perf_counter() - t0
+    finally:
+        if gc_was:
+            gc.enable()
     if timer is not None:
         timer.active = False
+        timer.finish()
     return dt, out
 
 
@@ -620,6 +645,8 @@ def make_workload(shape, wsegan, dev, rank, B, device_z=False):
     else:
         model.G.z_prefetch = z_lookahead_ok(wsegan)     # as the training loops run it: next z one step ahead
     names = ['utt_additive_{}'.format(i) if i % 2 == 0 else 'utt_{}'.format(i) for i in range(B)]
+    from segan_pytorch_amd.models.model import _freeze_gc
+    _freeze_gc()        # as SEGAN.train / WSEGAN.train do when they start
 
     def one_step():
         # z=None: Generator.forward draws it, exactly as inside train.py's loop
