@@ -324,10 +324,41 @@ class Model(nn.Module):
         # only trainable parameters, as the reference (core.py:196-197)
         return filter(lambda p: p.requires_grad, super().parameters(recurse))
 
+    def all_params(self):
+        """Every parameter of the network (trainable or not) as a list, cached: the autograd nodes take
+        it on every forward, and walking the module tree (nn.Module.parameters) per call was a tenth of
+        the launch path's python time.  Dropped whenever the module tree can have changed: .to() /
+        .cuda() / .float() (`_apply`), load_state_dict, add_module / register_parameter on this module,
+        train() / eval()."""
+        ps = self.__dict__.get('_all_params')
+        if ps is None:
+            ps = self.__dict__['_all_params'] = list(nn.Module.parameters(self))
+        return ps
+
+    def _drop_param_cache(self):
+        self.__dict__.pop('_all_params', None)
+
+    def _apply(self, fn, *a, **k):
+        self._drop_param_cache()
+        return super()._apply(fn, *a, **k)
+
+    def add_module(self, name, module):
+        self._drop_param_cache()
+        return super().add_module(name, module)
+
+    def register_parameter(self, name, param):
+        self._drop_param_cache()
+        return super().register_parameter(name, param)
+
+    def train(self, mode=True):
+        self._drop_param_cache()
+        return super().train(mode)
+
     def get_n_params(self):
         return sum(p.numel() for p in self.parameters())
 
     def load_state_dict(self, state_dict, *args, **kwargs):
+        self._drop_param_cache()
         out = super().load_state_dict(state_dict, *args, **kwargs)
         from .. import ops
         ops.bump_weights_epoch()

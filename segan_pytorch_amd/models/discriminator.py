@@ -111,7 +111,7 @@ class Discriminator(Model):
             self._total_pool *= p
 
     def _fn_params(self):
-        return [p for p in nn.Module.parameters(self)]
+        return self.all_params()
 
     def draw_rolls(self):
         """One signed circular shift per layer, consuming python's `random` exactly as

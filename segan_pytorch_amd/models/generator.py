@@ -248,7 +248,7 @@ class Generator(Model):
                 torch.set_rng_state(job['state'])
 
     def _fn_params(self):
-        return [p for p in nn.Module.parameters(self)]
+        return self.all_params()
 
     def forward(self, x, z=None, ret_hid=False):
         if x.dim() != 3:

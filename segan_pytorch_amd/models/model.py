@@ -103,7 +103,8 @@ class _frozen(object):
     """Context manager: parameters of `module` do not require grad inside."""
 
     def __init__(self, module):
-        self.params = [p for p in nn.Module.parameters(module) if p.requires_grad]
+        ps = module.all_params() if hasattr(module, 'all_params') else nn.Module.parameters(module)
+        self.params = [p for p in ps if p.requires_grad]
 
     def __enter__(self):
         for p in self.params:

@@ -93,7 +93,9 @@ def get_precision():
 
 
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # the raw handle of torch's current stream on the current device: two C calls (torch.cuda.
+    # current_stream() builds a python Stream object per call: 3 us, twice per library call)
+    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
 
 
 def _ptr(t):
@@ -164,12 +166,12 @@ _corr_scratch = {}
 
 def _scratch():
     """(pointer, bytes) of this device+stream's stream-K scratch."""
-    st = torch.cuda.current_stream()
-    key = (st.device.index, st.cuda_stream)
+    dev = torch._C._cuda_getDevice()
+    key = (dev, torch._C._cuda_getCurrentRawStream(dev))
     buf = _corr_scratch.get(key)
     if buf is None:
         nbytes = _lib.load().segan_corr_scratch_bytes()
-        buf = torch.empty(nbytes, device=st.device, dtype=torch.uint8)
+        buf = torch.empty(nbytes, device=torch.device('cuda', dev), dtype=torch.uint8)
         _corr_scratch[key] = buf
     return ctypes.c_void_p(buf.data_ptr()), buf.numel()
 
@@ -202,13 +204,15 @@ def _stream_scratch(nbytes, device):
     and none keeps its scratch past its last kernel (round-3 advice: a fresh torch.empty of
     134+ MB per bf16 contraction call went through the caching allocator thousands of times per
     step)."""
-    st = torch.cuda.current_stream(device)
-    key = (st.device.index, st.cuda_stream)
+    dev = torch.device(device).index
+    if dev is None:
+        dev = torch._C._cuda_getDevice()
+    key = (dev, torch._C._cuda_getCurrentRawStream(dev))
     buf = _call_scratch.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = None
         _call_scratch.pop(key, None)          # release before growing
-        buf = torch.empty(int(nbytes), device=st.device, dtype=torch.uint8)
+        buf = torch.empty(int(nbytes), device=torch.device('cuda', dev), dtype=torch.uint8)
         _call_scratch[key] = buf
     return buf
 
