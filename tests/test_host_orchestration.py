@@ -393,6 +393,46 @@ def test_wsegan_interf_pair_literal_train(flavour, tmp_path):
     assert_weights_after_step(m.D.state_dict(), fx['D_final'], skip=NOISE_KEYS)
 
 
+def test_wsegan_train_keeps_the_z_lookahead_only_with_a_private_sampling_generator(tmp_path):
+    """WSEGAN.train draws a fresh batch every step.  With a plain loader that draw reseeds from
+    torch's global generator between two z draws (model.py:526-535, generator.py:197), so the next z
+    cannot be drawn ahead without changing the reference's stream: look-ahead off.  A loader whose
+    sample() uses its own generator (PCMShardLoader: `sample_keeps_global_rng`) leaves the global
+    generator to the z draws alone: look-ahead on for every step but the last, off again at the end."""
+    from conftest import load_golden
+    from segan_pytorch_amd.models import WSEGAN
+    fx = load_golden('tiny_wsegan2.pt')
+    o = dict(fx['opts'])
+    o['save_path'] = str(tmp_path)
+    o['epoch'] = 3
+
+    class Loader(object):
+        def __init__(self, private):
+            if private:
+                self.sample_keeps_global_rng = True
+            self.seen = []
+
+        def __len__(self):
+            return 1
+
+        def sample(self):
+            self.seen.append(m.G.z_prefetch)
+            return [fx['names'], fx['clean'], fx['noisy'], torch.zeros(3)]
+
+    for private, want in ((True, [False, True, True]), (False, [False, False, False])):
+        m = WSEGAN(SimpleNamespace(**o))
+        m.G.load_state_dict(fx['G0'])
+        m.D.load_state_dict(fx['D0'])
+        ld = Loader(private)
+        random.seed(1)
+        torch.manual_seed(1)
+        m.train(SimpleNamespace(**o), ld, None, o['l1_weight'], o['l1_dec_step'], o['l1_dec_epoch'], 1000,
+                va_dloader=None, device='cpu')
+        # sample() of step i sees the flag step i - 1 left: on after every step but the last
+        assert ld.seen == want, (private, ld.seen)
+        assert m.G.z_prefetch is False
+
+
 def _sum_merge_reference(sd, x, z):
     """generator.py:180-230 with skip_merge='sum' (GSkip.forward 64-74)."""
     import segan_oracle as O

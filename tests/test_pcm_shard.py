@@ -191,3 +191,47 @@ def test_loader_sample_leaves_the_global_generator_alone(tmp_path):
     assert got == want
     loader.close()
     assert loader._sample_loader is None
+
+
+@pytest.mark.gpu
+def test_wsegan_train_on_the_shard_loader_with_and_without_z_lookahead(tmp_path):
+    """WSEGAN.train over PCMShardLoader.sample() — the full-rate input path of train.py --wsegan
+    --pcm_shard: the next step's z is drawn one step ahead on a host thread (round 6), which is only
+    the reference's stream because sample() draws from a private generator.  Same seeds with the
+    look-ahead on (the default) and off (opts.prefetch_z False): the same weights, bit for bit."""
+    import random
+    from types import SimpleNamespace
+    from conftest import load_golden
+    from segan_pytorch_amd import ops
+    from segan_pytorch_amd.datasets import PCMShardLoader
+    from segan_pytorch_amd.models import WSEGAN
+    cd, nd = _write_wavs(tmp_path)
+    build_pcm_shard(cd, nd, str(tmp_path / 'sh'), slice_size=16384, stride=0.5)
+    ds = PCMShardDataset(str(tmp_path / 'sh'))
+    o = dict(load_golden('tiny_wsegan2.pt')['opts'])
+    o.update(save_path=str(tmp_path), epoch=2, dpool_slen=256, slice_size=16384, batch_size=4)
+    old = ops.get_deterministic()
+    ops.set_deterministic(True)
+    try:
+        out = {}
+        for pf in (True, False):
+            random.seed(3)
+            np.random.seed(3)
+            torch.manual_seed(3)
+            m = WSEGAN(SimpleNamespace(**o)).to('cuda')
+            loader = PCMShardLoader(ds, 4, 0.95, 'cuda', num_workers=0)
+            seen = []
+            real = m.wgan_step
+            m.wgan_step = lambda *a, **k: (seen.append(m.G.z_prefetch), real(*a, **k))[1]
+            oo = dict(o, prefetch_z=pf)
+            m.train(SimpleNamespace(**oo), loader, None, o['l1_weight'], o['l1_dec_step'], o['l1_dec_epoch'],
+                    1000, va_dloader=None, device='cuda')
+            n = 2 * len(loader)
+            assert seen == ([True] * (n - 1) + [False] if pf else [False] * n), (pf, seen)
+            out[pf] = {k: v.detach().cpu().clone() for k, v in list(m.G.state_dict().items()) +
+                       [('D.' + k, v) for k, v in m.D.state_dict().items()]}
+            loader.close()
+        for k, v in out[True].items():
+            assert torch.equal(v, out[False][k]), k
+    finally:
+        ops.set_deterministic(old)
