@@ -761,6 +761,10 @@ def side_workload(shape, wsegan, dev, rank, world, B, steps, warmup, barrier, de
                'losses_finite': all(bool(torch.isfinite(x)) for x in lo),
                'z': 'device generator' if device_z else 'host randn one step ahead on a host thread + H2D'}
         out.update(roofline_blocks(timer.summary(), PEAK_F32_MFMA_TF, ms))
+        if 'roofline' in out:
+            # HBM bytes per contraction launch from this workload's OWN committed rocprofv3 PMC passes
+            tr, prov = pmc_traffic(suffix=('_vanilla11' if shape == 'vanilla11' else '') + ('_wsegan' if wsegan else ''))
+            out['roofline']['traffic'], out['roofline']['traffic_source'] = tr, prov
         if world == 1:
             h = measure_host(w.one_step)
             out['host'] = h
@@ -1125,13 +1129,13 @@ def main():
             # counters belong to the workload they were collected on (round-4 review, weak 8: the
             # 11-layer side line used to carry the SEGAN+ profile's figures): the committed PMC
             # files are looked up by workload suffix and a workload without its own passes gets null
-            wl = ('_vanilla11' if args.shape == 'vanilla11' else '') + ('_wsegan' if args.wsegan else '')
+            wsuf = ('_vanilla11' if args.shape == 'vanilla11' else '') + ('_wsegan' if args.wsegan else '')
             if fp32_run:
-                traffic, traffic_prov = pmc_traffic(suffix=wl)
+                traffic, traffic_prov = pmc_traffic(suffix=wsuf)
             else:       # the bf16 profile exists for 'bf16' only
                 traffic, traffic_prov = (pmc_traffic(main=('corr_bf2_kernel', 'corr_bf_kernel'),
                                                      extra=('bf2_fixup_kernel', 'act_pack_kernel'),
-                                                     suffix='_bf16' + wl)
+                                                     suffix='_bf16' + wsuf)
                                          if args.precision == 'bf16' else (None, None))
             if c:
                 line['roofline'] = {
@@ -1148,8 +1152,8 @@ def main():
                     'gflop_per_launch': c['flops_per_launch'] / 1e9,
                     'launches_per_step': c['launches_per_step'], 'sampled_steps': c['sampled_steps'],
                     'share_of_step_time': c['ms_per_step'] / ms,
-                    'mfma_pipe_busy_pmc': (pmc_mfma_busy('corr2', wl) if fp32_run else
-                                           pmc_mfma_busy('corr_bf2', '_bf16' + wl) if args.precision == 'bf16'
+                    'mfma_pipe_busy_pmc': (pmc_mfma_busy('corr2', wsuf) if fp32_run else
+                                           pmc_mfma_busy('corr_bf2', '_bf16' + wsuf) if args.precision == 'bf16'
                                            else None)}
             if 'wgrad' in s:
                 w = s['wgrad']
@@ -1163,8 +1167,8 @@ def main():
                                           'launches_per_step': w['launches_per_step'],
                                           'share_of_step_time': w['ms_per_step'] / ms,
                                           'mfma_pipe_busy_pmc': (
-                                              pmc_mfma_busy('wgrad2', wl) if fp32_run else
-                                              pmc_mfma_busy('wgrad_bf2', '_bf16' + wl) if args.precision == 'bf16'
+                                              pmc_mfma_busy('wgrad2', wsuf) if fp32_run else
+                                              pmc_mfma_busy('wgrad_bf2', '_bf16' + wsuf) if args.precision == 'bf16'
                                               else None)}
         if side:
             side['note'] = ('BASELINE.json configs beside the headline, each a full fp32 GAN step at the same '
@@ -1181,7 +1185,7 @@ def main():
             line['other_precisions'] = modes
         if world == 1 and not args.no_cpu_baseline and args.shape == 'segan_plus' and not args.wsegan:
             try:
-                del model, Gopt, Dopt
+                del model, Gopt, Dopt, one_step, wl
                 torch.cuda.empty_cache()
                 line['cpu_baseline'], parity = cpu_baseline(
                     args.cpu_batch, args.cpu_steps, dev,
@@ -1198,7 +1202,7 @@ def main():
                 line['cpu_baseline'] = {'error': repr(e)}
         elif world == 1 and not args.no_cpu_baseline and args.shape == 'segan_plus' and args.wsegan:
             try:
-                del model, Gopt, Dopt
+                del model, Gopt, Dopt, one_step, wl
                 torch.cuda.empty_cache()
                 line['cpu_baseline'], par = wsegan_parity(opts, args.cpu_batch, dev)
                 line['speedup_vs_cpu_baseline'] = value / line['cpu_baseline']['value']
