@@ -351,12 +351,28 @@ PARITY_NOTE = ('HIP step vs the CPU oracle step timed above, same weights / inpu
                '(SEGAN_PREC_FP32_BLOCKED, opt-in: timed as ms_per_step_blocked_accumulation)')
 
 
+def port_vs_reference():
+    """The newest committed measurement of the oracle ("port") against the reference's literal
+    SEGAN.train on one host (oracle/time_ref_vs_port.py, build container: needs /root/reference)."""
+    path = _profile('ref_vs_port_cpu.json')
+    try:
+        d = json.load(open(path))
+        r = d['rows']
+        return ('{}: port / reference time per step {:.2f} (oneDNN on), {:.2f} (off) at batch {} on {} '
+                'threads in the build container'.format(os.path.relpath(path, ROOT),
+                                                        r['onednn_on']['port_over_reference'],
+                                                        r['onednn_off']['port_over_reference'], d['batch'],
+                                                        d['threads']))
+    except Exception:
+        return None
+
+
 def cpu_baseline(B=300, steps=3, dev=None, modes=('bf16x3', 'bf16')):
     """Time the CPU oracle's GAN step (oracle/segan_oracle.py: the reference's path restated on
     torch CPU ops; /root/reference does not exist on the GPU box, hence kind = 'port';
-    profiles/r04_ref_vs_port_cpu.json: timed back to back with the reference's literal SEGAN.train
-    in the build container the port takes 0.90 (oneDNN on) / 1.00 (off) of the reference's time
-    per step) on this host's cores at the metric's batch size, SURVEY.md 8d's protocol: per oneDNN
+    profiles/rNN_ref_vs_port_cpu.json: timed back to back with the reference's literal SEGAN.train
+    in the build container the port takes 0.90 - 1.00 (round 4) / 0.92 - 0.97 (round 6) of the
+    reference's time per step) on this host's cores at the metric's batch size, SURVEY.md 8d's protocol: per oneDNN
     setting one warm-up step at batch 8 (thread pools, allocator), then `steps` >= 3 timed steps
     at batch B; a setting's figure is the MEAN OF ITS STEPS >= 2, the FASTER setting is reported,
     min and mean both stated.  To bound the run (a step is 35-75 s on the boxes seen) the
@@ -421,8 +437,7 @@ def cpu_baseline(B=300, steps=3, dev=None, modes=('bf16x3', 'bf16')):
                seconds_per_step={k: {'steps': [round(t, 2) for t in v], 'min': round(min(v), 2),
                                      'mean_steps_ge2': round(fig[k], 2)} for k, v in results.items()},
                reported=best,
-               port_vs_reference='profiles/r04_ref_vs_port_cpu.json: port / reference time per step '
-                                 '0.90 (oneDNN on), 1.00 (off) at batch 32 in the build container',
+               port_vs_reference=port_vs_reference(),
                sample='oracle GAN step (SEGAN+ default net, fp32) at batch {}: warm-up at batch 8, then '
                       '{} timed steps with oneDNN on and {} with it off; value = batch / mean of the '
                       'steps >= 2 of the faster setting ({}); value_best_step = batch / its fastest '
