@@ -4,7 +4,7 @@ set -u
 R=${1:-r03}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/${R}p; rm -rf $O; mkdir -p $O
-B="python bench.py --no-modes --no-cpu-baseline --no-kernel-timer"
+B="python bench.py --no-modes --no-cpu-baseline --no-kernel-timer --no-side-workloads --no-host-measure"
 # per-kernel time of the step, fp32 (the default: deterministic reductions) and the bf16 modes
 for p in fp32 bf16 bf16x3; do
   rocprofv3 --kernel-trace --stats -d $O/prof_$p -o run -- $B --steps 6 --warmup 1 --precision $p > $O/bench_prof_$p.log 2>&1
