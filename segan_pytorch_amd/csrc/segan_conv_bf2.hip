@@ -725,11 +725,26 @@ __global__ __launch_bounds__(256) void pack_bf_f_kernel(const float* __restrict_
   const int RT = S == 1 ? 32 : 64;                 // rows per block (LDS: RT * (W + 1) floats)
   const int m0 = blockIdx.x * RT;
   auto t = [&](int ml, int x) -> float& { return tf[ml * (W + 1) + x]; };
-  for (int e = tid; e < RT * W; e += 256) {
-    const int ml = e / W, x = e - ml * W;
-    const int c = x >> 5, k = x & 31;
-    const int m = m0 + ml, n = n0 + c;
-    t(ml, x) = (m < M && n < N && k < K) ? w[((size_t)m * N + n) * K + k] : 0.0f;
+  // batches of 8 loads in flight per thread before their LDS stores (a rolled loop makes every
+  // load its own round trip: the packing ran at 1.1 - 1.3 TB/s until round 6)
+  for (int e0 = tid; e0 < RT * W; e0 += 8 * 256) {
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int e = e0 + 256 * i;
+      const int ml = e / W, x = e - ml * W;
+      const int c = x >> 5, k = x & 31;
+      const int m = m0 + ml, n = n0 + c;
+      v[i] = (e < RT * W && m < M && n < N && k < K) ? w[((size_t)m * N + n) * K + k] : 0.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int e = e0 + 256 * i;
+      if (e < RT * W) {
+        const int ml = e / W;
+        t(ml, e - ml * W) = v[i];
+      }
+    }
   }
   __syncthreads();
   for (int e = tid; e < U * RT; e += 256) {
@@ -759,11 +774,22 @@ __global__ __launch_bounds__(256) void pack_bf_t_kernel(const float* __restrict_
   const int hg = blockIdx.y;
   const int nn0 = blockIdx.x * 32;
   const int tid = threadIdx.x;
-  for (int e = tid; e < 8 * 32 * 32; e += 256) {
-    const int ml = e >> 10, x = e & 1023;
-    const int nl = x >> 5, k = x & 31;
-    const int m = 8 * hg + ml, nn = nn0 + nl;
-    t[ml][nl * 33 + k] = (m < M && nn < N && k < K) ? w[((size_t)m * N + nn) * K + k] : 0.0f;
+  for (int e0 = tid; e0 < 8 * 32 * 32; e0 += 8 * 256) {      // 8 loads in flight per thread
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int e = e0 + 256 * i;
+      const int ml = e >> 10, x = e & 1023;
+      const int nl = x >> 5, k = x & 31;
+      const int m = 8 * hg + ml, nn = nn0 + nl;
+      v[i] = (m < M && nn < N && k < K) ? w[((size_t)m * N + nn) * K + k] : 0.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int e = e0 + 256 * i;
+      const int ml = e >> 10, x = e & 1023;
+      t[ml][(x >> 5) * 33 + (x & 31)] = v[i];
+    }
   }
   __syncthreads();
   for (int e = tid; e < U * S * 32; e += 256) {

@@ -16,10 +16,22 @@ __global__ __launch_bounds__(256) void pack_f_kernel(const float* __restrict__ w
   const int n = blockIdx.y;                 // may run past N into the zero padding rows
   const int m0 = blockIdx.x * 64;
   const int tid = threadIdx.x;
-  for (int e = tid; e < 64 * 32; e += 256) {
-    const int ml = e >> 5, k = e & 31;
-    const int m = m0 + ml;
-    t[ml][k] = (m < M && n < N && k < K) ? w[((size_t)m * N + n) * K + k] : 0.0f;
+  // all 8 loads of a thread in flight before the first LDS store (left as a rolled loop the
+  // compiler issues load - wait - store eight times in a row: latency-bound, 2.8 TB/s)
+  {
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int e = tid + 256 * i;
+      const int ml = e >> 5, k = e & 31;
+      const int m = m0 + ml;
+      v[i] = (m < M && n < N && k < K) ? w[((size_t)m * N + n) * K + k] : 0.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int e = tid + 256 * i;
+      t[e >> 5][e & 31] = v[i];
+    }
   }
   // f_pair (K = 31): row 31 = (r, u) = (S-1, U-1), the padding tap k = 31, of an ODD channel
   // holds row 30 = (S-1, U-2), i.e. tap k = 31 - S, of its even partner n - 1 (segan_conv_shared.h)
@@ -45,10 +57,20 @@ __global__ __launch_bounds__(256) void pack_t_kernel(const float* __restrict__ w
   const int m = blockIdx.y;                 // may run past M into the zero padding rows
   const int n0 = blockIdx.x * 64;
   const int tid = threadIdx.x;
-  for (int e = tid; e < 64 * 32; e += 256) {
-    const int nl = e >> 5, k = e & 31;
-    const int n = n0 + nl;
-    t[nl][k] = (m < M && n < N && k < K) ? w[((size_t)m * N + n) * K + k] : 0.0f;
+  {
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int e = tid + 256 * i;
+      const int nl = e >> 5, k = e & 31;
+      const int n = n0 + nl;
+      v[i] = (m < M && n < N && k < K) ? w[((size_t)m * N + n) * K + k] : 0.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int e = tid + 256 * i;
+      t[e >> 5][e & 31] = v[i];
+    }
   }
   __syncthreads();
   for (int e = tid; e < 32 * 64; e += 256) {
