@@ -63,8 +63,12 @@ const char* segan_last_error(void);
  * slot with equal shares of the work, so a foreign kernel that holds n slots while one is launched
  * (RCCL's channels during a data-parallel step: one 256-thread workgroup each) delays it by a
  * whole share (+25-33 %), not by n / slots.  With a reserve of n the grids are planned for n fewer
- * workgroups.  Process-wide; returns the previous value.  (There is no reference counterpart: the
- * reference is single-GPU, README.md:79.) */
+ * workgroups.  Process-wide (an atomic: safe to call while other threads launch); returns the
+ * previous value.  The data-parallel path leaves it at 0 on purpose: measured with emulated 32-channel
+ * collectives behind the production reducer, a static reserve costs more (+2.3 ms per
+ * step while no collective is resident) than the delayed shares it avoids (+1.6 ms) — it is a knob
+ * for a first multi-GPU run, not a default.  (There is no reference counterpart: the reference is
+ * single-GPU, README.md:79.) */
 int segan_set_reserved_slots(int n);
 
 /* Bytes of packed-weight workspace segan_pack_weights needs for each form. */
