@@ -903,6 +903,9 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     finite = all(bool(torch.isfinite(x)) for x in losses_out)
+    # peak device memory of the warm-up + timed steps (no cyclic collection runs inside the timed region:
+    # the step must not depend on the collector to release its activations)
+    peak_gb = torch.cuda.max_memory_allocated(dev) / 2 ** 30
     if timer is not None and timer.sampled > 0:
         # what the engine EXECUTED, from the FLOPs the timed launches were booked with (round-5 review,
         # weak 7: the formula's "one D forward less" missed the skipped z half of dec0's data gradient
@@ -1104,6 +1107,7 @@ def main():
                        'global_batch': B * world, 'parallelism': 'dp{}'.format(world),
                        'z': 'device generator' if args.device_z else 'host randn (one step ahead on a host thread, as SEGAN.train) + H2D per step'},
             'losses_finite': finite,
+            'max_memory_allocated_gb': peak_gb,
             'comm': comm,
             'comm_wait_ms_per_step': comm['comm_wait_ms_per_step'] if comm else None,
             'precision': args.precision,

@@ -86,7 +86,7 @@ def test_bench_line_assembly_runs_without_a_gpu(prec, wsegan, shape):
 
     ns = dict(vars(bench))
     ns.update(B=300, world=1, dt=0.9, ranks_seen=[0], devices_seen=[0], backend=None, finite=True, comm=None,
-              timed_det=False, host=None, ms_other=90.0, ms_blocked=91.0, gflop=37.96, gflop_exec=35.84, timer=Timer(),
+              timed_det=False, host=None, peak_gb=30.0, ms_other=90.0, ms_blocked=91.0, gflop=37.96, gflop_exec=35.84, timer=Timer(),
               _ops=types.SimpleNamespace(get_accumulation=lambda: 'plain'),
               args=types.SimpleNamespace(steps=10, warmup=3, precision=prec, wsegan=wsegan, shape=shape,
                                          device_z=False))
