@@ -24,6 +24,15 @@ Prints ONE JSON line (rank 0):
   parity      BASELINE's second metric: the HIP step against that same oracle step (same
               weights, inputs, z and phase shifts): generator-output MSE / max-abs, losses and
               gradients
+  other_precisions   the same step with the contractions on the bf16 matrix cores (bf16x3, bf16 =
+              BASELINE config 5), timed beside the fp32 headline, never as `value`
+  other_workloads    BASELINE's other fp32 configurations, timed like the headline: `wsegan` (config 4:
+              --wsegan --misalign_pair) and `vanilla11` (the 11-layer stride-2 shape config 2 words),
+              each with its own roofline blocks, executed FLOPs and PMC traffic
+  host        what the launch path costs: host_enqueue_ms_per_step (python + ctypes + HIP launches of
+              one step, device idle at its start), gpu_ms_per_step_unstarved (HIP-event time of a step
+              whose launches were all queued behind a blocker), gpu_idle_ms_per_step = their gap to the
+              timed step
 """
 import argparse
 import json
