@@ -100,3 +100,57 @@ def test_bench_line_assembly_runs_without_a_gpu(prec, wsegan, shape):
     assert (line['step_frac_of_f32_mfma_peak'] is None) == (prec != 'fp32')
     assert abs(line['step_frac_of_mfma_peak'] - 37.96 * line['value'] / 1e3 / peak) < 1e-12
     assert prec in line['config']['workload'] or wsegan
+
+
+def test_kernel_timer_samples_three_steps_and_creates_its_events_before_the_timed_region(monkeypatch):
+    """bench.KernelTimer / run_timed (round 6: two freshly created timing events around every contraction
+    call made the 11-layer shape's step 78.6 instead of 68.1 ms in a fresh process).  On fakes: the last
+    warm-up step runs instrumented and creates the pool (three steps' worth of events), exactly the
+    first / middle / last timed steps are bracketed — from the pool, no event is created inside the timed
+    region —, the per-step figures divide by the sampled steps, and finish() drops the events."""
+    import types
+    sys.path.insert(0, ROOT)
+    import bench
+    import torch
+    from segan_pytorch_amd import ops
+    created = []
+
+    class Ev(object):
+        def __init__(self, enable_timing=False):
+            created.append(self)
+            self.n = 0
+
+        def record(self):
+            self.n += 1
+
+        def elapsed_time(self, other):
+            return 2.0
+
+    monkeypatch.setattr(torch.cuda, 'Event', Ev)
+    calls = []
+    monkeypatch.setattr(ops, 'gemm', lambda *a: calls.append(len(created)))
+    C = types.SimpleNamespace()
+    state = {'in_timed': False, 'created_in_timed': 0}
+
+    def one_step():
+        before = len(created)
+        ops.gemm(C, 0, 0, C, 0, 0, C, 4, 4, 4, True)
+        ops.gemm(C, 0, 0, C, 0, 0, C, 4, 4, 4, True)
+        if state['in_timed']:
+            state['created_in_timed'] += len(created) - before
+
+    def barrier():
+        state['in_timed'] = not state['in_timed']      # first call opens the timed region, second closes it
+
+    t = bench.KernelTimer()
+    t.install()
+    t.active = False
+    dt, _ = bench.run_timed(one_step, 10, 3, barrier, t)
+    t.uninstall()
+    assert bench.sample_steps(10) == [0, 5, 9] and bench.sample_steps(1) == [0] and bench.sample_steps(2) == [0, 1]
+    assert len(calls) == 2 * 13                          # 3 warm-up + 10 timed steps, instrumented or not
+    assert len(created) == 12 and state['created_in_timed'] == 0      # 2 calls x 2 events x 3 sampled steps
+    s = t.summary()['gemm']
+    assert t.sampled == 3 and s['launches'] == 6 and s['launches_per_step'] == 2.0 and s['sampled_steps'] == 3
+    assert abs(s['ms_per_step'] - 4.0) < 1e-12 and abs(t.booked_flops_per_step() - 2 * 128.0) < 1e-9
+    assert t.records == [] and t._pool == []             # finish(): nothing left for the collector to find
