@@ -252,7 +252,7 @@ class KernelTimer(object):
         return out
 
 
-def run_timed(one_step, steps, warmup, barrier, timer=None):
+def run_timed(one_step, steps, warmup, barrier, timer=None, on_timed_start=None):
     """`warmup` untimed steps, then EXACTLY `steps` steps timed between two barriers (barrier +
     device synchronisation on both sides).  With a KernelTimer the last warm-up step creates its
     events and the steps of `sample_steps` are instrumented.  Returns (seconds, last step's output)."""
@@ -268,6 +268,8 @@ def run_timed(one_step, steps, warmup, barrier, timer=None):
     gc.collect()
     gc_was = gc.isenabled()
     gc.disable()
+    if on_timed_start is not None:
+        on_timed_start()        # e.g. the data-parallel wait statistics: of the timed steps only
     try:
         barrier()
         t0 = time.perf_counter()
@@ -902,9 +904,9 @@ def main():
         timer = KernelTimer()
         timer.install()
         timer.active = False
-    if world > 1:
-        sdist.set_profile(True)         # two event records per optimizer step: comm_stats below
-    dt, losses_out = run_timed(one_step, args.steps, args.warmup, barrier, timer)
+    # world > 1: two event records per optimizer step of the TIMED steps (comm_stats below)
+    dt, losses_out = run_timed(one_step, args.steps, args.warmup, barrier, timer,
+                               on_timed_start=(lambda: sdist.set_profile(True)) if world > 1 else None)
     if timer is not None:
         timer.uninstall()
     if world > 1:
