@@ -1506,6 +1506,21 @@ static int launch_corr_tt(CorrArgs& a, hipStream_t st) {
       // tile is 64 channels x 2 phases — with 32 / 16 channels half / three quarters of its MFMAs
       // multiply padding.  64-row tiles (32 channels), and 32-row tiles (16 channels, both phases
       // inside one 32-row MFMA block: only without row shifts, i.e. for the conv data gradient)
+      // ... on 256 columns where the window allows it: these tiles' contractions are short (the conv
+      // data gradient of a 32-channel layer: 32 x 16 rows = 16 chunks), twice the columns halve what the
+      // per-tile prologue / epilogue weigh (SEGAN_T_WIDE=0: 128 columns, for A/B runs)
+      static const bool wide = [] { const char* e = getenv("SEGAN_T_WIDE"); return !(e && e[0] == '0'); }();
+      if (a.Nout <= 32 && wide) {
+        constexpr int NBW = 256;
+        CorrArgs b = a;
+        b.ncoltiles = ceil_div(b.Ctot, NBW);
+        b.RLs = NBW + samples_per_tile(b.Tcols, NBW) * b.H;
+        if (corr2_ok<U>(b, NBW)) {
+          a = b;
+          if (!SHIFT && a.Nout <= 16) return launch_corr2_t<32, NBW, 1, U, false, true, false>(a, st, true);
+          return launch_corr2_t<64, NBW, 1, U, false, true, SHIFT>(a, st, true);
+        }
+      }
       if (!SHIFT && a.Nout <= 16) return launch_corr2_t<32, NB, 1, U, false, true, false>(a, st, true);
       if (a.Nout <= 32) return launch_corr2_t<64, NB, 1, U, false, true, SHIFT>(a, st, true);
     }
