@@ -1506,11 +1506,13 @@ static int launch_corr_tt(CorrArgs& a, hipStream_t st) {
       // tile is 64 channels x 2 phases — with 32 / 16 channels half / three quarters of its MFMAs
       // multiply padding.  64-row tiles (32 channels), and 32-row tiles (16 channels, both phases
       // inside one 32-row MFMA block: only without row shifts, i.e. for the conv data gradient)
-      // ... on 256 columns where the window allows it: these tiles' contractions are short (the conv
-      // data gradient of a 32-channel layer: 32 x 16 rows = 16 chunks), twice the columns halve what the
-      // per-tile prologue / epilogue weigh (SEGAN_T_WIDE=0: 128 columns, for A/B runs)
+      // ... on 256 columns for the transposed-conv forward and for the 16-channel tile: twice the
+      // columns halve what the per-tile prologue / epilogue weigh.  Measured per layer on one box,
+      // alternating (round 6): deconv forward of 32 / 32 / 16 channels 0.611 / 0.608 / 0.635 -> 0.593 /
+      // 0.598 / 0.598 ms, conv data gradient into 16 channels 0.39 -> 0.37 ms, into 32 channels 0.36 ->
+      // 0.37 - 0.38 ms (worse: those keep 128 columns).  SEGAN_T_WIDE=0: 128 columns everywhere
       static const bool wide = [] { const char* e = getenv("SEGAN_T_WIDE"); return !(e && e[0] == '0'); }();
-      if (a.Nout <= 32 && wide) {
+      if (a.Nout <= 32 && wide && (a.halo == nullptr || a.Nout <= 16)) {
         constexpr int NBW = 256;
         CorrArgs b = a;
         b.ncoltiles = ceil_div(b.Ctot, NBW);

@@ -916,7 +916,7 @@ def test_stride2_conv_layers_take_the_small_row_tiles(name, N, M, L, roll, B):
     # per sample, 128 per tile
     tcols = B * ((L + 14 + 15 - 1) // 2 + 1)
     npt = 16 if N <= 16 else 32 if N <= 32 else 64
-    assert info_t['tiles'] == -(-N // npt) * -(-tcols // (256 if N <= 32 else 128))     # small-row T tiles: 256 columns
+    assert info_t['tiles'] == -(-N // npt) * -(-tcols // (256 if N <= 16 else 128))     # the 16-channel T tile: 256 columns
     assert info_w['tiles'] == -(-N * S // (128 // 16)) * 1       # one row tile of 32 / 64 rows
 
 
