@@ -460,6 +460,14 @@ __global__ __launch_bounds__(256, (NPL == 1 && NB == 128) ? 3 : 2) void corr_bf2
   int tile, c0, c1;
   if (tileA < a.sk_nfull) {
     tile = tileA; c0 = 0; c1 = nst;
+    if (a.tile_order) {
+      // each XCD (workgroup b runs on XCD b % 8, each with its own L2) a CONTIGUOUS range of the round's
+      // tiles; with the rows-first numbering below that is all row tiles of a run of column tiles: the
+      // workgroups resident on an XCD together share weight AND activation stages
+      const int rd = tileA / (int)gridDim.x;
+      const int left = a.sk_nfull - rd * (int)gridDim.x;
+      tile = rd * (int)gridDim.x + xcd_remap(blockIdx.x, left < (int)gridDim.x ? left : (int)gridDim.x);
+    }
     tileA += gridDim.x;
   } else if (unit < unit_end) {
     const int t = (int)(unit / nst);
@@ -471,8 +479,9 @@ __global__ __launch_bounds__(256, (NPL == 1 && NB == 128) ? 3 : 2) void corr_bf2
     break;
   }
   const bool partial = (c0 != 0) || (c1 != nst);
-  const int rowtile = a.rt0 + tile / a.ncoltiles;
-  const int coltile = tile % a.ncoltiles;
+  // tile -> (row tile, column tile): rows first (round 6) or columns first
+  const int coltile = a.tile_order ? tile / a.nrt : tile % a.ncoltiles;
+  const int rowtile = a.rt0 + (a.tile_order ? tile - coltile * a.nrt : tile / a.ncoltiles);
   const int m0 = rowtile * MB;
   const int n0 = rowtile * NPT;
   if (!OUT_HI) {
@@ -657,8 +666,8 @@ __global__ __launch_bounds__(256) void bf2_fixup_kernel(const CorrArgs a, int ns
   const int g_first = (int)(u0 / a.sk_units), g_last = (int)(u1 / a.sk_units);
   if (g_first == g_last) return;          // held whole by one workgroup: already stored
   const int tile = a.sk_nfull + t;
-  const int rowtile = a.rt0 + tile / a.ncoltiles;
-  const int coltile = tile % a.ncoltiles;
+  const int coltile = a.tile_order ? tile / a.nrt : tile % a.ncoltiles;
+  const int rowtile = a.rt0 + (a.tile_order ? tile - coltile * a.nrt : tile / a.ncoltiles);
   const int m0 = rowtile * MB, n0 = rowtile * NPT;
   if (!OUT_HI) {
     if (a.out0 == nullptr && m0 + MB <= a.OC0) return;
@@ -899,6 +908,17 @@ static int launch_bf2(CorrArgs a, Bf2Extra x, hipStream_t st) {
   a.rt0 = (!OUT_HI && a.out0 == nullptr) ? a.OC0 / MB : 0;
   const int ntiles = (nrowtiles - a.rt0) * a.ncoltiles;
   const int nst = x.ngroups * TCH;
+  // Tile order (round 6).  A bf16 tile streams 2 x 128 x K x 2 bytes of operands for 16x the matrix
+  // rate of an fp32 tile: these kernels move 2.5 - 3.8 TB/s of L2-miss traffic
+  // (profiles/r06_pmc_hbm_traffic_bf16.json) and what the fp32 kernels get for free — the re-fetches
+  // of a row-major tile walk served by the Infinity Cache — is on their critical path.  Rows first +
+  // XCD-contiguous ranges: the ~100 workgroups resident on an XCD cover all row tiles of a few
+  // column tiles and walk the contraction in step, so every weight stage is fetched once per column
+  // run and every activation stage once per XCD instead of once per workgroup.  SEGAN_BF2_ORDER=0:
+  // the columns-first walk of rounds 3 - 5.
+  static const int order = [] { const char* e = getenv("SEGAN_BF2_ORDER"); return e ? atoi(e) : 1; }();
+  a.tile_order = order ? 1 : 0;
+  a.nrt = nrowtiles - a.rt0;
   a.sk_nfull = ntiles;
   a.sk_units = 0;
   a.sk_total = 0;

@@ -83,6 +83,7 @@ struct CorrArgs {
   int RLv, nld;                // corr2: valid window positions (RLs is the padded row), loads per lane
   int f_pair;                  // F form, K = 31: the packing pairs the channels (f_pair() below)
   int zphase;                  // T form, K = 31: the output phase whose tap u' = 0 is the zero tap, else -1
+  int tile_order, nrt;         // bf16 kernels: 1 = tiles numbered rows-first (nrt row tiles per column tile), XCD-contiguous
 };
 
 // (*) 16-byte buffer stores take their row offset in the VECTOR offset, never in an SGPR soffset.
