@@ -908,15 +908,17 @@ static int launch_bf2(CorrArgs a, Bf2Extra x, hipStream_t st) {
   a.rt0 = (!OUT_HI && a.out0 == nullptr) ? a.OC0 / MB : 0;
   const int ntiles = (nrowtiles - a.rt0) * a.ncoltiles;
   const int nst = x.ngroups * TCH;
-  // Tile order (round 6).  A bf16 tile streams 2 x 128 x K x 2 bytes of operands for 16x the matrix
-  // rate of an fp32 tile: these kernels move 2.5 - 3.8 TB/s of L2-miss traffic
-  // (profiles/r06_pmc_hbm_traffic_bf16.json) and what the fp32 kernels get for free — the re-fetches
-  // of a row-major tile walk served by the Infinity Cache — is on their critical path.  Rows first +
-  // XCD-contiguous ranges: the ~100 workgroups resident on an XCD cover all row tiles of a few
-  // column tiles and walk the contraction in step, so every weight stage is fetched once per column
-  // run and every activation stage once per XCD instead of once per workgroup.  SEGAN_BF2_ORDER=0:
-  // the columns-first walk of rounds 3 - 5.
-  static const int order = [] { const char* e = getenv("SEGAN_BF2_ORDER"); return e ? atoi(e) : 1; }();
+  // Tile order (round 6 experiment, kept behind SEGAN_BF2_ORDER=1).  A bf16 tile streams 2 x 128 x K x 2
+  // bytes of operands for 16x the matrix rate of an fp32 tile, and these kernels move 2.5 - 3.8 TB/s of
+  // L2-miss traffic (profiles/r06_pmc_hbm_traffic_bf16.json) — is the re-fetching of the columns-first
+  // tile walk, which the fp32 kernels were measured to get for free (round 5), on THEIR critical path?
+  // Rows first + XCD-contiguous ranges (the ~100 workgroups resident on an XCD cover all row tiles of
+  // a few column tiles and walk the contraction in step) against the columns-first walk, alternating
+  // on one box (profiles/r06_bf16_tile_order_ab.json): every layer within +-1 % (the conv data
+  // gradient of enc1 +6 %, dec0 +2 % slower), the step 24.04 / 24.08 -> 23.97 / 24.04 ms.  No: the
+  // re-fetches are served by the Infinity Cache here too and nothing waits for them.  Default: the
+  // walk of rounds 3 - 5.
+  static const int order = [] { const char* e = getenv("SEGAN_BF2_ORDER"); return e ? atoi(e) : 0; }();
   a.tile_order = order ? 1 : 0;
   a.nrt = nrowtiles - a.rt0;
   a.sk_nfull = ntiles;
