@@ -800,6 +800,10 @@ def side_workload(shape, wsegan, dev, rank, world, B, steps, warmup, barrier, de
             # HBM bytes per contraction launch from this workload's OWN committed rocprofv3 PMC passes
             tr, prov = pmc_traffic(suffix=('_vanilla11' if shape == 'vanilla11' else '') + ('_wsegan' if wsegan else ''))
             out['roofline']['traffic'], out['roofline']['traffic_source'] = tr, prov
+            sfx = ('_vanilla11' if shape == 'vanilla11' else '') + ('_wsegan' if wsegan else '')
+            out['roofline']['mfma_pipe_busy_pmc'] = pmc_mfma_busy('corr2', sfx)
+            if 'roofline_wgrad' in out:
+                out['roofline_wgrad']['mfma_pipe_busy_pmc'] = pmc_mfma_busy('wgrad2', sfx)
         if world == 1:
             h = measure_host(w.one_step)
             out['host'] = h

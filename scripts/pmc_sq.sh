@@ -1,6 +1,6 @@
 #!/bin/bash
 # SQ counter passes (MFMA busy, VALU per MFMA, LDS / wait buckets) over the per-layer bench of
-# the contraction kernels.  usage: scripts/pmc_sq.sh OUTDIR LAYER [LAYER...]   (e.g. enc2 dec2)
+# the contraction kernels.  usage: [SHAPE=vanilla11] scripts/pmc_sq.sh OUTDIR LAYER [LAYER...]   (e.g. enc2 dec2)
 # Counters only (no --sys-trace etc.): two passes of 8 SQ counters each, as the 8 SQ slots allow.
 set -u
 out=$1; shift
@@ -11,6 +11,6 @@ for layer in "$@"; do
   for pass in A B; do
     c=$A; [ $pass = B ] && c=$B
     rocprofv3 --pmc $c --kernel-trace -d $out/sq${pass}_$layer -o run --output-format csv -- \
-      python scripts/bench_layers.py --iters 1 --only $layer > $out/sq${pass}_$layer.log 2>&1
+      python scripts/bench_layers.py --iters 1 --only $layer ${SHAPE:+--shape $SHAPE} > $out/sq${pass}_$layer.log 2>&1
   done
 done
