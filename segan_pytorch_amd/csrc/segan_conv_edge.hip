@@ -286,6 +286,74 @@ int segan_launch_tsmall(CorrArgs& a, const float* w, int K, int M, int N, int S,
 }
 
 
+// Staging of the F-form edge kernels with a thread's loads IN FLIGHT TOGETHER (round 6): written as
+// rolled loops `for (j = tid; j < n; j += 256) lds[j] = f(global[g(j)])` the compiler issues load -
+// s_waitcnt vmcnt(0) - store once per element, i.e. 17 (+ 16 for the weights) dependent HBM round
+// trips per workgroup before its first FMA — most of the kernel's duration.  Addresses are clamped so
+// that the loads are unconditional; the mask is applied to the loaded value.
+template <int S, int N, int XW>
+__device__ __forceinline__ void fsmall_stage_window(const CorrArgs& a, int b, int t0, int tid,
+                                                    float (&xs)[N][XW]) {
+  constexpr int NX = (XW + 255) / 256;
+  constexpr int BT = 6;                      // positions per batch (x N channels of loads in flight)
+  const float* rows[N];
+  ChanXf xf[N];
+#pragma unroll
+  for (int n = 0; n < N; ++n) {
+    rows[n] = segan_src_row(a.in, b, n, a.Lin);
+    xf[n] = segan_chan_xf(a.in, n);
+  }
+#pragma unroll
+  for (int g0 = 0; g0 < NX; g0 += BT) {
+    float v[N][BT];
+    int idx[BT];
+#pragma unroll
+    for (int i = 0; i < BT; ++i) {
+      const int j = tid + 256 * (g0 + i);
+      idx[i] = (g0 + i < NX && j < XW) ? segan_hi_index(S * t0 + j, a.Lin, a.padL, a.mode, a.roll) : -1;
+#pragma unroll
+      for (int n = 0; n < N; ++n) v[n][i] = rows[n][idx[i] >= 0 ? idx[i] : 0];
+    }
+#pragma unroll
+    for (int i = 0; i < BT; ++i) {
+      const int j = tid + 256 * (g0 + i);
+      if (g0 + i < NX && j < XW) {
+#pragma unroll
+        for (int n = 0; n < N; ++n) xs[n][j] = idx[i] >= 0 ? segan_apply_xf(xf[n], v[n][i]) : 0.0f;
+      }
+    }
+  }
+}
+
+// 64 output channels x N x 32 taps of the packed F layout into ws[ml * WST + n * 32 + k]
+template <int S, int N, int WST>
+__device__ __forceinline__ void fsmall_stage_weights(const CorrArgs& a, int m0, int tid, float* ws) {
+  constexpr int U = 32 / S;
+  constexpr int NW = 64 * N * 32 / 256;      // elements per thread
+  constexpr int BT = 8;
+  static_assert(NW % BT == 0, "weight staging batches");
+#pragma unroll
+  for (int g0 = 0; g0 < NW; g0 += BT) {
+    float v[BT];
+#pragma unroll
+    for (int i = 0; i < BT; ++i) {
+      const int e = tid + 256 * (g0 + i);
+      const int ml = e & 63, nk = e >> 6;
+      const int n = nk >> 5, k = nk & 31;
+      const int row = (n * S + k % S) * U + k / S;
+      const int m = m0 + ml;
+      v[i] = a.wp[(size_t)row * a.RP + (m < a.RP ? m : 0)];
+      v[i] = m < a.RP ? v[i] : 0.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < BT; ++i) {
+      const int e = tid + 256 * (g0 + i);
+      const int ml = e & 63, nk = e >> 6;
+      ws[ml * WST + (nk >> 5) * 32 + (nk & 31)] = v[i];
+    }
+  }
+}
+
 // ====================================================================================
 // F form for 1-2 input channels (the first conv of G and of D: HBM-bound, and an MFMA tile
 // whose contraction is N*32 <= 64 deep would be mostly the padding to the 64-deep LDS chunk).
@@ -296,7 +364,6 @@ int segan_launch_tsmall(CorrArgs& a, const float* w, int K, int M, int N, int S,
 // ====================================================================================
 template <int S, int N>
 __global__ __launch_bounds__(256) void fsmall_kernel(const CorrArgs a, int M) {
-  constexpr int U = 32 / S;
   constexpr int XW = S * 256 + 32;
   constexpr int WST = N * 32 + 4;          // row stride of the weight copy (16-B aligned)
   __shared__ __attribute__((aligned(16))) float xs[N][XW];
@@ -304,26 +371,12 @@ __global__ __launch_bounds__(256) void fsmall_kernel(const CorrArgs a, int M) {
   const int tid = threadIdx.x;
   const int b = blockIdx.y;
   const int t0 = blockIdx.x * 256;
-  for (int j = tid; j < XW; j += 256) {
-    const int idx = segan_hi_index(S * t0 + j, a.Lin, a.padL, a.mode, a.roll);
-#pragma unroll
-    for (int n = 0; n < N; ++n) {
-      float v = 0.0f;
-      if (idx >= 0) v = segan_apply_xf(segan_chan_xf(a.in, n), segan_src_row(a.in, b, n, a.Lin)[idx]);
-      xs[n][j] = v;
-    }
-  }
+  fsmall_stage_window<S, N, XW>(a, b, t0, tid, xs);
   const int t = t0 + tid;
   for (int m0 = 0; m0 < M; m0 += 64) {
     // packed F layout: w[m][n][S*u + r] = wp[((n*S + r)*U + u) * RP + m]; rows of taps >= K
     // are zero.  Lanes run along m so the global reads are coalesced.
-    for (int e = tid; e < 64 * N * 32; e += 256) {
-      const int ml = e & 63, nk = e >> 6;
-      const int n = nk >> 5, k = nk & 31;
-      const int row = (n * S + k % S) * U + k / S;
-      const int m = m0 + ml;
-      ws[ml * WST + n * 32 + k] = m < a.RP ? a.wp[(size_t)row * a.RP + m] : 0.0f;
-    }
+    fsmall_stage_weights<S, N, WST>(a, m0, tid, ws);
     __syncthreads();
     float xv[N][32];
 #pragma unroll
@@ -363,7 +416,7 @@ __global__ __launch_bounds__(256) void fsmall_kernel(const CorrArgs a, int M) {
 // stores 16 contiguous bytes per output channel.  A workgroup covers 1024 positions.
 template <int N>
 __global__ __launch_bounds__(256) void fsmall4_kernel(const CorrArgs a, int M) {
-  constexpr int S = 4, U = 8, Q = 4;
+  constexpr int S = 4, Q = 4;
   constexpr int XW = S * Q * 256 + 32;     // padded input samples a workgroup touches
   constexpr int WST = N * 32 + 4;
   constexpr int XR = S * (Q - 1) + 32;     // 44 input samples per thread and channel
@@ -372,24 +425,10 @@ __global__ __launch_bounds__(256) void fsmall4_kernel(const CorrArgs a, int M) {
   const int tid = threadIdx.x;
   const int b = blockIdx.y;
   const int t0 = blockIdx.x * (Q * 256);
-  for (int j = tid; j < XW; j += 256) {
-    const int idx = segan_hi_index(S * t0 + j, a.Lin, a.padL, a.mode, a.roll);
-#pragma unroll
-    for (int n = 0; n < N; ++n) {
-      float v = 0.0f;
-      if (idx >= 0) v = segan_apply_xf(segan_chan_xf(a.in, n), segan_src_row(a.in, b, n, a.Lin)[idx]);
-      xs[n][j] = v;
-    }
-  }
+  fsmall_stage_window<S, N, XW>(a, b, t0, tid, xs);
   const int t = t0 + Q * tid;
   for (int m0 = 0; m0 < M; m0 += 64) {
-    for (int e = tid; e < 64 * N * 32; e += 256) {
-      const int ml = e & 63, nk = e >> 6;
-      const int n = nk >> 5, k = nk & 31;
-      const int row = (n * S + k % S) * U + k / S;
-      const int m = m0 + ml;
-      ws[ml * WST + n * 32 + k] = m < a.RP ? a.wp[(size_t)row * a.RP + m] : 0.0f;
-    }
+    fsmall_stage_weights<S, N, WST>(a, m0, tid, ws);
     __syncthreads();
     float xv[N][XR];
 #pragma unroll
