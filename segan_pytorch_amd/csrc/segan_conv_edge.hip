@@ -169,24 +169,33 @@ __global__ __launch_bounds__(256) void tsmall4_kernel(const CorrArgs a, const fl
     if (ok) sok |= 1u << i;
   }
   const int bo0 = b * a.in.C0 * a.Lin, bo1 = b * a.in.C1 * a.Lin;
+  // the 8 x 5 loads of the NEXT chunk of input channels are issued before the FMAs of the current one
+  // (round 6: issued after them, every chunk began with an exposed HBM round trip)
+  float pv[MC][5];
+  auto load_rows = [&](int mc0) {
+#pragma unroll
+    for (int mc = 0; mc < MC; ++mc) {
+      const int m = mc0 + mc < M ? mc0 + mc : 0;
+      const bool seg1 = m >= a.in.C0;
+      const float* rowp = seg1 ? a.in.p1 + (size_t)(m - a.in.C0) * a.Lin + bo1
+                               : a.in.p0 + (size_t)m * a.Lin + bo0;
+#pragma unroll
+      for (int i = 0; i < 5; ++i) pv[mc][i] = rowp[so[i]];
+    }
+  };
+  load_rows(0);
   for (int mc0 = 0; mc0 < M; mc0 += MC) {
 #pragma unroll
     for (int mc = 0; mc < MC; ++mc) {
       const bool mok = mc0 + mc < M;
-      const int m = mok ? mc0 + mc : 0;
-      const bool seg1 = m >= a.in.C0;
-      const float* rowp = seg1 ? a.in.p1 + (size_t)(m - a.in.C0) * a.Lin + bo1
-                               : a.in.p0 + (size_t)m * a.Lin + bo0;
-      const ChanXf xf = segan_chan_xf(a.in, m);
-      float v[5];
-#pragma unroll
-      for (int i = 0; i < 5; ++i) v[i] = rowp[so[i]];
+      const ChanXf xf = segan_chan_xf(a.in, mok ? mc0 + mc : 0);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        xs[mc][tid + 256 * i] = (mok && ((sok >> i) & 1u)) ? segan_apply_xf(xf, v[i]) : 0.0f;
-      if (tid < 12) xs[mc][1024 + tid] = (mok && ((sok >> 4) & 1u)) ? segan_apply_xf(xf, v[4]) : 0.0f;
+        xs[mc][tid + 256 * i] = (mok && ((sok >> i) & 1u)) ? segan_apply_xf(xf, pv[mc][i]) : 0.0f;
+      if (tid < 12) xs[mc][1024 + tid] = (mok && ((sok >> 4) & 1u)) ? segan_apply_xf(xf, pv[mc][4]) : 0.0f;
     }
     __syncthreads();
+    if (mc0 + MC < M) load_rows(mc0 + MC);
     const int mcn = min(MC, M - mc0);
     for (int mc = 0; mc < mcn; ++mc) {
       float xv[12];
