@@ -39,20 +39,30 @@ __global__ __launch_bounds__(256) void tsmall_kernel(const CorrArgs a, const flo
   const bool ok0 = t0 >= 0 && t0 < a.Lin, ok1 = tid < U && t1 >= 0 && t1 < a.Lin;
   const int o0 = ok0 ? t0 : 0, o1 = ok1 ? t1 : 0;
   const int bo0 = b * a.in.C0 * a.Lin, bo1 = b * a.in.C1 * a.Lin;
-  for (int mc0 = 0; mc0 < M; mc0 += MC) {
-#pragma unroll 8
+  // the next chunk's 16 x 2 loads are issued before the FMAs of the current chunk (round 6, as tsmall4)
+  float pv0[MC], pv1[MC];
+  auto load_rows = [&](int mc0) {
+#pragma unroll
     for (int mc = 0; mc < MC; ++mc) {
       const int m = mc0 + mc < M ? mc0 + mc : 0;
       const bool seg1 = m >= a.in.C0;
       const float* rowp = seg1 ? a.in.p1 + (size_t)(m - a.in.C0) * a.Lin + bo1
                                : a.in.p0 + (size_t)m * a.Lin + bo0;
-      const ChanXf xf = segan_chan_xf(a.in, m);
-      const float v0 = rowp[o0], v1 = rowp[o1];
+      pv0[mc] = rowp[o0];
+      pv1[mc] = rowp[o1];
+    }
+  };
+  load_rows(0);
+  for (int mc0 = 0; mc0 < M; mc0 += MC) {
+#pragma unroll
+    for (int mc = 0; mc < MC; ++mc) {
       const bool mok = mc0 + mc < M;
-      xs[mc][tid] = (mok && ok0) ? segan_apply_xf(xf, v0) : 0.0f;
-      if (tid < U) xs[mc][256 + tid] = (mok && ok1) ? segan_apply_xf(xf, v1) : 0.0f;
+      const ChanXf xf = segan_chan_xf(a.in, mok ? mc0 + mc : 0);
+      xs[mc][tid] = (mok && ok0) ? segan_apply_xf(xf, pv0[mc]) : 0.0f;
+      if (tid < U) xs[mc][256 + tid] = (mok && ok1) ? segan_apply_xf(xf, pv1[mc]) : 0.0f;
     }
     __syncthreads();
+    if (mc0 + MC < M) load_rows(mc0 + MC);
     const int mcn = min(MC, M - mc0);
     for (int mc = 0; mc < mcn; ++mc) {
       float xv[U + 1];
