@@ -777,9 +777,10 @@ static int launch_wgrad2_rows(WgradArgs& a, hipStream_t st, bool deterministic, 
   return launch_wgrad2<U, XF, 128>(a, st, deterministic, slabs, slab_floats_avail);
 }
 
-template <int U, bool LO_ID, bool HI_ID, int MB, int NBT, int TK = 32>
+template <int U, bool LO_ID, bool HI_ID, int MB, int NBT>
 static int launch_wgrad_tile(WgradArgs& a, hipStream_t st, float* slabs, size_t slab_floats) {
   constexpr int CVW = NBT / U;
+  constexpr int TK = 32;
   int NS;
   if (a.Ls >= TK) NS = (a.Ls % TK == 0) ? 1 : 2;
   else NS = (TK % a.Ls == 0) ? TK / a.Ls : (TK + a.Ls - 2) / a.Ls + 1;
@@ -856,14 +857,6 @@ static int launch_wgrad_x(WgradArgs& a, hipStream_t st, float* slabs, size_t sla
   // edge layers (1-2 channels on the hi side: N*S <= 64/U virtual channels): 64 columns
   // suffice, and 64 rows when M <= 64
   if (a.Cv <= 64 / U) {
-    // long rows (the first conv / last deconv of the audio nets: thousands of positions per sample):
-    // contraction chunks of 64 columns — a 64 x 64 tile is ONE MFMA block per wave, 16 MFMAs per
-    // 32-column chunk against ~10 loads and a barrier; twice the columns per chunk halve that overhead
-    static const bool wide = [] { const char* e = getenv("SEGAN_WGRAD_EDGE_TK64"); return !(e && e[0] == '0'); }();
-    if (wide && a.Ls >= 256 && a.Ls % 64 == 0) {
-      if (a.M <= 64) return launch_wgrad_tile<U, LO_ID, HI_ID, 64, 64, 64>(a, st, slabs, slab_floats);
-      return launch_wgrad_tile<U, LO_ID, HI_ID, 128, 64, 64>(a, st, slabs, slab_floats);
-    }
     if (a.M <= 64) return launch_wgrad_tile<U, LO_ID, HI_ID, 64, 64>(a, st, slabs, slab_floats);
     return launch_wgrad_tile<U, LO_ID, HI_ID, 128, 64>(a, st, slabs, slab_floats);
   }
