@@ -159,13 +159,15 @@ __global__ __launch_bounds__(256) void tsmall4_kernel(const CorrArgs a, const fl
   const int tid = threadIdx.x;
   const int b = blockIdx.y;
   const int q0 = blockIdx.x * (Q * 256);
-  float acc[Q][S][N];
+  // accumulators of two ADJACENT positions share a register pair (i = 2*ip, 2*ip + 1): see the FMAs
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  f32x2 acc[Q / 2][S][N];
 #pragma unroll
-  for (int i = 0; i < Q; ++i)
+  for (int i = 0; i < Q / 2; ++i)
 #pragma unroll
     for (int r = 0; r < S; ++r)
 #pragma unroll
-      for (int n = 0; n < N; ++n) acc[i][r][n] = 0.0f;
+      for (int n = 0; n < N; ++n) acc[i][r][n] = f32x2{0.0f, 0.0f};
   // staging: window entry j <-> input time q0 + win_start + j; thread owns entries
   // tid + 256*i (i < 4) and 1024 + tid (tid < 12)
   int so[5];
@@ -208,13 +210,31 @@ __global__ __launch_bounds__(256) void tsmall4_kernel(const CorrArgs a, const fl
     if (mc0 + MC < M) load_rows(mc0 + MC);
     const int mcn = min(MC, M - mc0);
     for (int mc = 0; mc < mcn; ++mc) {
-      float xv[12];
+      // PACKED FMAs over pairs of positions (round 6; scripts/micro/pkfma.hip: 138 TF/s against 75 for
+      // v_fmac_f32 — the kernel ran at 45 - 52 TF/s): the tap is one half of an SGPR pair broadcast to
+      // both lanes by op_sel, the samples x[j], x[j+1] a VGPR pair — the 12-sample window is held
+      // twice, as the even pairs (0,1) .. (10,11) of the 16-byte reads and as the odd pairs (1,2) ..
+      // (9,10) read again from LDS.  Every accumulator sees the same FMA sequence as before.
+      f32x2 xe[6], xo[5];
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
         const f32x4 t4 = *reinterpret_cast<const f32x4*>(&xs[mc][4 * tid + 4 * i]);
-        xv[4 * i] = t4[0]; xv[4 * i + 1] = t4[1]; xv[4 * i + 2] = t4[2]; xv[4 * i + 3] = t4[3];
+        xe[2 * i] = f32x2{t4[0], t4[1]};
+        xe[2 * i + 1] = f32x2{t4[2], t4[3]};
       }
-      const float* wm = w + (size_t)(mc0 + mc) * N * KT;
+#pragma unroll
+      for (int i = 0; i < 5; ++i) xo[i] = f32x2{xs[mc][4 * tid + 2 * i + 1], xs[mc][4 * tid + 2 * i + 2]};
+      // the N x 31 taps of input channel m as pairs of the flat index f = n*31 + k (wave-uniform
+      // scalar loads, 4-byte aligned); with N = 1 the odd tap 30 is the high half of the pair (29, 30)
+      typedef const __attribute__((address_space(4))) float cfl;
+      constexpr int NPW = (N * KT + 1) / 2;
+      cfl* wm = (cfl*)w + (size_t)(mc0 + mc) * N * KT;
+      f32x2 wp[NPW];
+#pragma unroll
+      for (int p = 0; p < NPW; ++p) {
+        const int f0 = 2 * p + 1 < N * KT ? 2 * p : N * KT - 2;
+        wp[p] = f32x2{wm[f0], wm[f0 + 1]};
+      }
 #pragma unroll
       for (int r = 0; r < S; ++r) {
         const int rho = (r + PM) % S, cs = (r + PM) / S;
@@ -224,10 +244,20 @@ __global__ __launch_bounds__(256) void tsmall4_kernel(const CorrArgs a, const fl
           if (k < KT) {
 #pragma unroll
             for (int n = 0; n < N; ++n) {
-              const float wv = wm[n * KT + k];
+              const int f = n * KT + k;
+              const bool last = 2 * (f >> 1) + 1 >= N * KT;     // the unpaired last tap (N*KT odd)
+              const int p = f >> 1, h = last ? 1 : (f & 1);
 #pragma unroll
-              for (int i = 0; i < Q; ++i)
-                acc[i][r][n] = fmaf(wv, xv[i + cs + (U - 1) - u], acc[i][r][n]);
+              for (int ip = 0; ip < Q / 2; ++ip) {
+                const int j = 2 * ip + cs + (U - 1) - u;
+                const f32x2 xp = (j & 1) ? xo[j >> 1] : xe[j >> 1];
+                if (h)
+                  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]"
+                      : "+v"(acc[ip][r][n]) : "s"(wp[p]), "v"(xp));
+                else
+                  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]"
+                      : "+v"(acc[ip][r][n]) : "s"(wp[p]), "v"(xp));
+              }
             }
           }
         }
@@ -246,7 +276,7 @@ __global__ __launch_bounds__(256) void tsmall4_kernel(const CorrArgs a, const fl
       float v[S];
 #pragma unroll
       for (int r = 0; r < S; ++r) {
-        v[r] = acc[i][r][n] + bs;
+        v[r] = acc[i >> 1][r][n][i & 1] + bs;
         if (a.act == SEGAN_ACT_TANH) v[r] = tanhf(v[r]);
       }
       const int i0 = S * q - a.o_padL;
@@ -430,68 +460,137 @@ __global__ __launch_bounds__(256) void fsmall_kernel(const CorrArgs a, int M) {
 }
 
 
-// The same F form with FOUR consecutive output positions per thread (stride 4): the per-m tap
-// broadcast (16 LDS reads for 2 channels) then feeds 4 x 62 FMAs instead of 62, and a thread
-// stores 16 contiguous bytes per output channel.  A workgroup covers 1024 positions.
-template <int N>
-__global__ __launch_bounds__(256) void fsmall4_kernel(const CorrArgs a, int M) {
-  constexpr int S = 4, Q = 4;
+// The same F form with FOUR consecutive output positions per thread (strides 4 and 2), the taps as
+// WAVE-UNIFORM SCALAR LOADS and the FMAs PACKED over pairs of output channels (round 6).  The layer is
+// VALU-bound: 62 FMAs per output on 1 - 2 input channels, 9.75 GFLOP per D call; scripts/micro/pkfma.hip
+// measures the issue peaks on this chip as 75 TF/s for v_fmac_f32 and 138 TF/s for v_pk_fma_f32 with an
+// SGPR-pair operand, and the former version (taps as 16-byte LDS broadcasts, v_fmac) ran at 57 TF/s.
+// A pass owns MC = 8 output channels; for every (n, k) the eight channels' taps are 32 contiguous bytes
+// of the packed F layout — one s_load_dwordx8 through the scalar cache — and feed 4 pairs x 4 positions
+// of v_pk_fma_f32: the two channels' taps are the instruction's SGPR pair, the input sample one half
+// of a VGPR pair broadcast to both lanes by op_sel.  A workgroup covers 1024 positions; LDS holds the
+// input window only.
+// RPT: the pitch of the packed weights when known at compile time (64: every SEGAN first layer has
+// <= 64 output channels; the 64 row offsets of a pass are then immediates of the s_loads instead of 64
+// loop-invariant products the compiler keeps live in SGPRs and spills) or 0 = runtime pitch.
+template <int S, int N, int RPT>
+__global__ __launch_bounds__(256) void fsmall4_kernel(const CorrArgs a, const float* __restrict__ wq,
+                                                      const float* __restrict__ bias, int M) {
+  static_assert(S == 2 || S == 4, "fsmall4: strides 2 and 4");
+  constexpr int Q = 4, U = 32 / S, MC = 8, CP = MC / 2;
   constexpr int XW = S * Q * 256 + 32;     // padded input samples a workgroup touches
-  constexpr int WST = N * 32 + 4;
-  constexpr int XR = S * (Q - 1) + 32;     // 44 input samples per thread and channel
+  constexpr int XR = (S * (Q - 1) + 32 + 3) / 4 * 4;     // 44 (40) input samples per thread and channel
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
   __shared__ __attribute__((aligned(16))) float xs[N][XW];
-  __shared__ __attribute__((aligned(16))) float ws[64 * WST];
   const int tid = threadIdx.x;
   const int b = blockIdx.y;
   const int t0 = blockIdx.x * (Q * 256);
   fsmall_stage_window<S, N, XW>(a, b, t0, tid, xs);
+  __syncthreads();
   const int t = t0 + Q * tid;
-  for (int m0 = 0; m0 < M; m0 += 64) {
-    fsmall_stage_weights<S, N, WST>(a, m0, tid, ws);
-    __syncthreads();
-    float xv[N][XR];
+  f32x2 xv[N][XR / 2];
 #pragma unroll
-    for (int n = 0; n < N; ++n)
+  for (int n = 0; n < N; ++n)
 #pragma unroll
-      for (int i = 0; i < XR / 4; ++i) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(&xs[n][S * Q * tid + 4 * i]);
-        xv[n][4 * i] = v[0]; xv[n][4 * i + 1] = v[1]; xv[n][4 * i + 2] = v[2]; xv[n][4 * i + 3] = v[3];
+    for (int i = 0; i < XR / 4; ++i) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(&xs[n][S * Q * tid + 4 * i]);
+      xv[n][2 * i] = f32x2{v[0], v[1]};
+      xv[n][2 * i + 1] = f32x2{v[2], v[3]};
+    }
+  const int RP = RPT ? RPT : a.RP;
+  const bool vec = (a.Lout & 3) == 0 && t + Q <= a.Lout;
+  // constant address space: a wave-uniform load from it is always an s_load (the global stores of the
+  // previous pass otherwise make the compiler fall back to per-lane global loads)
+  typedef const __attribute__((address_space(4))) f32x2 cf2;
+  // packed F layout: w[m][n][S*u + r] = wq[((n*S + r)*U + u) * RP + m]; rows of taps >= K and the
+  // columns M <= m < RP (a multiple of 64) hold zeros, so a pass may read past M
+  for (int m0 = 0; m0 < M; m0 += MC) {
+    f32x2 acc[CP][Q];
+#pragma unroll
+    for (int c = 0; c < CP; ++c) {
+      const int ma = m0 + 2 * c < M ? m0 + 2 * c : M - 1, mb = m0 + 2 * c + 1 < M ? m0 + 2 * c + 1 : M - 1;
+      const f32x2 bs = bias ? f32x2{bias[ma], bias[mb]} : f32x2{0.0f, 0.0f};
+#pragma unroll
+      for (int q = 0; q < Q; ++q) acc[c][q] = bs;
+    }
+    // a GROUP = four consecutive taps k = 4g .. 4g+3 of one input channel (four s_load_dwordx8, 32 SGPRs);
+    // two groups' registers alternate.  Scalar loads return out of order, so a wait for one group is a
+    // wait for everything outstanding: the next group's loads are issued right AFTER the wait for the
+    // current one (its first tap's FMAs) and fly during the remaining three taps' FMAs.  The scheduling
+    // barriers keep the compiler from hoisting all 8N groups to the top (it then spills SGPRs into
+    // VGPR lanes); the FMA is spelled in assembly to pin the operand classes (left alone, the SLP
+    // vectoriser packs the channels too, but on splatted copies of the 44 x N window registers).
+    f32x2 wa[4][CP], wb[4][CP];
+    auto ld = [&](f32x2 (&w)[4][CP], int g) {
+      const int n = g >> 3;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int k = 4 * (g & 7) + e;     // tap k = S*u + r
+        cf2* wr = (cf2*)(wq + m0) + (((n * S + k % S) * U + k / S) * RP >> 1);
+#pragma unroll
+        for (int c = 0; c < CP; ++c) w[e][c] = wr[c];
       }
-    const int mcn = min(64, M - m0);
-    for (int ml = 0; ml < mcn; ++ml) {
-      const float bs = a.bias ? a.bias[m0 + ml] : 0.0f;
-      float acc[Q] = {bs, bs, bs, bs};
+    };
+    auto fm = [&](const f32x2 (&w)[4][CP], int g, int e0, int e1) {
+      const int n = g >> 3;
 #pragma unroll
-      for (int n = 0; n < N; ++n) {
+      for (int e = e0; e < e1; ++e)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const f32x4 wv = *reinterpret_cast<const f32x4*>(&ws[ml * WST + n * 32 + 4 * i]);
+        for (int c = 0; c < CP; ++c)
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
+          for (int q = 0; q < Q; ++q) {
+            const int j = S * q + 4 * (g & 7) + e;     // sample x[S*q + k]: half (j & 1) of pair j / 2
+            if (j & 1)
+              asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]"
+                  : "+v"(acc[c][q]) : "s"(w[e][c]), "v"(xv[n][j >> 1]));
+            else
+              asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]"
+                  : "+v"(acc[c][q]) : "s"(w[e][c]), "v"(xv[n][j >> 1]));
+          }
+    };
+    ld(wa, 0);
 #pragma unroll
-            for (int q = 0; q < Q; ++q) acc[q] = fmaf(wv[e], xv[n][S * q + 4 * i + e], acc[q]);
-        }
-      }
-      float* o = a.out0 + ((size_t)b * M + m0 + ml) * a.Lout + t;
-      if (t + Q <= a.Lout && (a.Lout & 3) == 0) {
-        const f32x4 ov = {acc[0], acc[1], acc[2], acc[3]};
+    for (int g = 0; g < 8 * N; g += 2) {
+      fm(wa, g, 0, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      ld(wb, g + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      fm(wa, g, 1, 4);
+      fm(wb, g + 1, 0, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (g + 2 < 8 * N) ld(wa, g + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      fm(wb, g + 1, 1, 4);
+    }
+#pragma unroll
+    for (int c = 0; c < MC; ++c) {
+      if (m0 + c >= M) break;
+      float* o = a.out0 + ((size_t)b * M + m0 + c) * a.Lout + t;
+      if (vec) {
+        const f32x4 ov = {acc[c / 2][0][c & 1], acc[c / 2][1][c & 1], acc[c / 2][2][c & 1], acc[c / 2][3][c & 1]};
         *reinterpret_cast<f32x4*>(o) = ov;
       } else {
 #pragma unroll
         for (int q = 0; q < Q; ++q)
-          if (t + q < a.Lout) o[q] = acc[q];
+          if (t + q < a.Lout) o[q] = acc[c / 2][q][c & 1];
       }
     }
-    __syncthreads();
   }
 }
 
 int segan_launch_fsmall(CorrArgs& a, int M, int N, int S, hipStream_t st) {
   if (int e = segan_src_defaults(&a.in, st, "fsmall")) return e;
-  if (S == 4 && a.Lout >= 1024) {
+  if ((S == 4 || S == 2) && a.Lout >= 1024) {
     dim3 grid4(ceil_div(a.Lout, 1024), a.B);
-    if (N == 1) hipLaunchKernelGGL((fsmall4_kernel<1>), grid4, dim3(256), 0, st, a, M);
-    else hipLaunchKernelGGL((fsmall4_kernel<2>), grid4, dim3(256), 0, st, a, M);
+#define FS4(SS, NN, RR) hipLaunchKernelGGL((fsmall4_kernel<SS, NN, RR>), grid4, dim3(256), 0, st, a, a.wp, a.bias, M)
+    if (S == 4) {
+      if (a.RP == 64) { if (N == 1) FS4(4, 1, 64); else FS4(4, 2, 64); }
+      else { if (N == 1) FS4(4, 1, 0); else FS4(4, 2, 0); }
+    } else {
+      if (a.RP == 64) { if (N == 1) FS4(2, 1, 64); else FS4(2, 2, 64); }
+      else { if (N == 1) FS4(2, 1, 0); else FS4(2, 2, 0); }
+    }
+#undef FS4
     return segan_check_launch("fsmall4_kernel");
   }
   dim3 grid(ceil_div(a.Lout, 256), a.B);

@@ -352,6 +352,265 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 }
 
 // ====================================================================================
+// wgrad_edge_kernel: the same contraction for the long edge layers (1 - 2 channels on the hi side:
+// the first conv of G and of D, the last deconv of G) whose lo operand is a 150 - 630 MB stream read
+// exactly once — the layer is HBM-bound, and wgrad_kernel above (a 64 x 64 tile, both operands
+// staged through LDS in 32-column chunks with a barrier each) ran it at 2 - 6x the stream time.
+// Here a WAVE is a self-contained stream with no LDS and no barrier in its loop:
+//   * the contraction index is free to be permuted as long as both operands agree: MFMA s of a
+//     32-column step takes column t0 + 16h + s from half-wave h, so lane (row l31, half h) supplies
+//     lo[m][t0 + 16h .. + 15].  The lo tile of a step (32*RB rows x 128 bytes) is loaded with eight
+//     lanes per row — a full line per row and instruction — into the registers that are the prefetch
+//     buffer, and transposed to the fragment layout through a per-WAVE LDS tile (loaded in the
+//     fragment layout directly, 32 rows x 32 bytes per instruction, the L1 took ~100 cycles an
+//     instruction);
+//   * the hi operand of column c = (r, u) (tap k = S*u + r) at time t is x[n][S*t + k - padL]: the
+//     step's window of 32*S + 32 padded samples goes through a per-WAVE LDS buffer (1 - 3 coalesced
+//     loads per channel; padding, reflection, roll and the transform applied while staging) and the
+//     MFMA operands are ds_read_b32 at immediate offsets S*s off one lane address;
+//   * two register sets alternate: the next step's loads are issued before the current step's
+//     16 x RB x NN MFMAs.
+// A workgroup's four waves share a range of steps round-robin; at the end they add their tiles through LDS
+// in wave order and hand out the MB x 64 tile in the slab layout of wgrad_kernel (2 x 2 waves), so the
+// ordered reduction kernels (and the atomic epilogue) are shared.
+// RB: 32-row blocks (1, 2: tile of 64 rows; 4: 128 rows), NN: hi channels (1 - 2).
+// Preconditions (launcher): Ls % 32 == 0, N <= 2, M <= 32*RB.
+// ====================================================================================
+template <int U, int RB, int NN, bool LO_ID, bool HI_ID>
+__global__ __launch_bounds__(256, RB >= 4 ? 1 : 2) void wgrad_edge_kernel(const WgradArgs a, int spw) {
+  constexpr int S = 32 / U;
+  constexpr int MB = RB <= 2 ? 64 : 128;
+  constexpr int NIW = MB / 64;                 // row blocks a wave owns after the reduction
+  constexpr int NBLK = RB * NN;
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [4 waves][NBLK][16][64]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, h = lane >> 5;
+  const int k = S * (l31 % U) + l31 / U;       // tap of this lane's tile column
+  const int Ls = a.Ls, Lhi = a.Lhi;
+  const int spb = Ls >> 5;                     // steps per sample
+  const int nsteps = a.B * spb;
+  // a workgroup owns 4*spw consecutive steps, its waves take them ROUND-ROBIN: at any time the four
+  // waves read adjacent 128-byte pieces of the same rows (DRAM page locality)
+  constexpr int DEPTH = RB * NN >= 4 ? 1 : 2;
+  const int wg_beg = min(nsteps, (int)blockIdx.z * 4 * spw), wg_end = min(nsteps, wg_beg + 4 * spw);
+  const int cnt = wg_end - wg_beg > wave ? (wg_end - wg_beg - wave + 3) / 4 : 0;   // steps of this wave
+
+  f32x16 acc[RB][NN];
+#pragma unroll
+  for (int i = 0; i < RB; ++i)
+#pragma unroll
+    for (int j = 0; j < NN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+  // MFMA row of this lane (transform, row mask) ...
+  bool rok[RB];
+  ChanXf axf[RB];
+#pragma unroll
+  for (int i = 0; i < RB; ++i) {
+    const int m = 32 * i + l31;
+    rok[i] = m < a.M;
+    if (!LO_ID) axf[i] = segan_chan_xf(a.lo, rok[i] ? m : 0);
+  }
+  // ... and the rows it LOADS: instruction q of row block i covers rows 32i + 8q .. + 7, eight lanes
+  // per row (16 bytes each: one full 128-byte line per row and instruction)
+  const int lrow = lane >> 3, lpc = lane & 7;
+  int crow[RB][4];           // element offset of the row inside its segment's sample
+  bool cs1[RB][4];
+#pragma unroll
+  for (int i = 0; i < RB; ++i)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      int m = 32 * i + 8 * q + lrow;
+      m = m < a.M ? m : 0;
+      cs1[i][q] = m >= a.lo.C0;
+      crow[i][q] = (cs1[i][q] ? m - a.lo.C0 : m) * Ls;
+    }
+  const bool rows_full = (a.M & 31) == 0;
+  bool hs1[NN];
+  int hn[NN];
+  ChanXf bxf[NN];
+#pragma unroll
+  for (int j = 0; j < NN; ++j) {
+    const int n = j < a.N ? j : 0;
+    hs1[j] = n >= a.hi.C0;
+    hn[j] = hs1[j] ? n - a.hi.C0 : n;
+    if (!HI_ID) bxf[j] = segan_chan_xf(a.hi, n);
+  }
+
+  // hi window of a step: the 32*S + 32 padded samples S*t0 .. S*t0 + 32*S + 31 of each channel, staged
+  // per WAVE in LDS (no workgroup barrier: a wave's DS operations execute in order).  Read directly
+  // from global memory the hi operand was 16 dword loads per channel and step at tap-permuted lane
+  // addresses, and the kernel's time followed their count (42 cycles each per CU); the window is 1 - 3
+  // coalesced loads per channel, with the padding / reflection / roll index and the transform applied
+  // to 1 - 3 samples per lane instead of 16.
+  constexpr int XWIN = 32 * S + 32, XL = (XWIN + 63) / 64;
+  constexpr int WLDS = NN * XL * 64 + RB * 1024;      // floats of LDS per wave: windows, lo tile
+  float* win = red + wave * WLDS;
+  float* atile = win + NN * XL * 64;
+  struct Regs {
+    f32x4 A[RB][4];
+    float X[NN][XL];
+    unsigned xok;           // bit e = window sample lane + 64*e is a stored one (not an implicit zero)
+  };
+  // issues the loads of step st (nothing here reads a loaded value: no wait is forced; no branch
+  // around a load either — with loads inside the arms of a branch the compiler's wait counters merge
+  // conservatively and every step ends up waiting for the loads it has just issued)
+  auto load = [&](Regs& R, int st) {
+    const int b = st / spb;
+    const int t0 = (st - b * spb) << 5;
+    const float* sb0 = a.lo.p0 + (size_t)b * a.lo.C0 * Ls + t0 + 4 * lpc;
+    const float* sb1 = a.lo.p1 + (size_t)b * a.lo.C1 * Ls + t0 + 4 * lpc;
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        R.A[i][q] = *reinterpret_cast<const f32x4*>((cs1[i][q] ? sb1 : sb0) + crow[i][q]);
+    R.xok = 0u;
+    int off[XL];
+#pragma unroll
+    for (int e = 0; e < XL; ++e) {
+      const int pw = lane + 64 * e;
+      const int idx = segan_hi_index(S * t0 + pw, Lhi, a.padL, a.mode, a.roll);
+      const bool ok = pw < XWIN && idx >= 0;
+      if (ok) R.xok |= 1u << e;
+      off[e] = ok ? idx : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < NN; ++j) {
+      const float* q = hs1[j] ? a.hi.p1 + ((size_t)b * a.hi.C1 + hn[j]) * Lhi
+                              : a.hi.p0 + ((size_t)b * a.hi.C0 + hn[j]) * Lhi;
+#pragma unroll
+      for (int e = 0; e < XL; ++e) R.X[j][e] = q[off[e]];
+    }
+  };
+  // transforms and masks, the window through LDS, then the step's MFMAs
+  auto compute = [&](Regs& R) {
+    // lo: the coalesced pieces into the wave's [32*RB rows][32 columns] tile, the 16-byte column
+    // XOR-swizzled by the row (conflict-free both ways), and back as MFMA fragments: lane (row l31,
+    // half h) takes columns 16h .. 16h + 15
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<f32x4*>(atile + (32 * i + 8 * q + lrow) * 32 + 4 * (lpc ^ lrow)) = R.A[i][q];
+    f32x4 Af[RB][4];
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        Af[i][q] = *reinterpret_cast<const f32x4*>(atile + (32 * i + l31) * 32 + 4 * ((4 * h + q) ^ (l31 & 7)));
+    if (!LO_ID || !rows_full) {
+#pragma unroll
+      for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v = Af[i][q][e];
+            if (!LO_ID) v = segan_apply_xf(axf[i], v);
+            Af[i][q][e] = rok[i] ? v : 0.0f;
+          }
+    }
+#pragma unroll
+    for (int j = 0; j < NN; ++j)
+#pragma unroll
+      for (int e = 0; e < XL; ++e) {
+        float v = R.X[j][e];
+        if (!HI_ID) v = segan_apply_xf(bxf[j], v);
+        win[j * (XL * 64) + lane + 64 * e] = ((R.xok >> e) & 1u) ? v : 0.0f;
+      }
+    float Bv[NN][16];
+#pragma unroll
+    for (int j = 0; j < NN; ++j)
+#pragma unroll
+      for (int s2 = 0; s2 < 16; ++s2) Bv[j][s2] = win[j * (XL * 64) + S * (16 * h + s2) + k];
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2)
+#pragma unroll
+      for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int j = 0; j < NN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(Af[i][s2 >> 2][s2 & 3], Bv[j][s2],
+                                                           acc[i][j], 0, 0, 0);
+  };
+
+  if (cnt > 0) {
+    // the loads are unconditional (past the end: the last step again, unused) for the same reason.
+    // DEPTH register sets in flight ahead of the MFMAs: a wave's loads are 64 rows x 128 bytes at a
+    // 4*Ls-byte stride, and at one step ahead the stream ran at latency x bytes in flight (measured
+    // 2.6 us a step on the 16-row shape = 1.6 TB/s; 5.3 us on the 64-row one = 3.1 TB/s)
+    auto stp = [&](int i) { return wg_beg + 4 * min(i, cnt - 1) + wave; };
+    if (DEPTH == 1) {
+      Regs R0, R1;
+      load(R0, stp(0));
+      for (int i = 0; i < cnt; i += 2) {
+        load(R1, stp(i + 1));
+        compute(R0);
+        load(R0, stp(i + 2));
+        if (i + 1 < cnt) compute(R1);
+      }
+    } else {
+      Regs R0, R1, R2;
+      load(R0, stp(0));
+      load(R1, stp(1));
+      for (int i = 0; i < cnt; i += 3) {
+        load(R2, stp(i + 2));
+        compute(R0);
+        load(R0, stp(i + 3));
+        if (i + 1 < cnt) compute(R1);
+        load(R1, stp(i + 4));
+        if (i + 2 < cnt) compute(R2);
+      }
+    }
+  }
+
+  // ---- the four waves' tiles, added in wave order; wave (wm, wn) takes row blocks wm*NIW + ii,
+  // column block wn of the MB x 64 tile (the 2 x 2 layout of wgrad_kernel).  red[] overlays the
+  // windows: every wave is past its last step ----
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < RB; ++i)
+#pragma unroll
+    for (int j = 0; j < NN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) red[((wave * NBLK + i * NN + j) * 16 + e) * 64 + lane] = acc[i][j][e];
+  __syncthreads();
+  const int wm = wave >> 1, wn = wave & 1;
+  f32x16 out[NIW][1];
+#pragma unroll
+  for (int ii = 0; ii < NIW; ++ii) {
+    const int rb = wm * NIW + ii;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      float sum = 0.0f;
+      if (rb < RB && wn < NN) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) sum += red[((w * NBLK + rb * NN + wn) * 16 + e) * 64 + lane];
+      }
+      out[ii][0][e] = sum;
+    }
+  }
+  if (a.w2_slabs) {
+    wgrad_slab_store<NIW, 1>(a.w2_slabs + (size_t)blockIdx.z * (MB * 64), out, tid);
+    return;
+  }
+  const int cc = wn * 32 + l31;
+  const int cv = cc / U, u = cc % U;
+  const int n = cv / S, r = cv % S;
+  const int kk = S * u + r;
+  if (cv >= a.Cv || kk >= a.K) return;
+#pragma unroll
+  for (int ii = 0; ii < NIW; ++ii)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int m = wm * (MB / 2) + 32 * ii + (e & 3) + 8 * (e >> 2) + 4 * h;
+      if (m < a.M) atomicAdd(a.dw + ((size_t)m * a.N + n) * a.K + kk, out[ii][0][e]);
+    }
+}
+
+// ====================================================================================
 // wgrad2_kernel: the same contraction for the big layers (128 x 128 block tiles) with a
 // staging path that leaves the matrix pipe alone (cost model: head of segan_conv.hip).
 //   * lo (always identity here: the launcher materialises a transformed or two-segment lo
@@ -852,8 +1111,89 @@ static int launch_wgrad_tile(WgradArgs& a, hipStream_t st, float* slabs, size_t 
   return SEGAN_OK;
 }
 
+// ---- wgrad_edge launch ----
+static bool wgrad_edge_geometry_ok(const WgradArgs& a, int U) {
+  if (a.Cv > 64 / U || a.N > 2) return false;          // 1 - 2 channels on the hi side
+  if (a.Ls % 32 != 0) return false;
+  if (a.M > 128 || (a.M > 64 && a.N > 1)) return false;
+  return true;
+}
+
+template <int U, int RB, int NN, bool LO_ID, bool HI_ID>
+static int launch_wgrad_edge_tile(WgradArgs& a, hipStream_t st, float* slabs, size_t slab_floats) {
+  constexpr int MB = RB <= 2 ? 64 : 128;
+  if ((long)a.B * a.M * a.Ls >= (1L << 31) || (long)a.B * a.N * a.Lhi >= (1L << 31)) {
+    segan_set_error("wgrad: operand exceeds the 2^31 element indexing limit");
+    return SEGAN_EUNSUPPORTED;
+  }
+  if (int e = segan_src_defaults(&a.lo, st, "wgrad(lo)")) return e;
+  if (int e = segan_src_defaults(&a.hi, st, "wgrad(hi)")) return e;
+  // a wave per range of 32-column steps: two workgroups per CU, at least 8 steps per wave; the
+  // decomposition depends on the geometry alone (deterministic mode)
+  const int nsteps = a.B * (a.Ls / 32);
+  // workgroups per CU: the register budget (__launch_bounds__ of the kernel).  Measured: 3 - 4 per CU
+  // for the 32-row instances (they fit) change nothing
+  constexpr int OCC = RB >= 4 ? 1 : 2;
+  int nwg = ceil_div(nsteps, 4 * 8);
+  if (nwg > 256 * OCC) nwg = 256 * OCC;
+  const int spw = ceil_div(nsteps, 4 * nwg);
+  nwg = ceil_div(nsteps, 4 * spw);
+  a.w2_slabs = nullptr;
+  if (nwg == 1) slabs = nullptr;         // one tile: every dw element is touched exactly once
+  if (slabs) {
+    if (slab_floats < (size_t)nwg * MB * 64) {
+      segan_set_error("wgrad: deterministic mode needs %zu bytes of scratch for the partial tiles",
+                      (size_t)nwg * MB * 64 * sizeof(float));
+      return SEGAN_EINVAL;
+    }
+    a.w2_slabs = slabs;
+  }
+  g_last_wgrad[0] = 4; g_last_wgrad[1] = 1; g_last_wgrad[2] = nwg; g_last_wgrad[3] = spw;
+  g_last_wgrad[4] = 0; g_last_wgrad[5] = 0;
+  constexpr int XL = (32 * (32 / U) + 32 + 63) / 64;
+  const size_t lds_red = (size_t)4 * RB * NN * 1024 * sizeof(float);
+  const size_t lds_win = (size_t)4 * (NN * XL * 64 + RB * 1024) * sizeof(float);
+  const size_t lds = lds_red > lds_win ? lds_red : lds_win;
+  auto kern = wgrad_edge_kernel<U, RB, NN, LO_ID, HI_ID>;
+  static bool attr_done[16];
+  const int d = wg_cur_device();
+  if (!attr_done[d]) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done[d] = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(1, 1, nwg), dim3(256), lds, st, a, spw);
+  if (int e = segan_check_launch("wgrad_edge_kernel")) return e;
+  if (slabs) {
+    int zstep = 1;
+    if (nwg >= 128) {
+      zstep = 32;
+      hipLaunchKernelGGL((wgrad_group_kernel<MB, 64>), dim3(1, 1, ceil_div(nwg, zstep)), dim3(256), 0,
+                         st, slabs, nwg, zstep);
+      if (int e = segan_check_launch("wgrad_group_kernel")) return e;
+    }
+    hipLaunchKernelGGL((wgrad_reduce_kernel<U, MB, 64>), dim3(1, 1), dim3(256), 0, st, a, nwg, zstep);
+    return segan_check_launch("wgrad_reduce_kernel");
+  }
+  return SEGAN_OK;
+}
+
+template <int U, bool LO_ID, bool HI_ID>
+static int launch_wgrad_edge(WgradArgs& a, hipStream_t st, float* slabs, size_t slab_floats) {
+  if (a.N == 1) {
+    if (a.M <= 32) return launch_wgrad_edge_tile<U, 1, 1, LO_ID, HI_ID>(a, st, slabs, slab_floats);
+    if (a.M <= 64) return launch_wgrad_edge_tile<U, 2, 1, LO_ID, HI_ID>(a, st, slabs, slab_floats);
+    return launch_wgrad_edge_tile<U, 4, 1, LO_ID, HI_ID>(a, st, slabs, slab_floats);
+  }
+  if (a.M <= 32) return launch_wgrad_edge_tile<U, 1, 2, LO_ID, HI_ID>(a, st, slabs, slab_floats);
+  return launch_wgrad_edge_tile<U, 2, 2, LO_ID, HI_ID>(a, st, slabs, slab_floats);
+}
+
 template <int U, bool LO_ID, bool HI_ID>
 static int launch_wgrad_x(WgradArgs& a, hipStream_t st, float* slabs, size_t slab_floats) {
+  // long edge layers: the streaming kernel
+  static const bool edge_on = getenv("SEGAN_WGRAD_EDGE") == nullptr || atoi(getenv("SEGAN_WGRAD_EDGE")) != 0;
+  if (edge_on && wgrad_edge_geometry_ok(a, U)) return launch_wgrad_edge<U, LO_ID, HI_ID>(a, st, slabs, slab_floats);
   // edge layers (1-2 channels on the hi side: N*S <= 64/U virtual channels): 64 columns
   // suffice, and 64 rows when M <= 64
   if (a.Cv <= 64 / U) {

@@ -452,6 +452,13 @@ EDGE_CONV = [
     # long enough for the 4-positions-per-thread edge kernel (L/4 + 8 >= 1024)
     (2, 2, 64, 8192, 4, 31, 3),
     (3, 1, 16, 4112, 4, 31, -7),
+    # the same kernel at stride 2 (vanilla11's first layer), with a pitch > 64 (M = 70: runtime-pitch
+    # instance), an odd channel count inside a pass of 8, and a short kernel in the 32-tap layout
+    (2, 1, 16, 4096, 2, 31, 0),
+    (2, 2, 16, 2104, 2, 31, -3),
+    (2, 2, 70, 4096, 4, 31, 1),
+    (2, 1, 13, 2048, 2, 31, 2),
+    (2, 2, 11, 4096, 4, 7, 0),
 ]
 
 
@@ -918,6 +925,89 @@ def test_stride2_conv_layers_take_the_small_row_tiles(name, N, M, L, roll, B):
     npt = 16 if N <= 16 else 32 if N <= 32 else 64
     assert info_t['tiles'] == -(-N // npt) * -(-tcols // (256 if N <= 16 else 128))     # the 16-channel T tile: 256 columns
     assert info_w['tiles'] == -(-N * S // (128 // 16)) * 1       # one row tile of 32 / 64 rows
+
+
+@pytest.mark.parametrize('kind,B,M,N,Ls,S,roll', [
+    # conv: lo = grad of the pre-activation (plain), hi = the 1 - 2 channel input, reflect padding
+    ('conv', 3, 64, 2, 1024, 4, 0),          # D first layer: 2 x 2 MFMA blocks
+    ('conv', 3, 64, 1, 1024, 4, 0),          # G first layer
+    ('conv', 2, 64, 2, 512, 4, -37),         # rolled input (the discriminator's phase shift)
+    ('conv', 3, 16, 1, 2048, 2, 0),          # 11-layer shape: 16 rows of a 32-row block
+    ('conv', 2, 16, 2, 2048, 2, 5),
+    ('conv', 2, 40, 1, 256, 4, 0),           # rows 40 of 64, few steps per wave
+    ('conv', 1, 64, 2, 32, 4, 0),            # one step per sample: every step touches both paddings
+    # deconv: lo = the layer input in two segments with PReLU / alpha on load, hi = dy, zero padding
+    ('deconv', 2, 128, 1, 1024, 4, 0),       # G last layer: 4 row blocks
+    ('deconv', 2, 64, 1, 2048, 2, 0),
+    ('deconv', 2, 24, 2, 512, 4, 0),
+])
+def test_long_edge_weight_gradients_stream(kind, B, M, N, Ls, S, roll):
+    """The weight gradient of the long 1 - 2 channel edge layers runs on wgrad_edge_kernel (record
+    kind 4: a wave per range of 32-column steps, no barrier in the loop) — against torch fp64, atomics
+    and slabs, the latter bit-reproducible; a length that is not a multiple of 32 still takes the
+    tiled kernel (kind 1)."""
+    ops = _ops()
+    K = 31
+    if kind == 'conv':
+        L = S * Ls
+        x = rnd(B, N, L, seed=41)
+        w = rnd(M, N, K, seed=42, scale=0.05)
+        xd = x.double()
+        wd = w.double().requires_grad_(True)
+        ref = conv_ref(xd, wd, None, S, roll)
+        da = rnd(*ref.shape, seed=43)
+        ref.backward(da.double())
+        lo, hi = ops.Src(da.to(DEV)), ops.Src(x.to(DEV))
+        padL, mode = ops.conv_pad(K, S)[0], ops.PAD_REFLECT
+        shape = (M, N, K)
+    else:
+        M0 = M // 2
+        x0, x1 = rnd(B, M0, Ls, seed=44), rnd(B, M - M0, Ls, seed=45)
+        scale = torch.cat((torch.ones(M0), rnd(M - M0, seed=46)))
+        slope = torch.cat((rnd(M0, seed=47).abs() * 0.3, torch.ones(M - M0)))
+        w = rnd(M, N, K, seed=48, scale=0.05)
+        xin = xform_ref(torch.cat((x0, x1), 1), scale, None, slope)
+        wd = w.double().requires_grad_(True)
+        pad = ops.deconv_pad(K, S)
+        ref = F.conv_transpose1d(xin, wd, None, stride=S, padding=pad)[:, :, :S * Ls]
+        dy = rnd(*ref.shape, seed=49)
+        ref.backward(dy.double())
+        lo = ops.Src(x0.to(DEV), x1.to(DEV), scale=scale.to(DEV), slope=slope.to(DEV))
+        hi = ops.Src(dy.to(DEV))
+        padL, mode = pad, ops.PAD_ZERO
+        shape = (M, N, K)
+    for det in (False, True):
+        ops.set_deterministic(det)
+        try:
+            dw = torch.zeros(shape, device=DEV)
+            ops.wgrad(lo, hi, dw, K, S, padL, mode, roll=roll)
+            info = ops.last_wgrad_launch()
+            assert info['kernel'] == 4, info
+            assert max_rel(dw, wd.grad) < TOL, (det, info)
+            if det:
+                dw2 = torch.zeros(shape, device=DEV)
+                ops.wgrad(lo, hi, dw2, K, S, padL, mode, roll=roll)
+                assert torch.equal(dw, dw2)
+                # accumulates into dw like torch accumulates .grad
+                ops.wgrad(lo, hi, dw2, K, S, padL, mode, roll=roll)
+                assert max_rel(dw2, 2 * wd.grad) < TOL
+        finally:
+            ops.set_deterministic(False)
+
+
+def test_edge_weight_gradient_of_a_ragged_length_takes_the_tiled_kernel():
+    ops = _ops()
+    B, M, N, Ls, S, K = 2, 64, 2, 300, 4, 31
+    x = rnd(B, N, S * Ls, seed=51)
+    w = rnd(M, N, K, seed=52, scale=0.05)
+    wd = w.double().requires_grad_(True)
+    ref = conv_ref(x.double(), wd, None, S, 0)
+    da = rnd(*ref.shape, seed=53)
+    ref.backward(da.double())
+    dw = torch.zeros((M, N, K), device=DEV)
+    ops.wgrad(ops.Src(da.to(DEV)), ops.Src(x.to(DEV)), dw, K, S, ops.conv_pad(K, S)[0], ops.PAD_REFLECT)
+    assert ops.last_wgrad_launch()['kernel'] == 1
+    assert max_rel(dw, wd.grad) < TOL
 
 
 @pytest.mark.parametrize('name,M0,M1,N,Ls,B', [('v11.dec7', 64, 64, 32, 1024, 40), ('v11.dec8', 32, 32, 32, 2048, 40),
