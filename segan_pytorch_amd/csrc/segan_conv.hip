@@ -180,7 +180,7 @@ __device__ __forceinline__ void corr_store_tile(
           for (int e = 0; e < 16; ++e) {
             const int rl = 32 * i + (e & 3) + 8 * (e >> 2);
             float bs = 0.0f;
-            if (a.bias) bs = a.bias[m0 + 32 * wm * NI + 4 * h + rl];
+            if (a.bias) bs = epi_bias(a.bias, m0 + 32 * wm * NI, rl, h);
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
               __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[i][j][e] + bs), ors,
@@ -233,7 +233,7 @@ __device__ __forceinline__ void corr_store_tile(
       for (int e = 0; e < 16; ++e) {
         const int nl = (e & 3) + 8 * (e >> 2);
         float bs = 0.0f;
-        if (a.bias) bs = a.bias[n0 + 4 * h + nl];
+        if (a.bias) bs = epi_bias(a.bias, n0, nl, h);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
           typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
@@ -276,7 +276,7 @@ __device__ __forceinline__ void corr_store_tile(
       for (int e = 0; e < 16; ++e) {
         const int nl = (e & 3) + 8 * (e >> 2);
         float bs = 0.0f;
-        if (a.bias) bs = a.bias[n0 + 4 * h + nl];
+        if (a.bias) bs = epi_bias(a.bias, n0, nl, h);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
           typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
@@ -324,7 +324,7 @@ __device__ __forceinline__ void corr_store_tile(
         for (int e = 0; e < NE; ++e) {
           const int nl = 32 * bk + (e & 3) + 8 * (e >> 2);
           float bs = 0.0f;
-          if (a.bias) bs = a.bias[n0 + 4 * h + nl];
+          if (a.bias) bs = epi_bias(a.bias, n0, nl, h);
 #pragma unroll
           for (int j = 0; j < NJ; ++j) {
             typedef unsigned u32x2s __attribute__((ext_vector_type(2)));

@@ -167,7 +167,7 @@ __device__ __forceinline__ void bf2_store_tile(const CorrArgs& a,
         for (int e = 0; e < 16; ++e) {
           const int rl = 32 * i + (e & 3) + 8 * (e >> 2);
           float bs = 0.0f;
-          if (a.bias && add_bias) bs = a.bias[m0 + 32 * wm * NI + 4 * h + rl];
+          if (a.bias && add_bias) bs = epi_bias(a.bias, m0 + 32 * wm * NI, rl, h);
 #pragma unroll
           for (int j = 0; j < NJ; ++j)
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[i][j][e] + bs), ors,
@@ -216,7 +216,7 @@ __device__ __forceinline__ void bf2_store_tile(const CorrArgs& a,
       for (int e = 0; e < 16; ++e) {
         const int nl = (e & 3) + 8 * (e >> 2);
         float bs = 0.0f;
-        if (a.bias && add_bias) bs = a.bias[n0 + 4 * h + nl];
+        if (a.bias && add_bias) bs = epi_bias(a.bias, n0, nl, h);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
           const u32x4 o = {__builtin_bit_cast(unsigned, acc[0][j][e] + bs),
@@ -261,7 +261,7 @@ __device__ __forceinline__ void bf2_store_tile(const CorrArgs& a,
       for (int e = 0; e < 16; ++e) {
         const int nl = (e & 3) + 8 * (e >> 2);
         float bs = 0.0f;
-        if (a.bias && add_bias) bs = a.bias[n0 + 4 * h + nl];
+        if (a.bias && add_bias) bs = epi_bias(a.bias, n0, nl, h);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
           const u32x4 o = {__builtin_bit_cast(unsigned, acc[0 % NI][j][e] + bs),

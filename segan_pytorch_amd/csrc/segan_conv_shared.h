@@ -131,6 +131,19 @@ struct WgradArgs {
   float* w2_slabs;        // deterministic mode: partial tiles [split][row tile][col tile]
 };
 
+// Bias of a lane's row in the fast epilogues: row base + rl0 for half-wave 0, base + rl0 + 4 for
+// half-wave 1.  Read as WAVE-UNIFORM SCALAR loads (both candidates, selected by the lane's half): a
+// per-lane global load here sits BETWEEN the tile's stores, and since loads and stores retire through
+// the same in-order counter every such load waited for all the stores issued before it (global_load -
+// s_waitcnt vmcnt(0) - two stores, 16 x NI times per tile: that many serialized store round trips at
+// every tile end).  Found in round 6; the "~60 us per whole-tile round" of DESIGN.md 5.2.
+__device__ __forceinline__ float epi_bias(const float* bias, int base, int rl0, int h) {
+  typedef const __attribute__((address_space(4))) float cfloat;
+  cfloat* bp = (cfloat*)bias + base;
+  const float lo = bp[rl0], hi = bp[rl0 + 4];
+  return h ? hi : lo;
+}
+
 // packed-weight geometry (shared by the pack kernels and the launchers)
 static inline int f_pitch(int M) { return M <= 64 ? 64 : round_up(M, 128); }
 static inline int f_rows(int N) { return round_up(N * 32, KCH); }
