@@ -571,7 +571,7 @@ __global__ __launch_bounds__(256, 2) void corr_kernel(const CorrArgs a) {
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, h = lane >> 5;
 
@@ -1015,7 +1015,7 @@ __global__ __launch_bounds__(256) void corr_fixup_kernel(const CorrArgs a) {
   using G = TileGeom<MB, NB, WM, U>;
   constexpr int WN = G::WN, NI = G::NI, NJ = G::NJ, NPT = G::NPT;
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: scalar bias loads (epi_bias)
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, h = lane >> 5;
   const int nch = (a.Ktot + KC - 1) / KC;

@@ -658,7 +658,7 @@ __global__ __launch_bounds__(256) void bf2_fixup_kernel(const CorrArgs a, int ns
   constexpr int NJ = NB / (32 * WN);
   constexpr int NPT = MB / S;
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, h = lane >> 5;
   const int t = blockIdx.x;

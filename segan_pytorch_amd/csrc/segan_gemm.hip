@@ -180,21 +180,38 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const float* __restrict
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wn * 64 + 32 * j + l31;
+      const int mb = m0 + wm * 64 + 32 * i + 4 * h;
+      if (!slabs && !atomic) {
+        // unsplit: C += acc.  All 16 loads of the block before its first store: a load issued after a
+        // store waits for that store (one in-order counter) — element by element this was 64 dependent
+        // read-modify-write round trips per thread
+        float old[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = mb + (e & 3) + 8 * (e >> 2);
+          old[e] = (m < M && n < N) ? C[(long)m * ldc + n] : 0.0f;
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = mb + (e & 3) + 8 * (e >> 2);
+          if (m < M && n < N) C[(long)m * ldc + n] = old[e] + acc[i][j][e];
+        }
+        continue;
+      }
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int m = m0 + wm * 64 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
-        const int n = n0 + wn * 64 + 32 * j + l31;
+        const int m = mb + (e & 3) + 8 * (e >> 2);
         if (m < M && n < N) {
           if (slabs) {      // deterministic split-K: this split's partial, added in split order later
             slabs[((size_t)blockIdx.z * M + m) * N + n] = acc[i][j][e];
             continue;
           }
-          float* c = C + (long)m * ldc + n;
-          if (atomic) atomicAdd(c, acc[i][j][e]);
-          else *c += acc[i][j][e];
+          atomicAdd(C + (long)m * ldc + n, acc[i][j][e]);
         }
       }
+    }
 }
 
 // C (+)= sum over the contraction splits, in split order (bit-reproducible)

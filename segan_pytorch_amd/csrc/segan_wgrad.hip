@@ -92,13 +92,22 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs a, in
     const int n = cv / S, r = cv % S;
     const int k = S * u + r;
     if (cv >= a.Cv || k >= a.K) continue;
+    // dw += sum.  All loads of a block before its first store (a load after a store waits for it: one
+    // in-order counter — element by element these were 16 x NI x NJ dependent round trips per thread)
 #pragma unroll
-    for (int i = 0; i < NI; ++i)
+    for (int i = 0; i < NI; ++i) {
+      float old[16];
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int m = m0 + wm * (MB / WM) + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (m < a.M) a.dw[((size_t)m * a.N + n) * a.K + k] += acc[i][j][e];
+        old[e] = m < a.M ? a.dw[((size_t)m * a.N + n) * a.K + k] : 0.0f;
       }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * (MB / WM) + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (m < a.M) a.dw[((size_t)m * a.N + n) * a.K + k] = old[e] + acc[i][j][e];
+      }
+    }
   }
 }
 
