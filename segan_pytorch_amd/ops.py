@@ -29,9 +29,11 @@ def set_deterministic(on):
     """Bit-reproducible mode.  The forward / data-gradient contractions always are reproducible
     (their stream-K tail is reduced in a fixed order); this switch makes the weight gradients and
     the dense-head GEMMs reduce their contraction splits in a fixed order too (slabs + a second
-    kernel) instead of with fp32 atomics.  Measured cost since round 3: 0.6 - 2.2 % of the step, 0.4 % at the end of round 6
-    (round 2: 11 %) — just above the 1 % at which it would have become the default, so it stays
-    opt-in: ``set_deterministic(True)`` / SEGAN_DETERMINISTIC=1 / train.py --deterministic.  (The
+    kernel) instead of with fp32 atomics.  Measured cost: 11 % of the step in round 2, 0.6 - 2.2 % in
+    rounds 3 - 5, 0.4 % at the end of round 6 (one box; the ordered reductions now issue their loads
+    before their stores) — the first reading below the 1 % at which it would become the default, so
+    it stays opt-in until that holds across boxes: ``set_deterministic(True)`` /
+    SEGAN_DETERMINISTIC=1 / train.py --deterministic.  (The
     bf16 / bf16x3 weight gradients always add their splits with atomics.)"""
     global _deterministic
     _deterministic = bool(on)
